@@ -1,0 +1,198 @@
+/*
+ * xsi_hip.h — C ABI of the MI355X-native xSqueezeIt genotype-block codec (libxsi_hip.so).
+ *
+ * This is the drop-in boundary for the reference's per-block hot path.  Plain C, caller-owned
+ * buffers, int return codes (0 = ok, <0 = error; text via xsi_hip_last_error()), no exceptions
+ * and no torch / C++ types in any signature.  Pointers named d_* are DEVICE pointers (HBM),
+ * pointers named h_* are HOST pointers.  All device work is enqueued on the context's HIP
+ * stream; calls that return host-visible results synchronise that stream themselves.
+ *
+ * What each group replaces in the reference (paths relative to the reference tree):
+ *   - block encode   : GtBlock::encode_line + write_to_stream (include/gt_block.hpp:279-406,
+ *                      185-204, 512-647), wah_encode2_with_size (include/wah.hpp:441-578),
+ *                      pbwt_sort (include/internal_gt_record.hpp:32-59), Sparse/SparseGtLine
+ *                      (include/block.hpp:54-99), IBinaryBlock::write_to_file
+ *                      (include/interfaces.hpp:176-268) and the per-block part of
+ *                      XsiFactoryExt::append/finalize_file (include/xsi_factory.hpp:513-606).
+ *   - block decode   : DecompressPointerGTBlock (include/accessor_internals_new.hpp:49-717) and
+ *                      AccessorInternalsNewTemplate::fill_genotype_array / fill_allele_counts
+ *                      (include/accessor_internals_new.hpp:719-906).
+ *   - writer/accessor: XsiFactoryInterface::append/finalize_file (include/xsi_factory.hpp:38-46)
+ *                      and Accessor::fill_genotype_array / get_genotypes (include/accessor.hpp:48-67),
+ *                      i.e. what c_xcf_get_genotypes (include/c_api.h:82-83) lands on.
+ * The reference-side bindings are shown in INTEGRATION.md.
+ */
+#ifndef XSI_HIP_H
+#define XSI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XSI_HIP_ABI_VERSION 1
+
+/* error codes */
+#define XSI_OK 0
+#define XSI_ERR_ARG (-1)       /* bad argument */
+#define XSI_ERR_HIP (-2)       /* HIP runtime error (no device, launch failure, ...) */
+#define XSI_ERR_CAPACITY (-3)  /* caller-provided output buffer too small */
+#define XSI_ERR_FORMAT (-4)    /* bad magic / version / corrupt block */
+#define XSI_ERR_UNSUPPORTED (-5)
+#define XSI_ERR_IO (-6)
+
+typedef struct xsi_hip_ctx xsi_hip_ctx;
+
+int xsi_hip_abi_version(void);
+/* Thread-local text of the last error returned on this thread. */
+const char* xsi_hip_last_error(void);
+
+/* Create a context on `device` using `stream` (a hipStream_t passed as void*, NULL = the
+ * context creates its own).  Fails with XSI_ERR_HIP when no GPU is present: there is no
+ * CPU fallback anywhere in this library. */
+int xsi_hip_ctx_create(xsi_hip_ctx** ctx, int device, void* stream);
+void xsi_hip_ctx_destroy(xsi_hip_ctx* ctx);
+int xsi_hip_ctx_synchronize(xsi_hip_ctx* ctx);
+/* Bytes of device workspace currently held by the context. */
+uint64_t xsi_hip_ctx_workspace_bytes(const xsi_hip_ctx* ctx);
+
+/* Parameters of one encode job (the arguments of XsiFactoryExt's constructor that reach
+ * GtBlock: include/xsi_factory.hpp:439-449, include/gt_block.hpp:159-181). */
+typedef struct xsi_encode_params {
+    uint32_t n_samples;          /* samples; haplotype columns = 2*n_samples (diploid lines) */
+    uint32_t block_len;          /* BCF lines per block (--variant-block-length, 8192) */
+    uint32_t mac_threshold;      /* (size_t)(n_samples*ploidy*MAF), gt_compressor_new.hpp:98-99 */
+    int32_t default_phased;      /* 0/1, xcf.cpp:811-836 */
+    uint32_t wah_encode_missing; /* 0 = WS_SPARSE (default), 1 = WS_WAH (--wah-encode-missing) */
+    uint32_t reserved;
+} xsi_encode_params;
+
+/* Result of an encode call (host struct, filled after the stream is synchronised). */
+typedef struct xsi_encode_result {
+    uint64_t n_blocks;      /* blocks written */
+    uint64_t blocks_bytes;  /* bytes of the blocks region (each block padded to 4, region not yet padded to 8) */
+    uint64_t n_binary_lines;
+    uint64_t n_wah_lines;
+    uint32_t max_ploidy;    /* max line ploidy seen (for finalize_file(max_ploidy)) */
+    uint32_t reserved;
+} xsi_encode_result;
+
+/* Upper bound of the blocks region for a job, for sizing d_out. */
+uint64_t xsi_hip_encode_bound(const xsi_encode_params* p, uint64_t n_bcf_lines, uint64_t n_binary_lines);
+
+/*
+ * Encode bi-allelic, diploid, fully called genotypes from a bit-packed site-major matrix
+ * resident in HBM: row l = BCF line l, bit h (LSB-first within little-endian 32-bit words) =
+ * 1 iff haplotype h carries ALT.  row_stride_bytes must be a multiple of 8; bits >= 2*n_samples
+ * in a row must be zero.  Phase: every second allele carries p->default_phased.
+ *
+ * Writes the blocks region of the .xsi file (what lies between byte 256 and indices_offset,
+ * before the pad to 8) to d_out[0..blocks_bytes) and the file offset of every block
+ * (256 + offset in d_out) to d_block_offsets[0..n_blocks).  Byte-identical to what the
+ * reference writes for the same lines.
+ */
+int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const void* d_bits,
+                          uint64_t n_lines, uint32_t row_stride_bytes, void* d_out, uint64_t out_capacity,
+                          uint64_t* d_block_offsets, xsi_encode_result* h_result);
+
+/*
+ * General encode from htslib-encoded int32 genotype rows resident in HBM (what
+ * bcf_get_genotypes hands GtBlock::encode_line): row l at d_gt + l*gt_stride (int32 units),
+ * h_ngt[l] values used (n_samples or 2*n_samples), h_n_allele[l] alleles (>= 2).
+ * Handles multi-allelic lines, missing, end-of-vector, non-default phase and haploid lines.
+ */
+int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_t* d_gt, uint64_t gt_stride,
+                      uint64_t n_lines, const uint32_t* h_ngt, const uint32_t* h_n_allele, void* d_out,
+                      uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result);
+
+/* Fill a complete 256-byte .xsi v5 header (include/compression.hpp:40-104 as written by
+ * xsi_factory.hpp:468-500, 543-605).  Host-only helper, no device work. */
+typedef struct xsi_header_fields {
+    uint32_t n_samples;
+    uint32_t max_ploidy;
+    uint32_t block_len;
+    uint32_t mac_threshold;
+    int32_t default_phased;
+    uint32_t zstd;
+    uint64_t num_variants;   /* sum over lines of (n_allele-1) */
+    uint64_t xcf_entries;    /* BCF lines */
+    uint64_t indices_offset;
+    uint64_t samples_offset;
+} xsi_header_fields;
+int xsi_hip_make_header(const xsi_header_fields* f, uint8_t h_header[256]);
+
+/*
+ * Decode.  d_file is a complete .xsi image in HBM (header, blocks, index).  Blocks
+ * [first_block, first_block+n_blocks) are decoded.
+ *
+ * xsi_hip_decode_packed: every BCF line of those blocks must be bi-allelic and diploid without
+ * side channels; output row r (r counts binary lines from the first decoded block) is the
+ * natural-order haplotype bit row, same layout as xsi_hip_encode_packed's input.
+ * h_counts (optional, may be NULL): ALT allele count per row.
+ */
+int xsi_hip_decode_packed(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block,
+                          uint64_t n_blocks, void* d_bits_out, uint32_t row_stride_bytes, uint64_t out_rows_capacity,
+                          uint64_t* h_rows_written, uint32_t* d_counts);
+
+/*
+ * xsi_hip_decode_gt: general decode to htslib int32 rows, what Accessor::fill_genotype_array
+ * writes (include/accessor_internals_new.hpp:198-384).  h_n_allele[l] for every BCF line l of
+ * the decoded blocks (the reference takes it from the variant BCF record, accessor.hpp:66).
+ * Row l at d_gt_out + l*gt_stride; h_line_ngt[l] (optional) receives the value count of the
+ * line (N_HAPS or N_SAMPLES); d_allele_counts (optional) receives max_alleles counts per line.
+ */
+int xsi_hip_decode_gt(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block,
+                      uint64_t n_blocks, const uint32_t* h_n_allele, uint64_t n_lines, int32_t* d_gt_out,
+                      uint64_t gt_stride, uint32_t* h_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles);
+
+/* Deterministic synthetic haplotype matrix: writes n_lines packed rows starting
+ * at site index first_line.  Generator defined in DESIGN.md; mirrored in numpy for the tests. */
+int xsi_hip_synth_packed(xsi_hip_ctx* ctx, uint64_t seed, uint64_t first_line, uint64_t n_lines, uint32_t n_haps,
+                         void* d_bits, uint32_t row_stride_bytes);
+
+/* ---- per-stage entry points used by the parity tests to localise a mismatch ---- */
+/* PBWT chain only: permuted bit rows y (one per WAH line, ordered) for the given packed input. */
+int xsi_hip_debug_chain_encode(xsi_hip_ctx* ctx, const xsi_encode_params* p, const void* d_bits, uint64_t n_lines,
+                               uint32_t row_stride_bytes, void* d_yrows, uint32_t y_stride_bytes,
+                               uint32_t* d_line_kind, uint64_t* h_n_wah);
+
+/* ---- host-side writer / accessor (file level), mirroring XsiFactoryInterface and Accessor ---- */
+typedef struct xsi_writer xsi_writer;
+typedef struct xsi_accessor xsi_accessor;
+
+/* XsiFactoryExt(filename, block_len, mac_thr, default_phased, sample_list, zstd=false)
+ * (include/xsi_factory.hpp:439-511).  sample_names: n_samples C strings. */
+int xsi_writer_open(xsi_writer** w, xsi_hip_ctx* ctx, const char* path, const xsi_encode_params* p,
+                    const char* const* sample_names);
+/* XsiFactoryInterface::append(bcf_fri): one BCF line, host int32 row (bcf_fri.gt_arr), ngt values,
+ * n_allele = bcf_fri.line->n_allele.  Lines are batched per block and encoded on the GPU. */
+int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t n_allele);
+/* XsiFactoryInterface::finalize_file(max_ploidy); max_ploidy = 0 -> use the maximum seen. */
+int xsi_writer_finalize(xsi_writer* w, uint32_t max_ploidy);
+void xsi_writer_close(xsi_writer* w);
+
+/* Accessor(filename) (accessor.cpp:26-82). */
+int xsi_accessor_open(xsi_accessor** a, xsi_hip_ctx* ctx, const char* path);
+/* Accessor::fill_genotype_array(gt_arr, gt_arr_size, n_alleles, position) (accessor.hpp:48-50):
+ * position = BM value (block<<15 | binary-line offset).  Returns the number of values written
+ * (N_HAPS or N_SAMPLES) or <0. */
+int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_t gt_size, uint32_t n_alleles,
+                                         uint64_t position);
+/* Accessor::get_genotypes without the htslib record: mallocs *h_gt when NULL (hap_samples ints),
+ * sets *ngt_arr = hap_samples (accessor.hpp:58-67). */
+int64_t xsi_accessor_get_genotypes(xsi_accessor* a, uint32_t n_alleles, uint64_t position, void** h_gt,
+                                   int* ngt_arr);
+/* Accessor::get_allele_counts after a fill (accessor.hpp:56). */
+int xsi_accessor_allele_counts(xsi_accessor* a, uint64_t* h_counts, uint32_t n_alleles);
+uint64_t xsi_accessor_hap_samples(const xsi_accessor* a);
+uint64_t xsi_accessor_num_samples(const xsi_accessor* a);
+/* Accessor::get_sample_list()[i] */
+const char* xsi_accessor_sample_name(const xsi_accessor* a, uint64_t i);
+void xsi_accessor_close(xsi_accessor* a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XSI_HIP_H */

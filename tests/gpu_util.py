@@ -1,0 +1,121 @@
+"""Helpers for the -m gpu parity tests: device buffers via torch, calls through the C ABI."""
+import ctypes
+import struct
+
+import numpy as np
+
+from xsqueezeit_amd import binding, synth
+
+
+def torch_mod():
+    import torch
+    return torch
+
+
+_CTX = None
+
+
+def ctx():
+    global _CTX
+    if _CTX is None:
+        torch = torch_mod()
+        assert torch.cuda.is_available(), "GPU tests need a GPU"
+        torch.cuda.init()
+        _CTX = binding.Context(0, torch.cuda.current_stream().cuda_stream)
+    return _CTX
+
+
+def dev_u8(arr):
+    torch = torch_mod()
+    return torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).cuda()
+
+
+def dev_empty(nbytes):
+    torch = torch_mod()
+    return torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
+
+
+def params(n_samples, block_len=8192, mac_thr=0, default_phased=1, wah_encode_missing=0):
+    return binding.EncodeParams(n_samples, block_len, mac_thr, default_phased, wah_encode_missing, 0)
+
+
+def encode_packed(packed, n_haps, p):
+    """packed: uint8 [n_lines, stride].  Returns (blocks_region bytes, block_offsets, result)."""
+    torch = torch_mod()
+    L = binding.lib()
+    n_lines, stride = packed.shape
+    d_bits = dev_u8(packed)
+    cap = int(L.xsi_hip_encode_bound(ctypes.byref(p), n_lines, n_lines))
+    d_out = dev_empty(cap)
+    n_blocks = (n_lines + p.block_len - 1) // p.block_len
+    d_off = torch.zeros(n_blocks, dtype=torch.int64, device="cuda")
+    res = binding.EncodeResult()
+    binding.check(L.xsi_hip_encode_packed(ctx().handle, ctypes.byref(p), d_bits.data_ptr(), n_lines, stride,
+                                          d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)))
+    region = d_out[:res.blocks_bytes].cpu().numpy().tobytes()
+    return region, d_off.cpu().numpy().astype(np.uint64), res
+
+
+def assemble_file(region, offsets, p, n_lines, num_variants, sample_names, max_ploidy=2):
+    """Host-side rest of XsiFactoryExt::finalize_file (xsi_factory.hpp:558-605) around a GPU-made
+    blocks region: pad to 8, u64 index, sample names, header."""
+    body = bytearray(region)
+    while (256 + len(body)) % 8:
+        body.append(0)
+    indices_offset = 256 + len(body)
+    body += np.asarray(offsets, dtype="<u8").tobytes()
+    samples_offset = 256 + len(body)
+    for s in sample_names:
+        body += s.encode() + b"\0"
+    hf = binding.HeaderFields(p.n_samples, max_ploidy, p.block_len, p.mac_threshold, p.default_phased, 0,
+                              num_variants, n_lines, indices_offset, samples_offset)
+    hdr = (ctypes.c_uint8 * 256)()
+    binding.check(binding.lib().xsi_hip_make_header(ctypes.byref(hf), hdr))
+    return bytes(hdr) + bytes(body)
+
+
+def decode_packed(file_bytes, n_haps, stride, first_block=0, n_blocks=None, max_rows=None):
+    torch = torch_mod()
+    L = binding.lib()
+    d_file = dev_u8(np.frombuffer(file_bytes, dtype=np.uint8))
+    if n_blocks is None:
+        io, so = struct.unpack_from("<QQ", file_bytes, 72)
+        n_blocks = (so - io) // 8 - first_block
+    if max_rows is None:
+        max_rows = struct.unpack_from("<Q", file_bytes, 40)[0]
+    d_out = dev_empty(max_rows * stride)
+    d_cnt = torch.zeros(max_rows, dtype=torch.int32, device="cuda")
+    rows = ctypes.c_uint64(0)
+    binding.check(L.xsi_hip_decode_packed(ctx().handle, d_file.data_ptr(), len(file_bytes), first_block, n_blocks,
+                                          d_out.data_ptr(), stride, max_rows, ctypes.byref(rows), d_cnt.data_ptr()))
+    n = rows.value
+    out = d_out[:n * stride].cpu().numpy().reshape(n, stride)
+    return out, d_cnt[:n].cpu().numpy()
+
+
+def oracle_file_from_bits(bits01, p, sample_names=None):
+    from oracle import oracle
+    n_samples = bits01.shape[1] // 2
+    w = oracle.Writer(n_samples, p.block_len, p.mac_threshold, p.default_phased, bool(p.wah_encode_missing),
+                      sample_names)
+    gt = synth.bits_to_gt(bits01, p.default_phased)
+    for r in gt:
+        w.append(r, 2)
+    return w.finalize(2)
+
+
+def numpy_chain_yrows(bits01, block_len, mac_thr):
+    """Reference PBWT chain in numpy: list of (line, permuted bits) for the WAH lines."""
+    n_lines, N = bits01.shape
+    out = []
+    a = None
+    for l in range(n_lines):
+        if l % block_len == 0:
+            a = np.arange(N)
+        x = bits01[l]
+        c = int(x.sum())
+        if min(c, N - c) > mac_thr:
+            y = x[a]
+            out.append((l, y.copy()))
+            a = np.concatenate([a[y == 0], a[y == 1]])
+    return out

@@ -1,0 +1,11 @@
+"""xsqueezeit_amd — MI355X-native genotype-block codec for xSqueezeIt's .xsi format.
+
+The product is the C-ABI shared library ``libxsi_hip.so`` (see ``include/xsi_hip.h``), built
+from the hand-written gfx950 HIP kernels under ``csrc/``.  This package is the thin Python
+host side: a ctypes binding (``binding``), the file-level writer/accessor mirrors of the
+reference's ``XsiFactoryInterface`` / ``Accessor`` (``host``), the synthetic workload generator
+(``synth``) and a GT-only VCF reader (``vcf_lite``).  There is no CPU fallback: importing
+``binding`` without the built library, or creating a context without a GPU, raises.
+"""
+
+__version__ = "0.1.0"

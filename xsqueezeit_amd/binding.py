@@ -1,0 +1,153 @@
+"""ctypes binding of libxsi_hip.so (include/xsi_hip.h).  Raises if the library is missing."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxsi_hip.so")
+
+XSI_OK = 0
+XSI_ERR_ARG = -1
+XSI_ERR_HIP = -2
+XSI_ERR_CAPACITY = -3
+XSI_ERR_FORMAT = -4
+XSI_ERR_UNSUPPORTED = -5
+XSI_ERR_IO = -6
+
+
+class XsiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("xsi_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class EncodeParams(ctypes.Structure):
+    _fields_ = [("n_samples", ctypes.c_uint32), ("block_len", ctypes.c_uint32), ("mac_threshold", ctypes.c_uint32),
+                ("default_phased", ctypes.c_int32), ("wah_encode_missing", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
+
+
+class EncodeResult(ctypes.Structure):
+    _fields_ = [("n_blocks", ctypes.c_uint64), ("blocks_bytes", ctypes.c_uint64),
+                ("n_binary_lines", ctypes.c_uint64), ("n_wah_lines", ctypes.c_uint64),
+                ("max_ploidy", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+class HeaderFields(ctypes.Structure):
+    _fields_ = [("n_samples", ctypes.c_uint32), ("max_ploidy", ctypes.c_uint32), ("block_len", ctypes.c_uint32),
+                ("mac_threshold", ctypes.c_uint32), ("default_phased", ctypes.c_int32), ("zstd", ctypes.c_uint32),
+                ("num_variants", ctypes.c_uint64), ("xcf_entries", ctypes.c_uint64),
+                ("indices_offset", ctypes.c_uint64), ("samples_offset", ctypes.c_uint64)]
+
+
+# every symbol include/xsi_hip.h declares; tests check the library exports all of them
+SYMBOLS = [
+    "xsi_hip_abi_version", "xsi_hip_last_error", "xsi_hip_ctx_create", "xsi_hip_ctx_destroy",
+    "xsi_hip_ctx_synchronize", "xsi_hip_ctx_workspace_bytes", "xsi_hip_encode_bound", "xsi_hip_encode_packed",
+    "xsi_hip_encode_gt", "xsi_hip_make_header", "xsi_hip_decode_packed", "xsi_hip_decode_gt",
+    "xsi_hip_synth_packed", "xsi_hip_debug_chain_encode", "xsi_writer_open", "xsi_writer_append",
+    "xsi_writer_finalize", "xsi_writer_close", "xsi_accessor_open", "xsi_accessor_fill_genotype_array",
+    "xsi_accessor_get_genotypes", "xsi_accessor_allele_counts", "xsi_accessor_hap_samples",
+    "xsi_accessor_num_samples", "xsi_accessor_sample_name", "xsi_accessor_close",
+]
+
+_LIB = None
+
+
+def lib():
+    """Load libxsi_hip.so.  No fallback: a missing library is an error."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, u64, u32, i32 = c.c_void_p, c.c_uint64, c.c_uint32, c.c_int32
+    L.xsi_hip_abi_version.restype = c.c_int
+    L.xsi_hip_last_error.restype = c.c_char_p
+    L.xsi_hip_ctx_create.restype = c.c_int
+    L.xsi_hip_ctx_create.argtypes = [c.POINTER(vp), c.c_int, vp]
+    L.xsi_hip_ctx_destroy.restype = None
+    L.xsi_hip_ctx_destroy.argtypes = [vp]
+    L.xsi_hip_ctx_synchronize.restype = c.c_int
+    L.xsi_hip_ctx_synchronize.argtypes = [vp]
+    L.xsi_hip_ctx_workspace_bytes.restype = u64
+    L.xsi_hip_ctx_workspace_bytes.argtypes = [vp]
+    L.xsi_hip_encode_bound.restype = u64
+    L.xsi_hip_encode_bound.argtypes = [c.POINTER(EncodeParams), u64, u64]
+    L.xsi_hip_encode_packed.restype = c.c_int
+    L.xsi_hip_encode_packed.argtypes = [vp, c.POINTER(EncodeParams), vp, u64, u32, vp, u64, vp,
+                                        c.POINTER(EncodeResult)]
+    L.xsi_hip_encode_gt.restype = c.c_int
+    L.xsi_hip_encode_gt.argtypes = [vp, c.POINTER(EncodeParams), vp, u64, u64, vp, vp, vp, u64, vp,
+                                    c.POINTER(EncodeResult)]
+    L.xsi_hip_make_header.restype = c.c_int
+    L.xsi_hip_make_header.argtypes = [c.POINTER(HeaderFields), vp]
+    L.xsi_hip_decode_packed.restype = c.c_int
+    L.xsi_hip_decode_packed.argtypes = [vp, vp, u64, u64, u64, vp, u32, u64, c.POINTER(u64), vp]
+    L.xsi_hip_decode_gt.restype = c.c_int
+    L.xsi_hip_decode_gt.argtypes = [vp, vp, u64, u64, u64, vp, u64, vp, u64, vp, vp, u32]
+    L.xsi_hip_synth_packed.restype = c.c_int
+    L.xsi_hip_synth_packed.argtypes = [vp, u64, u64, u64, u32, vp, u32]
+    L.xsi_hip_debug_chain_encode.restype = c.c_int
+    L.xsi_hip_debug_chain_encode.argtypes = [vp, c.POINTER(EncodeParams), vp, u64, u32, vp, u32, vp,
+                                             c.POINTER(u64)]
+    L.xsi_writer_open.restype = c.c_int
+    L.xsi_writer_open.argtypes = [c.POINTER(vp), vp, c.c_char_p, c.POINTER(EncodeParams), c.POINTER(c.c_char_p)]
+    L.xsi_writer_append.restype = c.c_int
+    L.xsi_writer_append.argtypes = [vp, vp, u32, u32]
+    L.xsi_writer_finalize.restype = c.c_int
+    L.xsi_writer_finalize.argtypes = [vp, u32]
+    L.xsi_writer_close.restype = None
+    L.xsi_writer_close.argtypes = [vp]
+    L.xsi_accessor_open.restype = c.c_int
+    L.xsi_accessor_open.argtypes = [c.POINTER(vp), vp, c.c_char_p]
+    L.xsi_accessor_fill_genotype_array.restype = c.c_int64
+    L.xsi_accessor_fill_genotype_array.argtypes = [vp, vp, u64, u32, u64]
+    L.xsi_accessor_get_genotypes.restype = c.c_int64
+    L.xsi_accessor_get_genotypes.argtypes = [vp, u32, u64, c.POINTER(vp), c.POINTER(c.c_int)]
+    L.xsi_accessor_allele_counts.restype = c.c_int
+    L.xsi_accessor_allele_counts.argtypes = [vp, vp, u32]
+    L.xsi_accessor_hap_samples.restype = u64
+    L.xsi_accessor_hap_samples.argtypes = [vp]
+    L.xsi_accessor_num_samples.restype = u64
+    L.xsi_accessor_num_samples.argtypes = [vp]
+    L.xsi_accessor_sample_name.restype = c.c_char_p
+    L.xsi_accessor_sample_name.argtypes = [vp, u64]
+    L.xsi_accessor_close.restype = None
+    L.xsi_accessor_close.argtypes = [vp]
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        raise XsiError(rc, lib().xsi_hip_last_error().decode(errors="replace"))
+    return rc
+
+
+class Context:
+    """One per process / GPU.  `stream` is a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device=0, stream=None):
+        h = ctypes.c_void_p()
+        check(lib().xsi_hip_ctx_create(ctypes.byref(h), device, ctypes.c_void_p(stream) if stream else None))
+        self.handle = h
+
+    def synchronize(self):
+        check(lib().xsi_hip_ctx_synchronize(self.handle))
+
+    def workspace_bytes(self):
+        return int(lib().xsi_hip_ctx_workspace_bytes(self.handle))
+
+    def close(self):
+        if self.handle:
+            lib().xsi_hip_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,507 @@
+// xsi_api.hip — C ABI of libxsi_hip.so (include/xsi_hip.h): context, workspace, and the
+// launch sequences of the encode / decode pipelines.  No CPU fallback: every entry point that
+// does codec work needs a context, and a context needs a GPU.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/xsi_hip.h"
+#include "xsi_ctx.hpp"
+#include "xsi_kernels.hpp"
+
+using namespace xsi;
+
+namespace xsi {
+static thread_local std::string g_err;
+int set_error(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+}  // namespace xsi
+
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) return set_error(XSI_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                               __FILE__, __LINE__);                                          \
+    } while (0)
+
+extern "C" {
+
+int xsi_hip_abi_version(void) { return XSI_HIP_ABI_VERSION; }
+const char* xsi_hip_last_error(void) { return g_err.c_str(); }
+
+int xsi_hip_ctx_create(xsi_hip_ctx** out, int device, void* stream) {
+    if (!out) return set_error(XSI_ERR_ARG, "ctx_create: null out pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_error(XSI_ERR_HIP, "no HIP device available (%s); this library has no CPU fallback",
+                         e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return set_error(XSI_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(XSI_ERR_HIP, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
+    xsi_hip_ctx* c = new xsi_hip_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = reinterpret_cast<hipStream_t>(stream);
+        c->owns_stream = false;
+    } else {
+        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            delete c;
+            return set_error(XSI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
+        }
+        c->owns_stream = true;
+    }
+    *out = c;
+    return XSI_OK;
+}
+
+void xsi_hip_ctx_destroy(xsi_hip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->bufs)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int xsi_hip_ctx_synchronize(xsi_hip_ctx* c) {
+    if (!c) return set_error(XSI_ERR_ARG, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return XSI_OK;
+}
+
+uint64_t xsi_hip_ctx_workspace_bytes(const xsi_hip_ctx* c) {
+    uint64_t t = 0;
+    if (c)
+        for (auto& kv : c->bufs) t += kv.second.cap;
+    return t;
+}
+
+uint64_t xsi_hip_encode_bound(const xsi_encode_params* p, uint64_t n_bcf_lines, uint64_t n_binary_lines) {
+    if (!p || !p->block_len) return 0;
+    const uint64_t N = 2ull * p->n_samples;
+    const uint64_t aet = p->n_samples <= 65535u ? 2 : 4;
+    const uint64_t n_blocks = (n_bcf_lines + p->block_len - 1) / p->block_len;
+    const uint64_t G = (N + 14) / 15;
+    // per binary line: a WAH line of at most G words, or a sparse list of at most 1 + thr (+1) entries
+    uint64_t per_line = G * 2;
+    const uint64_t sp = (2ull + p->mac_threshold) * aet;
+    if (sp > per_line) per_line = sp;
+    // side channels per BCF line (general path): missing + EOV lists and a phase WAH line
+    const uint64_t side = 2 * (1 + N) * aet + G * 2;
+    // per block: outer dict 16, GT dict 8 + 18*8, five flag vectors, pad
+    const uint64_t per_block = 16 + 8 + 18 * 8 + 5ull * FLAG_WORDS_MAX * 2 + 4;
+    return n_blocks * per_block + n_binary_lines * per_line + (n_binary_lines ? 0 : 0) + 0 * side;
+}
+
+int xsi_hip_make_header(const xsi_header_fields* f, uint8_t h[256]) {
+    if (!f || !h) return set_error(XSI_ERR_ARG, "make_header: null argument");
+    memset(h, 0, 256);
+    auto put = [&](size_t off, uint64_t v, int bytes) {
+        for (int i = 0; i < bytes; ++i) h[off + i] = (uint8_t)(v >> (8 * i));
+    };
+    // header_t, compression.hpp:40-104, as filled by xsi_factory.hpp:468-500, 543-605
+    put(0, 0xaabbccddu, 4);
+    put(4, 0xfeed1767u, 4);
+    put(8, 5, 4);
+    h[12] = (uint8_t)f->max_ploidy;
+    h[13] = 4;  // ind_bytes = sizeof(uint32_t) (stale: the v5 index is u64)
+    h[14] = ((uint64_t)f->n_samples * 2 <= 65535u) ? 2 : 4;  // gt_compressor_new.hpp:177-187
+    h[15] = 2;
+    h[16] = (uint8_t)((f->default_phased ? 1 : 0) << 2);
+    h[17] = (uint8_t)(1u | (f->zstd ? 4u : 0u));
+    put(32, (uint64_t)f->n_samples * f->max_ploidy, 8);
+    put(40, f->num_variants, 8);
+    put(48, 0, 4);
+    put(52, 1, 4);
+    put(56, f->block_len, 4);
+    put(60, f->block_len ? (uint32_t)((f->xcf_entries + f->block_len - 1) / f->block_len) : 0, 4);
+    put(64, 256, 8);
+    put(72, f->indices_offset, 8);
+    put(80, f->samples_offset, 8);
+    put(88, 0xFFFFFFFFu, 4);
+    put(92, 0xFFFFFFFFu, 4);
+    put(96, f->mac_threshold, 4);
+    put(100, f->xcf_entries, 8);
+    put(108, 0, 4);
+    put(112, f->n_samples, 8);
+    put(252, 0xfeed1767u, 4);
+    return XSI_OK;
+}
+
+}  // extern "C"
+
+namespace xsi {
+
+int ws_ensure(xsi_hip_ctx* c, const char* name, size_t bytes, void** out) {
+    auto& b = c->bufs[name];
+    if (b.cap < bytes) {
+        // growing a buffer that queued work may still read: drain the stream first
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return set_error(XSI_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+        const size_t want = bytes + bytes / 8 + 256;
+        e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) return set_error(XSI_ERR_HIP, "hipMalloc(%zu) for %s: %s", want, name, hipGetErrorString(e));
+        b.cap = want;
+    }
+    *out = b.p;
+    return XSI_OK;
+}
+
+int pinned_ensure(xsi_hip_ctx* c, size_t bytes, void** out) {
+    if (c->pinned_cap < bytes) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return set_error(XSI_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr;
+        c->pinned_cap = 0;
+        e = hipHostMalloc(&c->pinned, bytes + 4096, hipHostMallocDefault);
+        if (e != hipSuccess) return set_error(XSI_ERR_HIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        c->pinned_cap = bytes + 4096;
+    }
+    *out = c->pinned;
+    return XSI_OK;
+}
+
+#define WS(ptr, name, bytes)                                                        \
+    do {                                                                            \
+        void* _p;                                                                   \
+        int _rc = ws_ensure(ctx, name, (bytes), &_p);                               \
+        if (_rc) return _rc;                                                        \
+        ptr = reinterpret_cast<decltype(ptr)>(_p);                                  \
+    } while (0)
+
+// Shared tail of both encode entry points: everything after the per-line bit planes, counts
+// and kinds exist.  Lines/side describe the batch; blocks_h holds the host-filled part.
+int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide S, std::vector<EncBlock>& blocks_h,
+               void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n_blocks = (uint32_t)blocks_h.size();
+    const uint32_t n_bin = L.n_bin;
+    const uint32_t N = L.N;
+
+    EncBlock* d_blocks;
+    WS(d_blocks, "enc.blocks", sizeof(EncBlock) * (size_t)n_blocks);
+    WS(L.line_block, "enc.line_block", 4ull * n_bin);
+    WS(L.wah_rank, "enc.wah_rank", 4ull * n_bin);
+    WS(L.sparse_off, "enc.sparse_off", 4ull * n_bin);
+    WS(L.wah_lines, "enc.wah_lines", 4ull * n_bin);
+    WS(L.wah_len, "enc.wah_len", 4ull * n_bin);
+    WS(L.wah_off, "enc.wah_off", 4ull * n_bin);
+    L.y_stride64 = (N + 63u) / 64u;
+    WS(L.yrows, "enc.yrows", 8ull * L.y_stride64 * (size_t)n_bin);
+    WS(L.flagbits, "enc.flagbits", 4ull * (MAX_BIN_PER_BLOCK / 32) * FV_COUNT * (size_t)n_blocks);
+    WS(L.flagwah, "enc.flagwah", 2ull * FLAG_WORDS_MAX * FV_COUNT * (size_t)n_blocks);
+    uint32_t* d_totals;
+    WS(d_totals, "enc.totals", 64);
+    uint64_t* d_result;
+    WS(d_result, "enc.result", 64);
+    uint32_t* scratch_a = nullptr;
+    const ChainGeom g = chain_geometry(N, false);
+    if (!g.in_lds) WS(scratch_a, "chain.a", 4ull * 2ull * (((size_t)N + 63u) & ~(size_t)63u) * n_blocks);
+
+    HIP_TRY(hipMemcpyAsync(d_blocks, blocks_h.data(), sizeof(EncBlock) * (size_t)n_blocks, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_classify(s, d_blocks, n_blocks, L));
+    HIP_TRY(launch_scan_blocks_wah(s, d_blocks, n_blocks, d_totals));
+    HIP_TRY(launch_build_wah_list(s, d_blocks, n_blocks, L));
+    HIP_TRY(launch_chain_encode(s, d_blocks, n_blocks, L, scratch_a));
+    HIP_TRY(launch_wah_sizes(s, L, d_totals, n_bin));
+    HIP_TRY(launch_block_layout(s, d_blocks, n_blocks, L, S, p->default_phased));
+    HIP_TRY(launch_scan_blocks_out(s, d_blocks, n_blocks, out_capacity, d_block_offsets, d_result));
+    const uint32_t strategy = p->wah_encode_missing ? WS_WAH : WS_SPARSE;
+    HIP_TRY(launch_write_headers(s, d_blocks, n_blocks, L, p->default_phased, strategy, (uint8_t*)d_out, d_result));
+    HIP_TRY(launch_wah_write(s, d_blocks, L, n_bin, (uint8_t*)d_out, d_result));
+    HIP_TRY(launch_sparse_write(s, d_blocks, L, (uint8_t*)d_out, d_result));
+    if (S.bcf_flags) {
+        int rc = encode_side_write(ctx, d_blocks, n_blocks, L, S, (uint8_t*)d_out, d_result);
+        if (rc) return rc;
+    }
+    uint64_t res[4];
+    HIP_TRY(hipMemcpyAsync(res, d_result, sizeof(res), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (res[3]) return set_error(XSI_ERR_CAPACITY, "encode: output needs %llu bytes, capacity is %llu",
+                                 (unsigned long long)res[0], (unsigned long long)out_capacity);
+    if (h_result) {
+        h_result->n_blocks = n_blocks;
+        h_result->blocks_bytes = res[0];
+        h_result->n_binary_lines = n_bin;
+        h_result->n_wah_lines = res[2];
+        h_result->max_ploidy = 2;
+        h_result->reserved = 0;
+    }
+    return XSI_OK;
+}
+
+}  // namespace xsi
+
+extern "C" {
+
+int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const void* d_bits, uint64_t n_lines,
+                          uint32_t row_stride_bytes, void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets,
+                          xsi_encode_result* h_result) {
+    if (!ctx || !p || !d_bits || !d_out) return set_error(XSI_ERR_ARG, "encode_packed: null argument");
+    if (!p->n_samples || !p->block_len) return set_error(XSI_ERR_ARG, "encode_packed: n_samples and block_len must be > 0");
+    if (p->block_len > MAX_BIN_PER_BLOCK)
+        return set_error(XSI_ERR_ARG, "block_len %u exceeds the BM offset range (%u binary lines per block)", p->block_len,
+                         MAX_BIN_PER_BLOCK);
+    const uint64_t N64 = 2ull * p->n_samples;
+    if (row_stride_bytes % 8u || (uint64_t)row_stride_bytes * 8u < N64)
+        return set_error(XSI_ERR_ARG, "row_stride_bytes %u must be a multiple of 8 and hold %llu bits", row_stride_bytes,
+                         (unsigned long long)N64);
+    if (n_lines == 0 || n_lines > 0x7FFFFFFFull) return set_error(XSI_ERR_ARG, "n_lines %llu out of range", (unsigned long long)n_lines);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t N = (uint32_t)N64;
+    const uint32_t n_bin = (uint32_t)n_lines;
+    const uint32_t n_blocks = (uint32_t)((n_lines + p->block_len - 1) / p->block_len);
+    std::vector<EncBlock> blocks(n_blocks);
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        memset(&blocks[b], 0, sizeof(EncBlock));
+        blocks[b].first_bcf = blocks[b].first_bin = b * p->block_len;
+        const uint64_t left = n_lines - (uint64_t)b * p->block_len;
+        blocks[b].n_bcf = blocks[b].n_bin = (uint32_t)(left < p->block_len ? left : p->block_len);
+    }
+    EncLines L{};
+    L.planes = reinterpret_cast<const uint32_t*>(d_bits);
+    L.plane_stride_w = row_stride_bytes / 4u;
+    L.n_bin = n_bin;
+    L.N = N;
+    L.aet = p->n_samples <= 65535u ? 2u : 4u;  // xsi_factory.hpp:424-427
+    L.thr = p->mac_threshold;
+    WS(L.cnt, "enc.cnt", 4ull * n_bin);
+    WS(L.kind, "enc.kind", (size_t)n_bin);
+    HIP_TRY(hipMemsetAsync(L.kind, 0, n_bin, s));
+    HIP_TRY(launch_count_rows(s, L.planes, L.plane_stride_w, N, n_bin, L.cnt));
+    EncSide S{};
+    return encode_run(ctx, p, L, S, blocks, d_out, out_capacity, d_block_offsets, h_result);
+}
+
+int xsi_hip_debug_chain_encode(xsi_hip_ctx* ctx, const xsi_encode_params* p, const void* d_bits, uint64_t n_lines,
+                               uint32_t row_stride_bytes, void* d_yrows, uint32_t y_stride_bytes, uint32_t* d_line_kind,
+                               uint64_t* h_n_wah) {
+    if (!ctx || !p || !d_bits || !d_yrows) return set_error(XSI_ERR_ARG, "debug_chain_encode: null argument");
+    const uint32_t N = 2u * p->n_samples;
+    if (y_stride_bytes % 8u || y_stride_bytes * 8ull < (((uint64_t)N + 63u) & ~63ull))
+        return set_error(XSI_ERR_ARG, "y_stride_bytes too small");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t n_bin = (uint32_t)n_lines;
+    const uint32_t n_blocks = (uint32_t)((n_lines + p->block_len - 1) / p->block_len);
+    std::vector<EncBlock> blocks(n_blocks);
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        memset(&blocks[b], 0, sizeof(EncBlock));
+        blocks[b].first_bcf = blocks[b].first_bin = b * p->block_len;
+        const uint64_t left = n_lines - (uint64_t)b * p->block_len;
+        blocks[b].n_bcf = blocks[b].n_bin = (uint32_t)(left < p->block_len ? left : p->block_len);
+    }
+    EncLines L{};
+    L.planes = reinterpret_cast<const uint32_t*>(d_bits);
+    L.plane_stride_w = row_stride_bytes / 4u;
+    L.n_bin = n_bin;
+    L.N = N;
+    L.aet = p->n_samples <= 65535u ? 2u : 4u;
+    L.thr = p->mac_threshold;
+    EncBlock* d_blocks;
+    WS(d_blocks, "enc.blocks", sizeof(EncBlock) * (size_t)n_blocks);
+    WS(L.cnt, "enc.cnt", 4ull * n_bin);
+    WS(L.kind, "enc.kind", (size_t)n_bin);
+    WS(L.line_block, "enc.line_block", 4ull * n_bin);
+    WS(L.wah_rank, "enc.wah_rank", 4ull * n_bin);
+    WS(L.sparse_off, "enc.sparse_off", 4ull * n_bin);
+    WS(L.wah_lines, "enc.wah_lines", 4ull * n_bin);
+    WS(L.flagbits, "enc.flagbits", 4ull * (MAX_BIN_PER_BLOCK / 32) * FV_COUNT * (size_t)n_blocks);
+    uint32_t* d_totals;
+    WS(d_totals, "enc.totals", 64);
+    L.yrows = reinterpret_cast<uint64_t*>(d_yrows);
+    L.y_stride64 = y_stride_bytes / 8u;
+    uint32_t* scratch_a = nullptr;
+    if (!chain_geometry(N, false).in_lds) WS(scratch_a, "chain.a", 4ull * 2ull * (((size_t)N + 63u) & ~(size_t)63u) * n_blocks);
+    HIP_TRY(hipMemsetAsync(L.kind, 0, n_bin, s));
+    HIP_TRY(hipMemcpyAsync(d_blocks, blocks.data(), sizeof(EncBlock) * (size_t)n_blocks, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_count_rows(s, L.planes, L.plane_stride_w, N, n_bin, L.cnt));
+    HIP_TRY(launch_classify(s, d_blocks, n_blocks, L));
+    HIP_TRY(launch_scan_blocks_wah(s, d_blocks, n_blocks, d_totals));
+    HIP_TRY(launch_build_wah_list(s, d_blocks, n_blocks, L));
+    HIP_TRY(launch_chain_encode(s, d_blocks, n_blocks, L, scratch_a));
+    uint32_t tot[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(tot, d_totals, 4, hipMemcpyDeviceToHost, s));
+    if (d_line_kind) {
+        // widen kinds to uint32 on the host side of the test: copy raw bytes
+        HIP_TRY(hipMemcpyAsync(d_line_kind, L.kind, n_bin, hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h_n_wah) *h_n_wah = tot[0];
+    return XSI_OK;
+}
+
+int xsi_hip_decode_packed(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block,
+                          uint64_t n_blocks64, void* d_bits_out, uint32_t row_stride_bytes, uint64_t out_rows_capacity,
+                          uint64_t* h_rows_written, uint32_t* d_counts) {
+    if (!ctx || !d_file || !d_bits_out) return set_error(XSI_ERR_ARG, "decode_packed: null argument");
+    if (file_len < 256) return set_error(XSI_ERR_FORMAT, "file image shorter than the 256-byte header");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DecodePlan P;
+    int rc = decode_prepare(ctx, d_file, file_len, first_block, n_blocks64, &P);
+    if (rc) return rc;
+    if (row_stride_bytes % 8u || (uint64_t)row_stride_bytes * 8u < P.L.N)
+        return set_error(XSI_ERR_ARG, "row_stride_bytes %u must be a multiple of 8 and hold %u bits", row_stride_bytes, P.L.N);
+    if (P.n_bin > out_rows_capacity)
+        return set_error(XSI_ERR_CAPACITY, "decode_packed: %u rows, capacity %llu", P.n_bin, (unsigned long long)out_rows_capacity);
+    if (P.has_side)
+        return set_error(XSI_ERR_UNSUPPORTED, "decode_packed: blocks carry missing / end-of-vector / phase / haploid data; use xsi_hip_decode_gt");
+    if (P.n_bin != P.n_bcf)
+        return set_error(XSI_ERR_UNSUPPORTED, "decode_packed: multi-allelic lines present; use xsi_hip_decode_gt");
+    uint32_t* out = reinterpret_cast<uint32_t*>(d_bits_out);
+    const uint32_t stride_w = row_stride_bytes / 4u;
+    rc = decode_planes(ctx, d_file, P, out, stride_w, /*apply_negation=*/1);
+    if (rc) return rc;
+    if (d_counts) HIP_TRY(hipMemcpyAsync(d_counts, P.L.ones, 4ull * P.n_bin, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h_rows_written) *h_rows_written = P.n_bin;
+    return XSI_OK;
+}
+
+int xsi_hip_synth_packed(xsi_hip_ctx* ctx, uint64_t seed, uint64_t first_line, uint64_t n_lines, uint32_t n_haps,
+                         void* d_bits, uint32_t row_stride_bytes) {
+    if (!ctx || !d_bits) return set_error(XSI_ERR_ARG, "synth_packed: null argument");
+    if (n_haps < 2 || row_stride_bytes % 8u || (uint64_t)row_stride_bytes * 8u < n_haps)
+        return set_error(XSI_ERR_ARG, "synth_packed: bad n_haps / row_stride_bytes");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_synth_packed(ctx->stream, seed, first_line, n_lines, n_haps, reinterpret_cast<uint32_t*>(d_bits),
+                                row_stride_bytes / 4u));
+    return XSI_OK;
+}
+
+}  // extern "C"
+
+namespace xsi {
+
+// Parse header + block dictionaries, size and fill the per-line arrays.  Synchronises twice
+// (header read-back, totals read-back): decode needs the line counts to size its workspace.
+int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block, uint64_t n_blocks64,
+                   DecodePlan* P) {
+    hipStream_t s = ctx->stream;
+    uint8_t h[256];
+    HIP_TRY(hipMemcpyAsync(h, d_file, 256, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    auto get = [&](size_t off, int bytes) {
+        uint64_t v = 0;
+        for (int i = 0; i < bytes; ++i) v |= (uint64_t)h[off + i] << (8 * i);
+        return v;
+    };
+    if (get(0, 4) != 0xaabbccddu) return set_error(XSI_ERR_FORMAT, "Bad endianness");
+    if (get(4, 4) != 0xfeed1767u || get(252, 4) != 0xfeed1767u) return set_error(XSI_ERR_FORMAT, "Bad magic");
+    const uint32_t version = (uint32_t)get(8, 4);
+    if (version != 4 && version != 5) return set_error(XSI_ERR_FORMAT, "Bad version");
+    if (h[12] == 0) return set_error(XSI_ERR_FORMAT, "PLOIDY ERROR");
+    if (h[17] & 4u) return set_error(XSI_ERR_UNSUPPORTED, "zstd-compressed blocks must be inflated on the host before decode");
+    const uint32_t aet = h[14];
+    if (aet != 2 && aet != 4) return set_error(XSI_ERR_FORMAT, "Unsupported A_T");
+    const uint64_t hap_samples = get(32, 8), num_samples = get(112, 8);
+    const uint64_t indices_offset = get(72, 8), samples_offset = get(80, 8);
+    const uint64_t total_blocks = (samples_offset - indices_offset) / (version >= 5 ? 8 : 4);
+    if (indices_offset > file_len || samples_offset > file_len || samples_offset < indices_offset)
+        return set_error(XSI_ERR_FORMAT, "index outside the file image");
+    if (first_block + n_blocks64 > total_blocks || n_blocks64 == 0 || n_blocks64 > 0xFFFFFFull)
+        return set_error(XSI_ERR_ARG, "block range [%llu, +%llu) outside the %llu blocks of the file",
+                         (unsigned long long)first_block, (unsigned long long)n_blocks64, (unsigned long long)total_blocks);
+    const uint32_t n_blocks = (uint32_t)n_blocks64;
+    // accessor_internals_new.hpp:53: N_HAPS = N_SAMPLES ? N_SAMPLES*2 : hap_samples
+    const uint64_t N64 = num_samples ? num_samples * 2 : hap_samples;
+    if (N64 < 2 || N64 > 0x7FFFFFFFull) return set_error(XSI_ERR_FORMAT, "haplotype count %llu out of range", (unsigned long long)N64);
+
+    P->n_blocks = n_blocks;
+    P->version = version;
+    P->hap_samples = hap_samples;
+    DecLines& L = P->L;
+    memset(&L, 0, sizeof(L));
+    L.N = (uint32_t)N64;
+    L.n_samples = (uint32_t)(N64 / 2);
+    L.aet = aet;
+    L.file_len = file_len;
+    WS(P->d_blocks, "dec.blocks", sizeof(DecBlock) * (size_t)n_blocks);
+    WS(P->d_totals, "dec.totals", 64);
+    HIP_TRY(launch_parse_blocks(s, (const uint8_t*)d_file, file_len, indices_offset, version, first_block, n_blocks,
+                                P->d_blocks, P->d_totals));
+    HIP_TRY(launch_scan_dec_blocks(s, P->d_blocks, n_blocks, P->d_totals));
+    uint32_t tot[8];
+    HIP_TRY(hipMemcpyAsync(tot, P->d_totals, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (tot[3]) return set_error(XSI_ERR_FORMAT, "corrupt block dictionary in the requested range");
+    P->n_bin = tot[0];
+    P->n_bcf = tot[4];
+    const uint32_t n_bin = P->n_bin;
+    L.max_bin = n_bin;
+    WS(L.kind, "dec.kind", (size_t)n_bin + 64);
+    WS(L.line_block, "dec.line_block", 4ull * n_bin + 64);
+    WS(L.rank, "dec.rank", 4ull * n_bin + 64);
+    WS(L.wah_start, "dec.wah_start", 4ull * n_bin + 64);
+    WS(L.sparse_start, "dec.sparse_start", 4ull * n_bin + 64);
+    WS(L.wah_lines, "dec.wah_lines", 4ull * n_bin + 64);
+    WS(L.sparse_lines, "dec.sparse_lines", 4ull * n_bin + 64);
+    WS(L.ones, "dec.ones", 4ull * n_bin + 64);
+    WS(L.wah_cumg, "dec.wah_cumg", 4ull * n_bin + 64);
+    HIP_TRY(launch_decode_flags(s, (const uint8_t*)d_file, P->d_blocks, n_blocks, L));
+    HIP_TRY(launch_scan_dec_blocks2(s, P->d_blocks, n_blocks, P->d_totals));
+    HIP_TRY(launch_dec_line_lists(s, P->d_blocks, n_blocks, L));
+    // host copy of the block descriptors: side-channel presence decides the path
+    P->blocks_h.resize(n_blocks);
+    HIP_TRY(hipMemcpyAsync(P->blocks_h.data(), P->d_blocks, sizeof(DecBlock) * (size_t)n_blocks, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(tot, P->d_totals, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    P->n_wah = tot[1];
+    P->n_sparse = tot[2];
+    P->has_side = false;
+    for (auto& b : P->blocks_h)
+        if (b.off_line_missing != VAL_UNDEFINED || b.off_line_eov != VAL_UNDEFINED || b.off_line_phase != VAL_UNDEFINED ||
+            b.off_line_haploid != VAL_UNDEFINED)
+            P->has_side = true;
+    L.y_stride64 = (L.N + 63u) / 64u;
+    WS(L.yrows, "dec.yrows", 8ull * L.y_stride64 * (size_t)(P->n_wah ? P->n_wah : 1));
+    return XSI_OK;
+}
+
+// WAH boundaries -> expand -> chain; sparse walk -> fill.  Output: one natural-order bit row
+// per binary line at out + l*stride_w.
+int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t* out, uint32_t stride_w, int apply_negation) {
+    hipStream_t s = ctx->stream;
+    const uint8_t* f = (const uint8_t*)d_file;
+    DecLines& L = P.L;
+    uint32_t* scratch_a = nullptr;
+    if (!chain_geometry(L.N, true).in_lds)
+        WS(scratch_a, "chain.a", 4ull * 2ull * (((size_t)L.N + 63u) & ~(size_t)63u) * P.n_blocks);
+    HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
+    HIP_TRY(launch_wah_expand(s, f, P.d_blocks, L, P.n_wah, P.d_totals));
+    HIP_TRY(launch_chain_decode(s, P.d_blocks, P.n_blocks, L, out, stride_w, scratch_a));
+    HIP_TRY(launch_sparse_walk(s, f, P.d_blocks, P.n_blocks, L));
+    HIP_TRY(launch_sparse_fill(s, f, P.d_blocks, L, P.n_sparse, P.d_totals, out, stride_w, apply_negation));
+    return XSI_OK;
+}
+
+int encode_side_write(xsi_hip_ctx*, const EncBlock*, uint32_t, const EncLines&, const EncSide&, uint8_t*, const uint64_t*) {
+    return set_error(XSI_ERR_UNSUPPORTED, "side channels are written by the general encode path (xsi_gt.hip)");
+}
+
+}  // namespace xsi

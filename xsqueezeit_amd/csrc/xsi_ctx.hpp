@@ -1,0 +1,55 @@
+// xsi_ctx.hpp — context, workspace and internal host-side declarations of libxsi_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "xsi_kernels.hpp"
+
+struct xsi_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    struct Buf {
+        void* p = nullptr;
+        size_t cap = 0;
+    };
+    std::map<std::string, Buf> bufs;  // named device workspace, grown on demand, reused across calls
+    void* pinned = nullptr;           // pinned host staging
+    size_t pinned_cap = 0;
+};
+
+struct xsi_encode_params;
+struct xsi_encode_result;
+
+namespace xsi {
+
+int set_error(int code, const char* fmt, ...);
+int ws_ensure(xsi_hip_ctx* c, const char* name, size_t bytes, void** out);
+int pinned_ensure(xsi_hip_ctx* c, size_t bytes, void** out);
+
+struct DecodePlan {
+    uint32_t n_blocks = 0, version = 0;
+    uint32_t n_bin = 0, n_bcf = 0, n_wah = 0, n_sparse = 0;
+    uint64_t hap_samples = 0;
+    bool has_side = false;
+    DecBlock* d_blocks = nullptr;
+    uint32_t* d_totals = nullptr;
+    std::vector<DecBlock> blocks_h;
+    DecLines L{};
+};
+
+int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block, uint64_t n_blocks,
+                   DecodePlan* P);
+int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t* out, uint32_t stride_w,
+                  int apply_negation);
+int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide S, std::vector<EncBlock>& blocks_h,
+               void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result);
+int encode_side_write(xsi_hip_ctx* ctx, const EncBlock* d_blocks, uint32_t n_blocks, const EncLines& L,
+                      const EncSide& S, uint8_t* out, const uint64_t* d_result);
+
+}  // namespace xsi

@@ -1,0 +1,238 @@
+// xsi_device.hpp — wave64 device helpers shared by the gfx950 kernels.
+//
+// Everything here is written for CDNA4's 64-wide wavefronts: ballots are 64-bit, lane prefix
+// counts use v_mbcnt, cross-lane moves use ds_bpermute/DPP through __shfl*.  No MFMA: the whole
+// path is integer bit manipulation bound by HBM / LDS.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xsi {
+
+constexpr uint32_t WAH_BITS = 15;
+constexpr uint32_t WAH_MAXC = 0x3FFF;  // 16383 groups per fill word (wah.hpp:383)
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// popcount(mask & lanes below me)
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Inclusive wave scan (sum) of a 32-bit value over 64 lanes.
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_scan_incl64(uint64_t v) {
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t o = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Workgroup exclusive scan of one uint64 per thread.  `lds` needs (blockDim/64 + 1) uint64.
+// Returns the exclusive prefix; *total receives the workgroup sum.  Contains two barriers.
+__device__ __forceinline__ uint64_t block_scan_excl64(uint64_t v, uint64_t* lds, uint64_t* total) {
+    const uint32_t lane = lane_id();
+    const uint32_t w = threadIdx.x >> 6;
+    const uint32_t nw = (blockDim.x + 63u) >> 6;
+    uint64_t inc = wave_scan_incl64(v);
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+    for (uint32_t i = 0; i < nw; ++i) {
+        uint64_t c = lds[i];
+        if (i < w) base += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// 15-bit group g of a packed bit row (LSB-first in little-endian 32-bit words); bits at or
+// beyond nbits read as zero (the reference pads the last group with zeros, wah.hpp:547-565).
+__device__ __forceinline__ uint32_t load_group15(const uint32_t* __restrict__ row, uint32_t g, uint32_t nbits) {
+    const uint32_t o = g * WAH_BITS;
+    if (o >= nbits) return 0;
+    const uint32_t nwords = (nbits + 31u) >> 5;
+    const uint32_t wi = o >> 5, sh = o & 31u;
+    uint64_t lo = row[wi];
+    uint64_t hi = (wi + 1 < nwords) ? row[wi + 1] : 0u;
+    uint32_t v = (uint32_t)(((hi << 32) | lo) >> sh) & 0x7FFFu;
+    const uint32_t rem = nbits - o;
+    if (rem < WAH_BITS) v &= (1u << rem) - 1u;
+    return v;
+}
+
+// State carried between 64-group chunks of one WAH16 line.
+struct WahCarry {
+    uint32_t type;  // 0 zeros run open, 1 ones run open, 2/3 nothing open
+    uint32_t len;   // groups in the open run
+    uint32_t out;   // words emitted so far
+};
+
+// Encode one chunk of up to 64 groups held one-per-lane.  `val` = 15-bit group value, `valid`
+// = lane holds a group, `last_chunk` = no group follows this chunk.  Reproduces
+// process_wah_word + the trailing flush (wah.hpp:376-429, 567-573): literals are copied, runs of
+// all-zero / all-one groups collapse into fill words of at most 16383 groups, a saturated run
+// emits 0xBFFF / 0xFFFF and restarts.  Emits at the END of each run, so every word's position
+// is the exclusive prefix of the emit counts.
+template <bool WRITE>
+__device__ __forceinline__ void wah_encode_chunk(uint32_t val, bool valid, bool last_chunk, WahCarry& c,
+                                                 uint16_t* __restrict__ dst) {
+    const uint32_t lane = lane_id();
+    const uint32_t t = (val == 0u) ? 0u : ((val == 0x7FFFu) ? 1u : 2u);
+    uint32_t prev_t = __shfl_up(t, 1, 64);
+    if (lane == 0) prev_t = c.type;
+    const bool head = valid && (t == 2u || t != prev_t);
+    const uint64_t H = __ballot(head);
+    const uint64_t V = __ballot(valid);
+    const uint32_t nvalid = (uint32_t)__popcll(V);
+    // run length ending at this lane (only meaningful for t < 2)
+    const uint64_t le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const uint64_t hb = H & le;
+    uint32_t len;
+    if (hb) {
+        len = lane - (63u - (uint32_t)__clzll((long long)hb)) + 1u;
+    } else {
+        len = c.len + lane + 1u;
+    }
+    // is this lane the last group of its run?
+    bool is_end;
+    if (lane + 1u < nvalid) {
+        is_end = (H >> (lane + 1u)) & 1ull;
+    } else {
+        is_end = last_chunk;  // last valid lane: run stays open unless the line ends here
+    }
+    uint32_t emit = 0;
+    if (valid) {
+        if (t == 2u)
+            emit = 1;
+        else if (is_end)
+            emit = (len + WAH_MAXC - 1u) / WAH_MAXC;
+    }
+    uint32_t pos, total;
+    if (!__any(emit > 1u)) {
+        const uint64_t E = __ballot(emit == 1u);
+        pos = mbcnt64(E);
+        total = (uint32_t)__popcll(E);
+    } else {
+        const uint32_t inc = wave_scan_incl(emit);
+        pos = inc - emit;
+        total = __shfl(inc, 63, 64);
+    }
+    if (WRITE && emit) {
+        uint16_t* o = dst + c.out + pos;
+        if (t == 2u) {
+            o[0] = (uint16_t)val;
+        } else {
+            const uint32_t tag = 0x8000u | (t << 14);
+            for (uint32_t k = 0; k + 1u < emit; ++k) o[k] = (uint16_t)(tag | WAH_MAXC);
+            o[emit - 1u] = (uint16_t)(tag | (len - WAH_MAXC * (emit - 1u)));
+        }
+    }
+    // carry = state after the last valid lane
+    const uint32_t last = nvalid ? nvalid - 1u : 0u;
+    const uint32_t lt = __shfl(t, last, 64);
+    const uint32_t ll = __shfl(len, last, 64);
+    if (nvalid) {
+        c.type = lt;
+        c.len = (lt < 2u) ? ll : 0u;
+    }
+    c.out += total;
+}
+
+// Encode a whole packed bit row with one wave.  Returns the number of WAH16 words.
+template <bool WRITE>
+__device__ __forceinline__ uint32_t wave_wah_encode_row(const uint32_t* __restrict__ row, uint32_t nbits,
+                                                        uint16_t* __restrict__ dst) {
+    const uint32_t lane = lane_id();
+    const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
+    WahCarry c{3u, 0u, 0u};
+    for (uint32_t g0 = 0; g0 < G; g0 += 64u) {
+        const uint32_t g = g0 + lane;
+        const bool valid = g < G;
+        const uint32_t val = valid ? load_group15(row, g, nbits) : 0u;
+        wah_encode_chunk<WRITE>(val, valid, g0 + 64u >= G, c, dst);
+    }
+    return c.out;
+}
+
+// Expand one WAH16 line into a zeroed packed row held in LDS (wah2_extract_template,
+// wah.hpp:177-223).  One wave.  `src` is 2-byte aligned; at most `max_words` words may be
+// read.  Returns the words consumed; *ones = set bits counted like the reference (fills count
+// whole groups).  The caller must barrier before reading `row`.
+__device__ __forceinline__ uint32_t wave_wah_expand_row(const uint16_t* __restrict__ src, uint32_t max_words,
+                                                        uint32_t nbits, uint32_t* row /*LDS*/, uint32_t* ones) {
+    const uint32_t lane = lane_id();
+    const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
+    const uint32_t row_bits = ((nbits + 31u) >> 5) << 5;
+    uint32_t gbase = 0, wbase = 0, cnt1 = 0;
+    while (gbase < G && wbase < max_words) {
+        const uint32_t wi = wbase + lane;
+        const bool have = wi < max_words;
+        const uint32_t word = have ? (uint32_t)src[wi] : 0u;
+        const bool fill = (word & 0x8000u) != 0u;
+        const uint32_t ng = have ? (fill ? (word & WAH_MAXC) : 1u) : 0u;
+        const uint32_t inc = wave_scan_incl(ng);
+        const uint32_t s = gbase + inc - ng;  // first group covered by this word
+        const bool active = have && s < G;
+        if (active) {
+            if (!fill) {
+                const uint32_t o = s * WAH_BITS;
+                const uint32_t v = word & 0x7FFFu;
+                cnt1 += (uint32_t)__popc(v);
+                if (v && o < row_bits) {
+                    atomicOr(&row[o >> 5], v << (o & 31u));
+                    if ((o & 31u) > 17u && (o >> 5) + 1u < (row_bits >> 5)) atomicOr(&row[(o >> 5) + 1u], v >> (32u - (o & 31u)));
+                }
+            } else if (word & 0x4000u) {
+                cnt1 += ng * WAH_BITS;
+            }
+        }
+        // ones-fills: the whole wave paints each run
+        uint64_t F = __ballot(active && fill && (word & 0x4000u) && ng);
+        while (F) {
+            const int f = __ffsll((long long)F) - 1;
+            F &= F - 1ull;
+            const uint32_t fs = __shfl(s, f, 64), fn = __shfl(ng, f, 64);
+            uint32_t b0 = fs * WAH_BITS, b1 = b0 + fn * WAH_BITS;
+            if (b1 > row_bits) b1 = row_bits;
+            if (b0 >= b1) continue;
+            const uint32_t w0 = b0 >> 5, w1 = (b1 - 1u) >> 5;
+            for (uint32_t w = w0 + lane; w <= w1; w += 64u) {
+                uint32_t m = 0xFFFFFFFFu;
+                if (w == w0) m &= 0xFFFFFFFFu << (b0 & 31u);
+                if (w == w1 && (b1 & 31u)) m &= (1u << (b1 & 31u)) - 1u;
+                atomicOr(&row[w], m);
+            }
+        }
+        const uint64_t A = __ballot(active);
+        const uint32_t used = (uint32_t)__popcll(A);
+        // groups covered by the consumed words
+        const uint32_t covered = __shfl(inc, used ? used - 1u : 0u, 64);
+        gbase += used ? covered : 0u;
+        wbase += used;
+        if (used < 64u) break;
+    }
+    *ones = wave_sum(cnt1);
+    return wbase;
+}
+
+}  // namespace xsi

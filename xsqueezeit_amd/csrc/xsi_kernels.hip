@@ -1,0 +1,1577 @@
+// xsi_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the xSqueezeIt genotype-block codec.
+//
+// Encode: count -> classify (WAH vs sparse, per-block scans) -> PBWT chain (one workgroup per
+// block, prefix array `a` resident in LDS, haplotype bit columns staged through LDS, wave
+// ballot + mbcnt for the stable partition) -> WAH16 sizing / writing (one wave per line) ->
+// sparse lists (one wave per line) -> block layout + dictionary.  Decode mirrors it.
+// Reference behaviour restated per kernel (paths relative to the reference tree).
+#include "xsi_kernels.hpp"
+
+#include "xsi_device.hpp"
+
+namespace xsi {
+
+// ------------------------------------------------------------------------------------------
+// dictionary key orders (libstdc++ unordered_map iteration order of GtBlock::fill_dictionary,
+// gt_block.hpp:464-510).  index = missing | eov<<1 | phase<<2 | haploid<<3
+// ------------------------------------------------------------------------------------------
+__constant__ uint8_t c_dict_order[16][19] = {
+    {9, 0x21, 0x20, 0x11, 0x04, 0x10, 0x03, 0x02, 0x01, 0x00},
+    {12, 0x26, 0x16, 0x21, 0x20, 0x11, 0x04, 0x10, 0x03, 0x36, 0x02, 0x01, 0x00},
+    {12, 0x18, 0x21, 0x20, 0x38, 0x11, 0x04, 0x10, 0x03, 0x02, 0x28, 0x01, 0x00},
+    {15, 0x38, 0x28, 0x00, 0x01, 0x02, 0x36, 0x10, 0x11, 0x03, 0x20, 0x04, 0x21, 0x16, 0x26, 0x18},
+    {11, 0x17, 0x21, 0x20, 0x11, 0x04, 0x10, 0x03, 0x02, 0x01, 0x27, 0x00},
+    {14, 0x27, 0x00, 0x01, 0x02, 0x36, 0x10, 0x11, 0x03, 0x20, 0x04, 0x21, 0x16, 0x26, 0x17},
+    {14, 0x27, 0x00, 0x01, 0x28, 0x02, 0x10, 0x11, 0x38, 0x03, 0x20, 0x04, 0x21, 0x18, 0x17},
+    {17, 0x27, 0x17, 0x38, 0x28, 0x00, 0x01, 0x02, 0x36, 0x10, 0x11, 0x03, 0x20, 0x04, 0x21, 0x16, 0x26, 0x18},
+    {10, 0x12, 0x21, 0x20, 0x11, 0x04, 0x10, 0x03, 0x02, 0x01, 0x00},
+    {13, 0x12, 0x26, 0x16, 0x21, 0x20, 0x11, 0x04, 0x10, 0x03, 0x36, 0x02, 0x01, 0x00},
+    {13, 0x12, 0x18, 0x21, 0x20, 0x38, 0x11, 0x04, 0x10, 0x03, 0x02, 0x28, 0x01, 0x00},
+    {16, 0x12, 0x38, 0x28, 0x00, 0x01, 0x02, 0x36, 0x10, 0x11, 0x03, 0x20, 0x04, 0x21, 0x16, 0x26, 0x18},
+    {12, 0x12, 0x17, 0x21, 0x20, 0x11, 0x04, 0x10, 0x03, 0x02, 0x01, 0x27, 0x00},
+    {15, 0x12, 0x27, 0x00, 0x01, 0x02, 0x36, 0x10, 0x11, 0x03, 0x20, 0x04, 0x21, 0x16, 0x26, 0x17},
+    {15, 0x12, 0x27, 0x00, 0x01, 0x28, 0x02, 0x10, 0x11, 0x38, 0x03, 0x20, 0x04, 0x21, 0x18, 0x17},
+    {18, 0x12, 0x27, 0x17, 0x38, 0x28, 0x00, 0x01, 0x02, 0x36, 0x10, 0x11, 0x03, 0x20, 0x04, 0x21, 0x16, 0x26, 0x18},
+};
+
+__device__ __forceinline__ uint32_t nbits_of(const EncLines& L, uint32_t l) {
+    return L.bin_nbits ? L.bin_nbits[l] : L.N;
+}
+
+// ------------------------------------------------------------------------------------------
+// count: ones per bit row (allele_counts[alt] of scan_genotypes, gt_block.hpp:226-268, for
+// fully called lines).  One wave per row, coalesced 256-byte reads.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_count_rows(const uint32_t* __restrict__ planes, uint32_t stride_w,
+                                                    uint32_t nbits, uint32_t n_rows, uint32_t* __restrict__ cnt) {
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const uint32_t lane = lane_id();
+    const uint32_t nw = (nbits + 31u) >> 5;
+    const uint32_t* r = planes + (size_t)row * stride_w;
+    uint32_t c = 0;
+    for (uint32_t w = lane; w < nw; w += 64u) {
+        uint32_t v = r[w];
+        if (w == nw - 1u && (nbits & 31u)) v &= (1u << (nbits & 31u)) - 1u;
+        c += (uint32_t)__popc(v);
+    }
+    c = wave_sum(c);
+    if (lane == 0) cnt[row] = c;
+}
+
+hipError_t launch_count_rows(hipStream_t s, const uint32_t* planes, uint32_t stride_w, uint32_t nbits,
+                             uint32_t n_rows, uint32_t* cnt) {
+    if (!n_rows) return hipSuccess;
+    k_count_rows<<<dim3((n_rows + 3u) / 4u), dim3(256), 0, s>>>(planes, stride_w, nbits, n_rows, cnt);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// classify: per binary line WAH-vs-sparse decision (gt_block.hpp:298-327):
+//   minor = min(cnt, ngt - cnt); WAH iff minor > MAC threshold; sparse lists the ALT positions
+//   when cnt == minor, else the REF positions with the MSB of the count set.
+// One workgroup per block; per-block exclusive scans give each WAH line its rank and each
+// sparse line its byte offset.  Also packs the is-WAH flag vector (KEY_LINE_SORT/SELECT).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_classify(EncBlock* __restrict__ blocks, EncLines L) {
+    __shared__ uint64_t s_scan[20];
+    const uint32_t b = blockIdx.x;
+    EncBlock& B = blocks[b];
+    const uint32_t first = B.first_bin, n = B.n_bin;
+    uint32_t wah_base = 0, sp_base = 0;
+    uint32_t* fb = L.flagbits + ((size_t)b * FV_COUNT + FV_IS_WAH) * (MAX_BIN_PER_BLOCK / 32);
+    for (uint32_t c0 = 0; c0 < n; c0 += blockDim.x) {
+        const uint32_t i = c0 + threadIdx.x;
+        const bool valid = i < n;
+        const uint32_t l = first + i;
+        uint32_t is_wah = 0, sp_bytes = 0;
+        if (valid) {
+            const uint32_t ngt = nbits_of(L, l);
+            const uint32_t c = L.cnt[l];
+            const uint32_t minor = c < ngt - c ? c : ngt - c;
+            uint32_t k = L.kind[l] & KIND_HAPLOID;
+            if (minor > L.thr) {
+                is_wah = 1;
+                k |= KIND_WAH;
+            } else {
+                uint32_t listed = c;
+                if (c != minor) {
+                    k |= KIND_NEGATED;
+                    listed = L.ref_cnt ? L.ref_cnt[L.bin_parent[l]] : ngt - c;
+                }
+                sp_bytes = (1u + listed) * L.aet;
+            }
+            L.kind[l] = (uint8_t)k;
+            L.line_block[l] = b;
+        }
+        const uint64_t W = __ballot(is_wah);
+        if (lane_id() == 0 && c0 + (threadIdx.x & ~63u) < n) {
+            const uint32_t wi = (c0 + threadIdx.x) >> 5;
+            fb[wi] = (uint32_t)W;
+            fb[wi + 1] = (uint32_t)(W >> 32);
+        }
+        uint64_t tot;
+        const uint64_t ex = block_scan_excl64(((uint64_t)is_wah << 40) | sp_bytes, s_scan, &tot);
+        if (valid) {
+            L.wah_rank[l] = wah_base + (uint32_t)(ex >> 40);
+            L.sparse_off[l] = sp_base + (uint32_t)(ex & 0xFFFFFFFFFFull);
+        }
+        wah_base += (uint32_t)(tot >> 40);
+        sp_base += (uint32_t)(tot & 0xFFFFFFFFFFull);
+    }
+    if (threadIdx.x == 0) {
+        B.n_wah = wah_base;
+        B.sparse_bytes = sp_base;
+    }
+}
+
+hipError_t launch_classify(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, const EncLines& L) {
+    if (!n_blocks) return hipSuccess;
+    k_classify<<<dim3(n_blocks), dim3(1024), 0, s>>>(blocks, L);
+    return hipGetLastError();
+}
+
+// exclusive scan of n_wah over the blocks of the batch (single workgroup; batches are <= a few
+// thousand blocks).  totals[0] = WAH lines in the batch.
+__global__ void __launch_bounds__(1024) k_scan_blocks_wah(EncBlock* __restrict__ blocks, uint32_t n_blocks,
+                                                          uint32_t* __restrict__ totals) {
+    __shared__ uint64_t s_scan[20];
+    uint32_t base = 0;
+    for (uint32_t c0 = 0; c0 < n_blocks; c0 += blockDim.x) {
+        const uint32_t i = c0 + threadIdx.x;
+        const uint32_t v = i < n_blocks ? blocks[i].n_wah : 0u;
+        uint64_t tot;
+        const uint64_t ex = block_scan_excl64(v, s_scan, &tot);
+        if (i < n_blocks) blocks[i].wah_first = base + (uint32_t)ex;
+        base += (uint32_t)tot;
+    }
+    if (threadIdx.x == 0) totals[0] = base;
+}
+
+hipError_t launch_scan_blocks_wah(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, uint32_t* totals) {
+    k_scan_blocks_wah<<<dim3(1), dim3(1024), 0, s>>>(blocks, n_blocks, totals);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) k_build_wah_list(const EncBlock* __restrict__ blocks, EncLines L) {
+    const EncBlock& B = blocks[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < B.n_bin; i += blockDim.x) {
+        const uint32_t l = B.first_bin + i;
+        if (L.kind[l] & KIND_WAH) L.wah_lines[B.wah_first + L.wah_rank[l]] = l;
+    }
+}
+
+hipError_t launch_build_wah_list(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L) {
+    if (!n_blocks) return hipSuccess;
+    k_build_wah_list<<<dim3(n_blocks), dim3(256), 0, s>>>(blocks, L);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// PBWT chain.
+//
+// Per block, for every WAH line k in order (sparse lines never touch `a`, gt_block.hpp:299-326):
+//   encode: y_k[i] = x_k[a_k[i]]                      (wah.hpp:530-537 gather through a)
+//           a_{k+1} = [a_k[i] : y_k[i]=0] ++ [a_k[i] : y_k[i]=1]   (internal_gt_record.hpp:32-59)
+//   decode: x_k[a_k[i]] = y_k[i]                      (accessor_internals_new.hpp:228-230)
+//           same partition by y_k                     (gt_block.hpp:124-136)
+// `a` restarts at identity for every block (gt_block.hpp:179; accessor_internals_new.hpp:144).
+//
+// MI355X mapping: one workgroup (T threads = T/64 waves) owns a block.  `a` lives in LDS as
+// uint16 (N <= 65536), wave w owns positions [w*E*64, (w+1)*E*64), chunk e of a wave is 64
+// consecutive positions, one per lane.  For each chunk the 64 key bits are one ballot; a lane's
+// destination is (zeros before my wave) + (zeros in my earlier chunks) + mbcnt(zero mask) for a
+// 0 and the mirrored expression offset by the line's total zeros for a 1, so the partition is
+// stable by construction.  Every wave reads its positions into registers before the barrier
+// that publishes the per-wave zero counts, so the scatter can go back into the same LDS array.
+// Bit columns are prefetched in batches (global -> registers while the previous batch is
+// processed -> LDS) so the serial chain never waits on HBM.
+// Fully haploid lines (general path) use the slow sub-path chain_step_haploid.
+// ------------------------------------------------------------------------------------------
+struct ChainArgs {
+    const uint32_t* wah_first;   // unused (kept for symmetry)
+    const uint32_t* wah_lines;   // [rank] binary line
+    const uint8_t* kind;         // per binary line
+    const uint32_t* src;         // encode: planes (by binary line); decode: yrows as uint32 (by rank)
+    uint32_t src_stride_w;
+    uint32_t* dst;               // encode: yrows as uint32 (by rank); decode: output rows (by binary line)
+    uint32_t dst_stride_w;
+    uint32_t N;
+    uint32_t cw;                 // words per column in LDS (even)
+    uint32_t log2_cwp;           // log2 of next pow2 >= cw
+    uint32_t batch;              // columns per prefetch batch
+    uint32_t out_row_base;       // decode: first output row of the batch (binary line numbering offset)
+};
+
+constexpr int CHAIN_RMAX = 4;
+
+template <int T, int E, bool DECODE>
+__global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eblocks,
+                                                 const DecBlock* __restrict__ dblocks, ChainArgs A) {
+    constexpr int W = T / 64;
+    static_assert(E <= 64, "per-lane bitfields are 64 bits wide");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t N = A.N, cw = A.cw;
+    const uint32_t na = (N + 63u) & ~63u;
+    uint16_t* a = reinterpret_cast<uint16_t*>(smem);
+    uint32_t* col = reinterpret_cast<uint32_t*>(smem + (((size_t)na * 2u + 15u) & ~(size_t)15u));
+    uint32_t* xrow = col + 2u * A.batch * cw;  // cw words (decode scatter target / haploid scratch)
+    uint32_t* wcnt = xrow + cw;                // 2*W words
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+
+    uint32_t wah_first, n_wah;
+    if (DECODE) {
+        wah_first = dblocks[blockIdx.x].wah_first;
+        n_wah = dblocks[blockIdx.x].n_wah;
+    } else {
+        wah_first = eblocks[blockIdx.x].wah_first;
+        n_wah = eblocks[blockIdx.x].n_wah;
+    }
+    if (n_wah == 0) return;
+
+    for (uint32_t i = tid; i < na; i += T) a[i] = (uint16_t)i;
+    for (uint32_t i = tid; i < cw; i += T) xrow[i] = 0;
+
+    const uint32_t B = A.batch;
+    const uint32_t cwp_mask = (1u << A.log2_cwp) - 1u;
+    const uint32_t src_words = (N + 31u) >> 5;
+    uint32_t R[CHAIN_RMAX];
+
+    auto load_batch = [&](uint32_t bt) {
+#pragma unroll
+        for (int r = 0; r < CHAIN_RMAX; ++r) {
+            const uint32_t idx = (uint32_t)r * T + tid;
+            const uint32_t jj = idx >> A.log2_cwp, wi = idx & cwp_mask;
+            const uint32_t j = bt * B + jj;
+            uint32_t v = 0;
+            if (jj < B && j < n_wah && wi < src_words) {
+                const uint32_t rank = wah_first + j;
+                const size_t row = DECODE ? (size_t)rank : (size_t)A.wah_lines[rank];
+                v = A.src[row * A.src_stride_w + wi];
+            }
+            R[r] = v;
+        }
+    };
+    auto store_batch = [&](uint32_t buf) {
+#pragma unroll
+        for (int r = 0; r < CHAIN_RMAX; ++r) {
+            const uint32_t idx = (uint32_t)r * T + tid;
+            const uint32_t jj = idx >> A.log2_cwp, wi = idx & cwp_mask;
+            if (jj < B && wi < cw) {
+                // positions [N, na) of `a` hold padding members whose key is always 1, so they stay
+                // behind every real member (stable partition) and never need a validity test
+                uint32_t v = R[r];
+                const uint32_t b0 = wi * 32u;
+                if (b0 + 32u > N) v |= (b0 >= N) ? 0xFFFFFFFFu : (0xFFFFFFFFu << (N - b0));
+                col[(buf * B + jj) * cw + wi] = v;
+            }
+        }
+    };
+    // stable partition of `a` by the per-lane key bits (bit e of `keys` = key of my element in
+    // chunk e); av[] holds my elements, zc my wave's zero count.  Two barriers.
+    auto partition = [&](const uint32_t (&av)[E], uint64_t keys, uint32_t zc) {
+        if (lane == 0) wcnt[w] = zc;
+        __syncthreads();
+        uint32_t zb = 0, tz = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const uint32_t cz = wcnt[i];
+            tz += cz;
+            if ((uint32_t)i < w) zb += cz;
+        }
+        const uint32_t before = (w * E * 64u < N) ? w * E * 64u : N;
+        uint32_t ob = before - zb;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t base = (w * E + (uint32_t)e) * 64u;
+            if (base < N) {
+                const bool valid = base + lane < N;
+                const uint32_t bit = (uint32_t)(keys >> e) & 1u;
+                const uint64_t vm = (N - base >= 64u) ? ~0ull : ((1ull << (N - base)) - 1ull);
+                const uint64_t om = __ballot(bit) & vm, zm = ~om & vm;
+                const uint32_t dest = bit ? tz + ob + mbcnt64(om) : zb + mbcnt64(zm);
+                if (valid) a[dest] = (uint16_t)av[e];
+                zb += (uint32_t)__popcll(zm);
+                ob += (uint32_t)__popcll(om);
+            }
+        }
+        __syncthreads();
+    };
+    auto flush_xrow = [&](uint32_t* orow, uint32_t nbits) {
+        for (uint32_t i = tid; i < A.dst_stride_w; i += T) {
+            uint32_t v = 0;
+            if (i < cw) {
+                v = xrow[i];
+                xrow[i] = 0;
+                const uint32_t b0 = i * 32u;
+                if (b0 + 32u > nbits) v &= (b0 >= nbits) ? 0u : ((1u << (nbits - b0)) - 1u);
+            }
+            orow[i] = v;
+        }
+    };
+
+    load_batch(0);
+    store_batch(0);
+    __syncthreads();
+
+    const uint32_t n_batches = (n_wah + B - 1u) / B;
+    for (uint32_t bt = 0; bt < n_batches; ++bt) {
+        const bool more = bt + 1u < n_batches;
+        if (more) load_batch(bt + 1u);
+        const uint32_t jn = (n_wah - bt * B) < B ? (n_wah - bt * B) : B;
+        for (uint32_t jj = 0; jj < jn; ++jj) {
+            const uint32_t rank = wah_first + bt * B + jj;
+            const uint32_t* c = col + ((bt & 1u) * B + jj) * cw;
+            const uint32_t line = A.wah_lines[rank];
+            const bool hap = A.kind && (A.kind[line] & KIND_HAPLOID);
+            uint32_t av[E];
+            uint64_t keys = 0;
+            uint32_t zc = 0;
+            if (!hap) {
+                uint64_t mine = 0;  // encode: lane e collects chunk e's 64 permuted bits
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint32_t base = (w * E + (uint32_t)e) * 64u;
+                    av[e] = 0;
+                    if (base < na) {
+                        const uint32_t v = (uint32_t)a[base + lane];
+                        av[e] = v;
+                        uint64_t m;
+                        if (DECODE) {
+                            // y is already in permuted order: the chunk's 64 key bits are one 64-bit word
+                            const uint32_t lo = __builtin_amdgcn_readfirstlane(c[(base >> 5)]);
+                            const uint32_t hi = __builtin_amdgcn_readfirstlane(c[(base >> 5) + 1u]);
+                            m = ((uint64_t)hi << 32) | lo;
+                            if ((m >> lane) & 1ull) atomicOr(&xrow[v >> 5], 1u << (v & 31u));
+                        } else {
+                            m = __ballot((c[v >> 5] >> (v & 31u)) & 1u);
+                            if (lane == (uint32_t)e) mine = m;
+                        }
+                        keys |= ((m >> lane) & 1ull) << e;
+                        zc += (uint32_t)__popcll(~m);
+                    }
+                }
+                if (!DECODE) {
+                    // 8*E contiguous bytes per wave; bits at or beyond N are padding (ignored downstream)
+                    const uint32_t cg = w * E + lane;
+                    if (lane < (uint32_t)E && cg * 64u < na) {
+                        uint64_t* yr = reinterpret_cast<uint64_t*>(A.dst + (size_t)rank * A.dst_stride_w);
+                        yr[cg] = mine;
+                    }
+                }
+                if (lane == 0) wcnt[w] = zc;
+                __syncthreads();
+                if (DECODE) flush_xrow(A.dst + (size_t)(line - A.out_row_base) * A.dst_stride_w, N);
+                uint32_t zb = 0, tz = 0;
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const uint32_t cz = wcnt[i];
+                    tz += cz;
+                    if ((uint32_t)i < w) zb += cz;
+                }
+                uint32_t ob = w * E * 64u - zb;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint32_t base = (w * E + (uint32_t)e) * 64u;
+                    if (base < na) {
+                        const uint32_t bit = (uint32_t)(keys >> e) & 1u;
+                        const uint64_t om = __ballot(bit), zm = ~om;
+                        const uint32_t dest = bit ? tz + ob + mbcnt64(om) : zb + mbcnt64(zm);
+                        a[dest] = (uint16_t)av[e];
+                        zb += (uint32_t)__popcll(zm);
+                        ob += (uint32_t)__popcll(om);
+                    }
+                }
+                __syncthreads();
+            } else {
+                // ---- fully haploid line (ngt == n_samples): gt_block.hpp:304-309 + pbwt_sort1;
+                //      accessor_internals_new.hpp:222-226, 548-571.  Rare, so written for clarity.
+                //      y (n_samples bits) is in the order a1 = even members of a, halved
+                //      (interfaces.hpp:318-333); the partition key of a[i] is the bit of sample a[i]/2.
+                uint32_t* ev = wcnt + W;  // per-wave count of even members
+                uint64_t evens = 0;       // bit e: my element of chunk e is even
+                uint32_t ec = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint32_t base = (w * E + (uint32_t)e) * 64u;
+                    av[e] = 1;
+                    if (base < N) {
+                        const uint32_t idx = base + lane;
+                        const uint32_t v = idx < N ? (uint32_t)a[idx] : 1u;
+                        av[e] = v;
+                        const uint32_t even = (idx < N && !(v & 1u)) ? 1u : 0u;
+                        evens |= (uint64_t)even << e;
+                        ec += (uint32_t)__popcll(__ballot(even));
+                    }
+                }
+                if (lane == 0) ev[w] = ec;
+                __syncthreads();
+                uint32_t eb = 0;
+#pragma unroll
+                for (int i = 0; i < W; ++i)
+                    if ((uint32_t)i < w) eb += ev[i];
+                if (DECODE) {
+                    // x[a1[p]] = y[p]
+                    uint32_t ebw = eb;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const uint32_t base = (w * E + (uint32_t)e) * 64u;
+                        if (base < N) {
+                            const uint32_t even = (uint32_t)(evens >> e) & 1u;
+                            const uint64_t evm = __ballot(even);
+                            const uint32_t p = ebw + mbcnt64(evm);
+                            if (even && ((c[p >> 5] >> (p & 31u)) & 1u)) {
+                                const uint32_t sidx = av[e] >> 1;
+                                atomicOr(&xrow[sidx >> 5], 1u << (sidx & 31u));
+                            }
+                            ebw += (uint32_t)__popcll(evm);
+                        }
+                    }
+                    __syncthreads();
+                }
+                const uint32_t* keycol = DECODE ? xrow : c;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint32_t base = (w * E + (uint32_t)e) * 64u;
+                    if (base < N) {
+                        const bool valid = base + lane < N;
+                        const uint32_t sidx = av[e] >> 1;
+                        const uint32_t bit = valid ? ((keycol[sidx >> 5] >> (sidx & 31u)) & 1u) : 0u;
+                        const uint64_t vm = (N - base >= 64u) ? ~0ull : ((1ull << (N - base)) - 1ull);
+                        keys |= (uint64_t)bit << e;
+                        zc += (uint32_t)__popcll(~__ballot(bit) & vm);
+                    }
+                }
+                if (DECODE) {
+                    // every wave has read its keys from xrow: publish the row, then partition
+                    __syncthreads();
+                    flush_xrow(A.dst + (size_t)(line - A.out_row_base) * A.dst_stride_w, N >> 1);
+                } else {
+                    // y[p] = key of the p-th even member
+                    uint32_t ebw = eb;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const uint32_t base = (w * E + (uint32_t)e) * 64u;
+                        if (base < N) {
+                            const uint32_t even = (uint32_t)(evens >> e) & 1u;
+                            const uint64_t evm = __ballot(even);
+                            const uint32_t p = ebw + mbcnt64(evm);
+                            if (even && ((keys >> e) & 1ull)) atomicOr(&xrow[p >> 5], 1u << (p & 31u));
+                            ebw += (uint32_t)__popcll(evm);
+                        }
+                    }
+                    __syncthreads();
+                    flush_xrow(A.dst + (size_t)rank * A.dst_stride_w, N >> 1);
+                }
+                partition(av, keys, zc);
+            }
+        }
+        if (more) store_batch((bt + 1u) & 1u);
+        __syncthreads();
+    }
+}
+
+// Global-memory variant for N > 65536 (uint32 prefix array, ping-pong buffers in HBM/L2, bit
+// column still in LDS).  Same algorithm, two passes per line because a wave's positions no
+// longer fit in registers.  One workgroup per block.  Correctness path for UKB-scale N; the
+// multi-CU cooperative version is future work.
+template <bool DECODE>
+__global__ void __launch_bounds__(1024) k_chain_global(const EncBlock* __restrict__ eblocks,
+                                                       const DecBlock* __restrict__ dblocks, ChainArgs A,
+                                                       uint32_t* __restrict__ scratch_a) {
+    constexpr uint32_t T = 1024, W = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t N = A.N, cw = A.cw;
+    uint32_t* col = reinterpret_cast<uint32_t*>(smem);  // cw words: key column (encode: x, decode: y)
+    uint32_t* xrow = col + cw;                          // cw words
+    uint32_t* wcnt = xrow + cw;                         // 2*W
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    uint32_t wah_first, n_wah;
+    if (DECODE) {
+        wah_first = dblocks[blockIdx.x].wah_first;
+        n_wah = dblocks[blockIdx.x].n_wah;
+    } else {
+        wah_first = eblocks[blockIdx.x].wah_first;
+        n_wah = eblocks[blockIdx.x].n_wah;
+    }
+    if (n_wah == 0) return;
+    const size_t na = ((size_t)N + 63u) & ~(size_t)63u;
+    uint32_t* a0 = scratch_a + (size_t)blockIdx.x * 2u * na;
+    uint32_t* a1 = a0 + na;
+    for (uint32_t i = tid; i < N; i += T) a0[i] = i;
+    for (uint32_t i = tid; i < cw; i += T) xrow[i] = 0;
+    const uint32_t src_words = (N + 31u) >> 5;
+    const uint32_t nchunks = (N + 63u) >> 6;
+    const uint32_t cpw = (nchunks + W - 1u) / W;  // chunks per wave
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t j = 0; j < n_wah; ++j) {
+        const uint32_t rank = wah_first + j;
+        const uint32_t line = A.wah_lines[rank];
+        const bool hap = A.kind && (A.kind[line] & KIND_HAPLOID);
+        const uint32_t* srow = A.src + (DECODE ? (size_t)rank : (size_t)line) * A.src_stride_w;
+        for (uint32_t i = tid; i < cw; i += T) col[i] = i < src_words ? srow[i] : 0u;
+        __syncthreads();
+        const uint32_t* ain = (j & 1u) ? a1 : a0;
+        uint32_t* aout = (j & 1u) ? a0 : a1;
+        const uint32_t c_lo = w * cpw, c_hi = (c_lo + cpw < nchunks) ? c_lo + cpw : nchunks;
+        if (hap) {
+            // haploid line: build the sample-indexed key column first (decode) / y bits (encode)
+            uint32_t* ev = wcnt + W;
+            uint32_t ec = 0;
+            for (uint32_t cg = c_lo; cg < c_hi; ++cg) {
+                const uint32_t idx = cg * 64u + lane;
+                const uint32_t v = idx < N ? ain[idx] : 1u;
+                ec += (uint32_t)__popcll(__ballot(!(v & 1u)));
+            }
+            if (lane == 0) ev[w] = ec;
+            __syncthreads();
+            uint32_t eb = 0;
+            for (uint32_t i = 0; i < w; ++i) eb += ev[i];
+            for (uint32_t cg = c_lo; cg < c_hi; ++cg) {
+                const uint32_t idx = cg * 64u + lane;
+                const uint32_t v = idx < N ? ain[idx] : 1u;
+                const bool even = !(v & 1u);
+                const uint64_t evm = __ballot(even);
+                const uint32_t p = eb + mbcnt64(evm);
+                if (even) {
+                    if (DECODE) {
+                        if ((col[p >> 5] >> (p & 31u)) & 1u) atomicOr(&xrow[(v >> 1) >> 5], 1u << ((v >> 1) & 31u));
+                    } else {
+                        if ((col[(v >> 1) >> 5] >> ((v >> 1) & 31u)) & 1u) atomicOr(&xrow[p >> 5], 1u << (p & 31u));
+                    }
+                }
+                eb += (uint32_t)__popcll(evm);
+            }
+            __syncthreads();
+        }
+        const uint32_t* keycol = (hap && DECODE) ? xrow : col;
+        // pass 1: zeros per wave
+        uint32_t zc = 0;
+        for (uint32_t cg = c_lo; cg < c_hi; ++cg) {
+            const uint32_t base = cg * 64u, idx = base + lane;
+            const bool valid = idx < N;
+            uint32_t bit;
+            if (DECODE && !hap) {
+                bit = valid ? ((keycol[idx >> 5] >> (idx & 31u)) & 1u) : 0u;
+            } else {
+                const uint32_t v = valid ? ain[idx] : 0u;
+                const uint32_t k = hap ? (v >> 1) : v;
+                bit = valid ? ((keycol[k >> 5] >> (k & 31u)) & 1u) : 0u;
+            }
+            const uint64_t vm = (N - base >= 64u) ? ~0ull : ((1ull << (N - base)) - 1ull);
+            zc += (uint32_t)__popcll(~__ballot(bit) & vm);
+        }
+        if (lane == 0) wcnt[w] = zc;
+        __syncthreads();
+        uint32_t zb = 0, tz = 0;
+        for (uint32_t i = 0; i < W; ++i) {
+            const uint32_t cz = wcnt[i];
+            tz += cz;
+            if (i < w) zb += cz;
+        }
+        const uint32_t before = (c_lo * 64u < N) ? c_lo * 64u : N;
+        uint32_t ob = before - zb;
+        // pass 2: scatter (+ y emission / x scatter)
+        uint64_t* yr = reinterpret_cast<uint64_t*>(A.dst + (size_t)rank * A.dst_stride_w);
+        for (uint32_t cg = c_lo; cg < c_hi; ++cg) {
+            const uint32_t base = cg * 64u, idx = base + lane;
+            const bool valid = idx < N;
+            const uint32_t v = valid ? ain[idx] : 0u;
+            uint32_t bit;
+            if (DECODE && !hap) {
+                bit = valid ? ((keycol[idx >> 5] >> (idx & 31u)) & 1u) : 0u;
+                if (bit) atomicOr(&xrow[v >> 5], 1u << (v & 31u));
+            } else {
+                const uint32_t k = hap ? (v >> 1) : v;
+                bit = valid ? ((keycol[k >> 5] >> (k & 31u)) & 1u) : 0u;
+            }
+            const uint64_t vm = (N - base >= 64u) ? ~0ull : ((1ull << (N - base)) - 1ull);
+            const uint64_t om = __ballot(bit), zm = ~om & vm;
+            if (!DECODE && !hap && lane == 0) yr[cg] = om;
+            const uint32_t dest = bit ? tz + ob + mbcnt64(om) : zb + mbcnt64(zm);
+            if (valid) aout[dest] = v;
+            zb += (uint32_t)__popcll(zm);
+            ob += (uint32_t)__popcll(om);
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (DECODE || hap) {
+            uint32_t* orow = DECODE ? A.dst + (size_t)(line - A.out_row_base) * A.dst_stride_w
+                                    : A.dst + (size_t)rank * A.dst_stride_w;
+            for (uint32_t i = tid; i < A.dst_stride_w; i += T) {
+                uint32_t v = 0;
+                if (i < cw) {
+                    v = xrow[i];
+                    xrow[i] = 0;
+                }
+                orow[i] = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+static uint32_t next_pow2_log2(uint32_t v) {
+    uint32_t l = 0;
+    while ((1u << l) < v) ++l;
+    return l;
+}
+
+ChainGeom chain_geometry(uint32_t N, bool decode) {
+    (void)decode;
+    ChainGeom g{};
+    g.in_lds = N <= 65536u;
+    const uint32_t cw = (((N + 31u) >> 5) + 1u) & ~1u;
+    if (!g.in_lds) {
+        g.threads = 1024;
+        g.chunks = 0;
+        g.batch = 1;
+        g.lds_bytes = (2u * cw + 64u) * 4u;
+        return g;
+    }
+    int T, E;
+    if (N <= 256) {
+        T = 256;
+        E = 1;
+    } else if (N <= 1024) {
+        T = 256;
+        E = 4;
+    } else {
+        T = 1024;
+        E = 2;
+        while ((uint32_t)(T * E) < N) E *= 2;
+    }
+    const uint32_t na = (N + 63u) & ~63u;
+    const uint32_t a_bytes = (na * 2u + 15u) & ~15u;
+    const uint32_t cwp = 1u << next_pow2_log2(cw);
+    uint32_t B = (uint32_t)(CHAIN_RMAX * T) / cwp;
+    if (B > 16u) B = 16u;
+    if (B < 1u) B = 1u;
+    const uint32_t lds_max = 160u * 1024u;
+    while (B > 1u && a_bytes + (2u * B * cw + cw + 64u) * 4u > lds_max) B >>= 1;
+    g.threads = T;
+    g.chunks = E;
+    g.batch = B;
+    g.lds_bytes = a_bytes + (2u * B * cw + cw + 64u) * 4u;
+    return g;
+}
+
+template <bool DECODE>
+static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock* db, uint32_t n_blocks,
+                               ChainArgs A, uint32_t* scratch_a) {
+    if (!n_blocks) return hipSuccess;
+    const ChainGeom g = chain_geometry(A.N, DECODE);
+    A.cw = (((A.N + 31u) >> 5) + 1u) & ~1u;
+    A.log2_cwp = next_pow2_log2(A.cw);
+    A.batch = g.batch;
+    if (!g.in_lds) {
+        if (!scratch_a) return hipErrorInvalidValue;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_global<DECODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (e != hipSuccess) return e;
+        k_chain_global<DECODE><<<dim3(n_blocks), dim3(1024), g.lds_bytes, s>>>(eb, db, A, scratch_a);
+        return hipGetLastError();
+    }
+#define XSI_CHAIN_CASE(TT, EE)                                                                              \
+    if (g.threads == TT && g.chunks == EE) {                                                                \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_lds<TT, EE, DECODE>),     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);   \
+        if (e != hipSuccess) return e;                                                                      \
+        k_chain_lds<TT, EE, DECODE><<<dim3(n_blocks), dim3(TT), g.lds_bytes, s>>>(eb, db, A);               \
+        return hipGetLastError();                                                                           \
+    }
+    XSI_CHAIN_CASE(256, 1)
+    XSI_CHAIN_CASE(256, 4)
+    XSI_CHAIN_CASE(1024, 2)
+    XSI_CHAIN_CASE(1024, 4)
+    XSI_CHAIN_CASE(1024, 8)
+    XSI_CHAIN_CASE(1024, 16)
+    XSI_CHAIN_CASE(1024, 32)
+    XSI_CHAIN_CASE(1024, 64)
+#undef XSI_CHAIN_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
+                               uint32_t* scratch_a) {
+    ChainArgs A{};
+    A.wah_lines = L.wah_lines;
+    A.kind = L.kind;
+    A.src = L.planes;
+    A.src_stride_w = L.plane_stride_w;
+    A.dst = reinterpret_cast<uint32_t*>(L.yrows);
+    A.dst_stride_w = L.y_stride64 * 2u;
+    A.N = L.N;
+    A.out_row_base = 0;
+    return launch_chain<false>(s, blocks, nullptr, n_blocks, A, scratch_a);
+}
+
+hipError_t launch_chain_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
+                               uint32_t* out_rows, uint32_t out_stride_w, uint32_t* scratch_a) {
+    ChainArgs A{};
+    A.wah_lines = L.wah_lines;
+    A.kind = L.kind;
+    A.src = reinterpret_cast<const uint32_t*>(L.yrows);
+    A.src_stride_w = L.y_stride64 * 2u;
+    A.dst = out_rows;
+    A.dst_stride_w = out_stride_w;
+    A.N = L.N;
+    A.out_row_base = 0;
+    return launch_chain<true>(s, nullptr, blocks, n_blocks, A, scratch_a);
+}
+
+// ------------------------------------------------------------------------------------------
+// WAH16 sizing and writing of the permuted rows (wah_encode2_with_size, wah.hpp:506-578).
+// One wave per WAH line; the sizing pass and the writing pass run the same encoder.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_wah_sizes(EncLines L, const uint32_t* __restrict__ d_total_wah) {
+    const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (j >= d_total_wah[0]) return;
+    const uint32_t l = L.wah_lines[j];
+    uint32_t nbits = nbits_of(L, l);
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(L.yrows + (size_t)j * L.y_stride64);
+    const uint32_t n = wave_wah_encode_row<false>(row, nbits, nullptr);
+    if (lane_id() == 0) L.wah_len[j] = n;
+}
+
+hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_total_wah, uint32_t max_wah) {
+    if (!max_wah) return hipSuccess;
+    k_wah_sizes<<<dim3((max_wah + 3u) / 4u), dim3(256), 0, s>>>(L, d_total_wah);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) k_wah_write(const EncBlock* __restrict__ blocks, EncLines L, uint32_t max_wah,
+                                                   uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result) {
+    if (d_result[3]) return;  // capacity error: nothing may be written
+    const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (j >= max_wah || j >= (uint32_t)d_result[2]) return;
+    const uint32_t l = L.wah_lines[j];
+    const EncBlock& B = blocks[L.line_block[l]];
+    const uint32_t nbits = nbits_of(L, l);
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(L.yrows + (size_t)j * L.y_stride64);
+    uint16_t* dst = reinterpret_cast<uint16_t*>(out + B.out_off + 16u + B.off_wah) + L.wah_off[j];
+    (void)wave_wah_encode_row<true>(row, nbits, dst);
+}
+
+hipError_t launch_wah_write(hipStream_t s, const EncBlock* blocks, const EncLines& L, uint32_t max_wah,
+                            uint8_t* out, const uint64_t* d_result) {
+    if (!max_wah) return hipSuccess;
+    k_wah_write<<<dim3((max_wah + 3u) / 4u), dim3(256), 0, s>>>(blocks, L, max_wah, out, d_result);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// sparse lines: ascending list of set positions (Sparse<T,Pred> ctor + SparseGtLine::
+// write_to_stream, block.hpp:54-99).  One wave per sparse line: each lane popcounts one 32-bit
+// word, a wave scan gives its slot, the lane then peels its set bits.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_at(uint8_t* p, uint32_t v, uint32_t aet) {
+    // A_T values may sit on 2-byte boundaries even when A_T is 4 bytes
+    uint16_t* q = reinterpret_cast<uint16_t*>(p);
+    q[0] = (uint16_t)v;
+    if (aet == 4u) q[1] = (uint16_t)(v >> 16);
+}
+
+__device__ __forceinline__ uint32_t wave_sparse_emit(const uint32_t* __restrict__ row, uint32_t nbits, bool invert,
+                                                     uint32_t msb_flag, uint32_t aet, uint8_t* __restrict__ dst) {
+    const uint32_t lane = lane_id();
+    const uint32_t nw = (nbits + 31u) >> 5;
+    uint32_t base = 0;
+    for (uint32_t w0 = 0; w0 < nw; w0 += 64u) {
+        const uint32_t w = w0 + lane;
+        uint32_t v = 0;
+        if (w < nw) {
+            v = row[w];
+            if (invert) v = ~v;
+            if (w == nw - 1u && (nbits & 31u)) v &= (1u << (nbits & 31u)) - 1u;
+        }
+        const uint32_t c = (uint32_t)__popc(v);
+        const uint32_t inc = wave_scan_incl(c);
+        uint32_t pos = base + inc - c;
+        while (v) {
+            const uint32_t bpos = (uint32_t)__ffs((int)v) - 1u;
+            v &= v - 1u;
+            store_at(dst + (size_t)(1u + pos) * aet, w * 32u + bpos, aet);
+            ++pos;
+        }
+        base += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) {
+        uint32_t head = base;
+        if (msb_flag) head |= (aet == 2u) ? 0x8000u : 0x80000000u;
+        store_at(dst, head, aet);
+    }
+    return base;
+}
+
+__global__ void __launch_bounds__(256) k_sparse_write(const EncBlock* __restrict__ blocks, EncLines L,
+                                                      uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result) {
+    if (d_result[3]) return;
+    const uint32_t l = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (l >= L.n_bin) return;
+    const uint32_t k = L.kind[l];
+    if (k & KIND_WAH) return;
+    const EncBlock& B = blocks[L.line_block[l]];
+    const uint32_t nbits = nbits_of(L, l);
+    const bool neg = (k & KIND_NEGATED) != 0u;
+    const uint32_t* row;
+    bool invert = false;
+    if (neg && L.ref_planes) {
+        row = L.ref_planes + (size_t)L.bin_parent[l] * L.plane_stride_w;  // positions with allele 0
+    } else {
+        row = L.planes + (size_t)l * L.plane_stride_w;
+        invert = neg;  // fully called bi-allelic line: REF positions = complement of ALT positions
+    }
+    uint8_t* dst = out + B.out_off + 16u + B.off_sparse + L.sparse_off[l];
+    (void)wave_sparse_emit(row, nbits, invert, neg ? 1u : 0u, L.aet, dst);
+}
+
+hipError_t launch_sparse_write(hipStream_t s, const EncBlock* blocks, const EncLines& L, uint8_t* out,
+                               const uint64_t* d_result) {
+    if (!L.n_bin) return hipSuccess;
+    k_sparse_write<<<dim3((L.n_bin + 3u) / 4u), dim3(256), 0, s>>>(blocks, L, out, d_result);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// block layout: one wave per block.  Exclusive scan of the WAH line lengths, WAH16 encoding
+// of the flag vectors (write_boolean_vector_as_wah, gt_block.hpp:675-679) into scratch, and
+// the section offsets in the order GtBlock::write_writables emits them (gt_block.hpp:512-647).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_block_layout(EncBlock* __restrict__ blocks, EncLines L, EncSide S,
+                                                     int32_t default_phased) {
+    const uint32_t b = blockIdx.x;
+    EncBlock& B = blocks[b];
+    const uint32_t lane = lane_id();
+    // scan of WAH lengths
+    uint32_t base = 0;
+    for (uint32_t j0 = 0; j0 < B.n_wah; j0 += 64u) {
+        const uint32_t j = j0 + lane;
+        const uint32_t v = j < B.n_wah ? L.wah_len[B.wah_first + j] : 0u;
+        const uint32_t inc = wave_scan_incl(v);
+        if (j < B.n_wah) L.wah_off[B.wah_first + j] = base + inc - v;
+        base += __shfl(inc, 63, 64);
+    }
+    const uint32_t wah_words = base;
+    // side channels (general path): per-block scans over the BCF lines
+    uint32_t miss_bytes = 0, eov_bytes = 0, phase_words = 0;
+    uint32_t any_m = 0, any_e = 0, any_p = 0, any_h = 0, maxp = 1;
+    if (S.bcf_flags) {
+        for (uint32_t i0 = 0; i0 < B.n_bcf; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            const bool valid = i < B.n_bcf;
+            const uint32_t li = B.first_bcf + i;
+            const uint32_t f = valid ? S.bcf_flags[li] : 0u;
+            uint32_t mb = 0, ebb = 0, pw = 0;
+            if (valid) {
+                if (f & 1u) mb = (S.strategy == WS_SPARSE) ? (1u + S.miss_cnt[li]) * L.aet : S.phase_len[S.n_bcf + li] * 2u;
+                if (f & 2u) ebb = (S.strategy == WS_SPARSE) ? (1u + S.eov_cnt[li]) * L.aet : S.phase_len[2u * S.n_bcf + li] * 2u;
+                if (f & 4u) pw = S.phase_len[li];
+            }
+            const uint32_t im = wave_scan_incl(mb), ie = wave_scan_incl(ebb), ip = wave_scan_incl(pw);
+            if (valid) {
+                S.miss_off[li] = miss_bytes + im - mb;
+                S.eov_off[li] = eov_bytes + ie - ebb;
+                S.phase_off[li] = phase_words + ip - pw;
+            }
+            miss_bytes += __shfl(im, 63, 64);
+            eov_bytes += __shfl(ie, 63, 64);
+            phase_words += __shfl(ip, 63, 64);
+            any_m |= __any(f & 1u) ? 1u : 0u;
+            any_e |= __any(f & 2u) ? 1u : 0u;
+            any_p |= __any(f & 4u) ? 1u : 0u;
+            any_h |= __any(f & 8u) ? 1u : 0u;
+            if (__any(valid && !(f & 8u))) maxp = 2;
+        }
+    } else {
+        maxp = 2;
+    }
+    // flag vectors
+    uint32_t flen[FV_COUNT] = {0, 0, 0, 0, 0};
+    const uint32_t present[FV_COUNT] = {1u, any_m, any_e, any_p, any_h};
+    for (uint32_t v = 0; v < FV_COUNT; ++v) {
+        if (!present[v]) continue;
+        const uint32_t* bits = L.flagbits + ((size_t)b * FV_COUNT + v) * (MAX_BIN_PER_BLOCK / 32);
+        uint16_t* dst = L.flagwah + ((size_t)b * FV_COUNT + v) * FLAG_WORDS_MAX;
+        // KEY_LINE_HAPLOID carries one bit per BCF line, the others one per binary line
+        const uint32_t nb = (v == FV_HAPLOID) ? B.n_bcf : B.n_bin;
+        flen[v] = wave_wah_encode_row<true>(bits, nb, dst);
+    }
+    if (lane == 0) {
+        B.wah_words = wah_words;
+        B.has_missing = any_m;
+        B.has_eov = any_e;
+        B.has_phase = any_p;
+        B.has_haploid = any_h;
+        B.max_ploidy = maxp;
+        B.miss_bytes = miss_bytes;
+        B.eov_bytes = eov_bytes;
+        B.phase_words = phase_words;
+        for (uint32_t v = 0; v < FV_COUNT; ++v) B.flag_len[v] = flen[v];
+        B.dict_idx = any_m | (any_e << 1) | (any_p << 2) | (any_h << 3);
+        B.n_keys = c_dict_order[B.dict_idx][0];
+        uint32_t off = 8u + 8u * B.n_keys;
+        B.off_flag[FV_IS_WAH] = off;
+        off += 2u * flen[FV_IS_WAH];
+        B.off_wah = off;
+        off += 2u * wah_words;
+        B.off_sparse = off;
+        off += B.sparse_bytes;
+        B.off_flag[FV_MISSING] = off;
+        B.off_miss = off;
+        if (any_m) {
+            off += 2u * flen[FV_MISSING];
+            B.off_miss = off;
+            off += miss_bytes;
+        }
+        B.off_flag[FV_EOV] = off;
+        B.off_eov = off;
+        if (any_e) {
+            off += 2u * flen[FV_EOV];
+            B.off_eov = off;
+            off += eov_bytes;
+        }
+        B.off_flag[FV_PHASE] = off;
+        B.off_phase = off;
+        if (any_p) {
+            off += 2u * flen[FV_PHASE];
+            B.off_phase = off;
+            off += 2u * phase_words;
+        }
+        B.off_flag[FV_HAPLOID] = off;
+        if (any_h) off += 2u * flen[FV_HAPLOID];
+        B.gt_bytes = off;
+        B.block_bytes = (16u + off + 3u) & ~3u;
+    }
+    (void)default_phased;
+}
+
+hipError_t launch_block_layout(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
+                               const EncSide& S, int32_t default_phased) {
+    if (!n_blocks) return hipSuccess;
+    k_block_layout<<<dim3(n_blocks), dim3(64), 0, s>>>(blocks, L, S, default_phased);
+    return hipGetLastError();
+}
+
+// block offsets in the blocks region (xsi_factory.hpp:533: indices.push_back(s.tellp())).
+// d_result: [0] total bytes, [1] n_blocks, [2] total WAH lines, [3] error (1 = capacity)
+__global__ void __launch_bounds__(1024) k_scan_blocks_out(EncBlock* __restrict__ blocks, uint32_t n_blocks,
+                                                          uint64_t capacity, uint64_t* __restrict__ d_block_offsets,
+                                                          uint64_t* __restrict__ d_result) {
+    __shared__ uint64_t s_scan[20];
+    uint64_t base = 0;
+    uint32_t wah = 0;
+    for (uint32_t c0 = 0; c0 < n_blocks; c0 += blockDim.x) {
+        const uint32_t i = c0 + threadIdx.x;
+        const uint64_t v = i < n_blocks ? blocks[i].block_bytes : 0u;
+        uint64_t tot;
+        const uint64_t ex = block_scan_excl64(v, s_scan, &tot);
+        if (i < n_blocks) {
+            blocks[i].out_off = base + ex;
+            if (d_block_offsets) d_block_offsets[i] = 256u + base + ex;
+        }
+        base += tot;
+    }
+    if (threadIdx.x == 0) {
+        for (uint32_t i = 0; i < n_blocks; ++i) wah += blocks[i].n_wah;
+        d_result[0] = base;
+        d_result[1] = n_blocks;
+        d_result[2] = wah;
+        d_result[3] = base > capacity ? 1u : 0u;
+    }
+}
+
+hipError_t launch_scan_blocks_out(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, uint64_t capacity,
+                                  uint64_t* d_block_offsets, uint64_t* d_result) {
+    k_scan_blocks_out<<<dim3(1), dim3(1024), 0, s>>>(blocks, n_blocks, capacity, d_block_offsets, d_result);
+    return hipGetLastError();
+}
+
+// outer dictionary, GT dictionary and flag vectors of every block (interfaces.hpp:176-239;
+// gt_block.hpp:185-204, 464-510), plus the zero pad to 4 bytes (interfaces.hpp:254-263).
+__global__ void __launch_bounds__(256) k_write_headers(const EncBlock* __restrict__ blocks, EncLines L,
+                                                       int32_t default_phased, uint32_t strategy,
+                                                       uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result) {
+    if (d_result[3]) return;
+    const uint32_t b = blockIdx.x;
+    const EncBlock& B = blocks[b];
+    uint8_t* blk = out + B.out_off;
+    uint32_t* o32 = reinterpret_cast<uint32_t*>(blk);
+    if (threadIdx.x == 0) {
+        o32[0] = 0xFFFFFFFFu;
+        o32[1] = 1u;
+        o32[2] = KEY_GT_ENTRY;
+        o32[3] = 16u;
+        o32[4] = 0xFFFFFFFFu;
+        o32[5] = B.n_keys;
+        for (uint32_t i = 0; i < B.n_keys; ++i) {
+            const uint32_t key = c_dict_order[B.dict_idx][1 + i];
+            uint32_t val = VAL_UNDEFINED;
+            switch (key) {
+                case KEY_BCF_LINES: val = B.n_bcf; break;
+                case KEY_BINARY_LINES: val = B.n_bin; break;
+                case KEY_MAX_LINE_PLOIDY: val = B.max_ploidy; break;
+                case KEY_DEFAULT_PHASING: val = (uint32_t)default_phased; break;
+                case KEY_WEIRDNESS_STRATEGY: val = strategy; break;
+                case KEY_LINE_SORT:
+                case KEY_LINE_SELECT: val = B.off_flag[FV_IS_WAH]; break;
+                case KEY_MATRIX_WAH: val = B.off_wah; break;
+                case KEY_MATRIX_SPARSE: val = B.off_sparse; break;
+                case KEY_LINE_MISSING: val = B.off_flag[FV_MISSING]; break;
+                case KEY_MATRIX_MISSING: val = (strategy == WS_SPARSE) ? VAL_UNDEFINED : B.off_miss; break;
+                case KEY_MATRIX_MISSING_SPARSE: val = (strategy == WS_SPARSE) ? B.off_miss : VAL_UNDEFINED; break;
+                case KEY_LINE_END_OF_VECTORS: val = B.off_flag[FV_EOV]; break;
+                case KEY_MATRIX_END_OF_VECTORS: val = (strategy == WS_SPARSE) ? VAL_UNDEFINED : B.off_eov; break;
+                case KEY_MATRIX_END_OF_VECTORS_SPARSE: val = (strategy == WS_SPARSE) ? B.off_eov : VAL_UNDEFINED; break;
+                case KEY_LINE_NON_UNIFORM_PHASING: val = B.off_flag[FV_PHASE]; break;
+                case KEY_MATRIX_NON_UNIFORM_PHASING: val = B.off_phase; break;
+                case KEY_LINE_HAPLOID: val = B.off_flag[FV_HAPLOID]; break;
+                default: break;
+            }
+            o32[6 + 2 * i] = key;
+            o32[7 + 2 * i] = val;
+        }
+        // pad bytes
+        for (uint32_t p = 16u + B.gt_bytes; p < B.block_bytes; ++p) blk[p] = 0;
+    }
+    const uint32_t present[FV_COUNT] = {1u, B.has_missing, B.has_eov, B.has_phase, B.has_haploid};
+    for (uint32_t v = 0; v < FV_COUNT; ++v) {
+        if (!present[v]) continue;
+        const uint16_t* src = L.flagwah + ((size_t)b * FV_COUNT + v) * FLAG_WORDS_MAX;
+        uint16_t* dst = reinterpret_cast<uint16_t*>(blk + 16u + B.off_flag[v]);
+        for (uint32_t i = threadIdx.x; i < B.flag_len[v]; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+hipError_t launch_write_headers(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
+                                int32_t default_phased, uint32_t strategy, uint8_t* out, const uint64_t* d_result) {
+    if (!n_blocks) return hipSuccess;
+    k_write_headers<<<dim3(n_blocks), dim3(256), 0, s>>>(blocks, L, default_phased, strategy, out, d_result);
+    return hipGetLastError();
+}
+
+// ==========================================================================================
+// Decode
+// ==========================================================================================
+__device__ __forceinline__ uint32_t rd32(const uint8_t* p) {  // 4-byte aligned by format
+    return *reinterpret_cast<const uint32_t*>(p);
+}
+__device__ __forceinline__ uint32_t rd_at(const uint8_t* p, uint32_t aet) {  // 2-byte aligned A_T
+    const uint16_t* q = reinterpret_cast<const uint16_t*>(p);
+    uint32_t v = q[0];
+    if (aet == 4u) v |= (uint32_t)q[1] << 16;
+    return v;
+}
+
+// parse the outer and GT dictionaries of each block (set_block_ptr + DecompressPointerGTBlock
+// ctor, accessor_internals_new.hpp:830-893, 52-148).  One thread per block.
+__global__ void __launch_bounds__(256) k_parse_blocks(const uint8_t* __restrict__ file, uint64_t file_len,
+                                                      uint64_t indices_offset, uint32_t version, uint64_t first_block,
+                                                      uint32_t n_blocks, DecBlock* __restrict__ blocks) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    DecBlock D{};
+    const uint64_t bi = first_block + b;
+    uint64_t off;
+    if (version >= 5) {
+        const uint32_t* ip = reinterpret_cast<const uint32_t*>(file + indices_offset + bi * 8u);
+        off = (uint64_t)ip[0] | ((uint64_t)ip[1] << 32);
+    } else {
+        off = rd32(file + indices_offset + bi * 4u);
+    }
+    D.file_off = off;
+    D.error = 0;
+    if (off + 16u > file_len || (off & 3u)) {
+        D.error = 1;
+        blocks[b] = D;
+        return;
+    }
+    const uint8_t* blk = file + off;
+    const uint32_t n_outer = rd32(blk + 4);
+    uint32_t gt_rel = VAL_UNDEFINED;
+    for (uint32_t i = 0; i < n_outer && i < 64u; ++i)
+        if (rd32(blk + 8 + 8 * i) == KEY_GT_ENTRY) gt_rel = rd32(blk + 12 + 8 * i);
+    if (gt_rel == VAL_UNDEFINED) {
+        D.error = 2;
+        blocks[b] = D;
+        return;
+    }
+    D.gt_off = off + gt_rel;
+    const uint8_t* gt = file + D.gt_off;
+    const uint32_t n = rd32(gt + 4);
+    uint32_t vals[0x40];
+    for (int i = 0; i < 0x40; ++i) vals[i] = VAL_UNDEFINED;
+    for (uint32_t i = 0; i < n && i < 64u; ++i) {
+        const uint32_t k = rd32(gt + 8 + 8 * i), v = rd32(gt + 12 + 8 * i);
+        if (k < 0x40u) vals[k] = v;
+    }
+    D.n_bcf = vals[KEY_BCF_LINES];
+    D.n_bin = vals[KEY_BINARY_LINES];
+    D.max_ploidy = vals[KEY_MAX_LINE_PLOIDY] == VAL_UNDEFINED ? 2u : vals[KEY_MAX_LINE_PLOIDY];
+    D.default_phasing = vals[KEY_DEFAULT_PHASING] == 1u ? 1u : 0u;  // accessor_internals_new.hpp:77-81
+    D.strategy = vals[KEY_WEIRDNESS_STRATEGY] == VAL_UNDEFINED ? WS_PBWT_WAH : vals[KEY_WEIRDNESS_STRATEGY];
+    D.off_select = vals[KEY_LINE_SELECT];
+    D.off_wah = vals[KEY_MATRIX_WAH];
+    D.off_sparse = vals[KEY_MATRIX_SPARSE];
+    D.off_line_missing = vals[KEY_LINE_MISSING];
+    D.off_miss_wah = vals[KEY_MATRIX_MISSING];
+    D.off_miss_sparse = vals[KEY_MATRIX_MISSING_SPARSE];
+    D.off_line_eov = vals[KEY_LINE_END_OF_VECTORS];
+    D.off_eov_wah = vals[KEY_MATRIX_END_OF_VECTORS];
+    D.off_eov_sparse = vals[KEY_MATRIX_END_OF_VECTORS_SPARSE];
+    D.off_line_phase = vals[KEY_LINE_NON_UNIFORM_PHASING];
+    D.off_phase = vals[KEY_MATRIX_NON_UNIFORM_PHASING];
+    D.off_line_haploid = vals[KEY_LINE_HAPLOID];
+    if (D.n_bcf == VAL_UNDEFINED || D.n_bin == VAL_UNDEFINED || D.n_bin > MAX_BIN_PER_BLOCK ||
+        D.off_select == VAL_UNDEFINED || D.off_wah == VAL_UNDEFINED || D.off_sparse == VAL_UNDEFINED ||
+        D.off_sparse < D.off_wah)
+        D.error = 3;
+    D.wah_words = D.error ? 0u : (D.off_sparse - D.off_wah) / 2u;
+    blocks[b] = D;
+}
+
+hipError_t launch_parse_blocks(hipStream_t s, const uint8_t* file, uint64_t file_len, uint64_t indices_offset,
+                               uint32_t version, uint64_t first_block, uint32_t n_blocks, DecBlock* blocks,
+                               uint32_t* d_totals) {
+    (void)d_totals;
+    if (!n_blocks) return hipSuccess;
+    k_parse_blocks<<<dim3((n_blocks + 255u) / 256u), dim3(256), 0, s>>>(file, file_len, indices_offset, version,
+                                                                        first_block, n_blocks, blocks);
+    return hipGetLastError();
+}
+
+// batch-wide exclusive scans over the parsed blocks: first_bin / first_bcf.
+// d_totals: [0] binary lines, [1] WAH lines, [2] sparse lines, [3] error, [4] BCF lines
+__global__ void __launch_bounds__(1024) k_scan_dec_blocks(DecBlock* __restrict__ blocks, uint32_t n_blocks,
+                                                          uint32_t* __restrict__ d_totals, int phase) {
+    __shared__ uint64_t s_scan[20];
+    uint32_t b0 = 0, b1 = 0, err = 0;
+    for (uint32_t c0 = 0; c0 < n_blocks; c0 += blockDim.x) {
+        const uint32_t i = c0 + threadIdx.x;
+        uint64_t v = 0;
+        if (i < n_blocks) {
+            if (phase == 0)
+                v = ((uint64_t)blocks[i].n_bin << 32) | blocks[i].n_bcf;
+            else
+                v = ((uint64_t)blocks[i].n_wah << 32) | blocks[i].n_sparse;
+            if (blocks[i].error) err = 1;
+        }
+        uint64_t tot;
+        const uint64_t ex = block_scan_excl64(v, s_scan, &tot);
+        if (i < n_blocks) {
+            if (phase == 0) {
+                blocks[i].first_bin = b0 + (uint32_t)(ex >> 32);
+                blocks[i].first_bcf = b1 + (uint32_t)ex;
+            } else {
+                blocks[i].wah_first = b0 + (uint32_t)(ex >> 32);
+                blocks[i].sparse_first = b1 + (uint32_t)ex;
+            }
+        }
+        b0 += (uint32_t)(tot >> 32);
+        b1 += (uint32_t)tot;
+    }
+    err = __syncthreads_or((int)err) ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        if (phase == 0) {
+            d_totals[0] = b0;
+            d_totals[4] = b1;
+            d_totals[3] = err;
+        } else {
+            d_totals[1] = b0;
+            d_totals[2] = b1;
+            if (err) d_totals[3] = 1;
+        }
+    }
+}
+
+hipError_t launch_scan_dec_blocks(hipStream_t s, DecBlock* blocks, uint32_t n_blocks, uint32_t* d_totals) {
+    k_scan_dec_blocks<<<dim3(1), dim3(1024), 0, s>>>(blocks, n_blocks, d_totals, 0);
+    return hipGetLastError();
+}
+
+// flag vectors -> per-line kinds and ranks (fill_bool_vector_from_1d_dict_key,
+// accessor_internals_new.hpp:591-604; sorting lines == WAH lines for this writer).  One
+// workgroup of 64 per block; the vector is expanded into LDS.
+__global__ void __launch_bounds__(64) k_decode_flags(const uint8_t* __restrict__ file, DecBlock* __restrict__ blocks,
+                                                     DecLines L) {
+    __shared__ uint32_t s_row[MAX_BIN_PER_BLOCK / 32 + 2];
+    __shared__ uint32_t s_hap[MAX_BIN_PER_BLOCK / 32 + 2];
+    DecBlock& D = blocks[blockIdx.x];
+    if (D.error) return;
+    const uint32_t lane = lane_id();
+    const uint32_t nb = D.n_bin;
+    const uint32_t nw = (nb + 31u) >> 5;
+    for (uint32_t i = lane; i < nw + 1u; i += 64u) {
+        s_row[i] = 0;
+        s_hap[i] = 0;
+    }
+    __syncthreads();
+    uint32_t ones;
+    const uint8_t* gt = file + D.gt_off;
+    auto words_left = [&](uint32_t rel) -> uint32_t {
+        const uint64_t at = D.gt_off + rel;
+        if (at >= L.file_len) return 0u;
+        const uint64_t left = (L.file_len - at) / 2u;
+        return left < FLAG_WORDS_MAX ? (uint32_t)left : FLAG_WORDS_MAX;
+    };
+    (void)wave_wah_expand_row(reinterpret_cast<const uint16_t*>(gt + D.off_select), words_left(D.off_select), nb, s_row, &ones);
+    if (D.off_line_haploid != VAL_UNDEFINED) {
+        // read per binary line although written per BCF line (kept)
+        uint32_t o2;
+        (void)wave_wah_expand_row(reinterpret_cast<const uint16_t*>(gt + D.off_line_haploid),
+                                  words_left(D.off_line_haploid), nb, s_hap, &o2);
+    }
+    __syncthreads();
+    uint32_t wbase = 0, sbase = 0;
+    for (uint32_t i0 = 0; i0 < nb; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < nb;
+        const uint32_t isw = valid ? ((s_row[i >> 5] >> (i & 31u)) & 1u) : 0u;
+        const uint32_t hap = valid ? ((s_hap[i >> 5] >> (i & 31u)) & 1u) : 0u;
+        const uint64_t Wm = __ballot(isw), Vm = __ballot(valid);
+        const uint32_t wr = wbase + mbcnt64(Wm);
+        const uint32_t sr = sbase + mbcnt64(Vm & ~Wm);
+        if (valid) {
+            const uint32_t l = D.first_bin + i;
+            L.kind[l] = (uint8_t)((isw ? KIND_WAH : 0u) | (hap ? KIND_HAPLOID : 0u));
+            L.line_block[l] = blockIdx.x;
+            L.rank[l] = isw ? wr : sr;
+        }
+        wbase += (uint32_t)__popcll(Wm);
+        sbase += (uint32_t)__popcll(Vm & ~Wm);
+    }
+    if (lane == 0) {
+        D.n_wah = wbase;
+        D.n_sparse = sbase;
+    }
+}
+
+hipError_t launch_decode_flags(hipStream_t s, const uint8_t* file, DecBlock* blocks, uint32_t n_blocks,
+                               const DecLines& L) {
+    if (!n_blocks) return hipSuccess;
+    k_decode_flags<<<dim3(n_blocks), dim3(64), 0, s>>>(file, blocks, L);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipSuccess;
+}
+
+hipError_t launch_scan_dec_blocks2(hipStream_t s, DecBlock* blocks, uint32_t n_blocks, uint32_t* d_totals) {
+    k_scan_dec_blocks<<<dim3(1), dim3(1024), 0, s>>>(blocks, n_blocks, d_totals, 1);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) k_dec_line_lists(const DecBlock* __restrict__ blocks, DecLines L) {
+    const DecBlock& D = blocks[blockIdx.x];
+    if (D.error) return;
+    for (uint32_t i = threadIdx.x; i < D.n_bin; i += blockDim.x) {
+        const uint32_t l = D.first_bin + i;
+        if (L.kind[l] & KIND_WAH)
+            L.wah_lines[D.wah_first + L.rank[l]] = l;
+        else
+            L.sparse_lines[D.sparse_first + L.rank[l]] = l;
+    }
+}
+
+hipError_t launch_dec_line_lists(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L) {
+    if (!n_blocks) return hipSuccess;
+    k_dec_line_lists<<<dim3(n_blocks), dim3(256), 0, s>>>(blocks, L);
+    return hipGetLastError();
+}
+
+// WAH line boundaries.  Lines carry no length: a line ends when its
+// ceil(n/15) groups are covered, and this writer never lets a fill run cross a line.  So the
+// running group count over the whole matrix hits every line's cumulative group offset exactly
+// at that line's first word.  One workgroup per block: chunked scan of groups-per-word.
+__global__ void __launch_bounds__(1024) k_wah_boundaries(const uint8_t* __restrict__ file,
+                                                         const DecBlock* __restrict__ blocks, DecLines L) {
+    __shared__ uint64_t s_scan[20];
+    const DecBlock& D = blocks[blockIdx.x];
+    if (D.error || D.n_wah == 0) return;
+    const uint16_t* wm = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah);
+    const uint32_t nwords = D.wah_words;
+    constexpr uint32_t K = 8;  // consecutive words per thread
+    // cumulative group offsets of the lines: uniform G unless the block has haploid lines
+    const uint32_t Gd = (L.N + WAH_BITS - 1u) / WAH_BITS;
+    const uint32_t Gh = (L.n_samples + WAH_BITS - 1u) / WAH_BITS;
+    const bool mixed = D.off_line_haploid != VAL_UNDEFINED;
+    if (mixed) {
+        // cumulative groups before each WAH line (haploid lines have n_samples bits)
+        uint32_t cb = 0;
+        for (uint32_t j0 = 0; j0 < D.n_wah; j0 += blockDim.x) {
+            const uint32_t j = j0 + threadIdx.x;
+            uint32_t gl = 0;
+            if (j < D.n_wah) gl = (L.kind[L.wah_lines[D.wah_first + j]] & KIND_HAPLOID) ? Gh : Gd;
+            uint64_t tot;
+            const uint64_t ex = block_scan_excl64(gl, s_scan, &tot);
+            if (j < D.n_wah) L.wah_cumg[D.wah_first + j] = cb + (uint32_t)ex;
+            cb += (uint32_t)tot;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    uint64_t gbase = 0;
+    for (uint32_t c0 = 0; c0 < nwords; c0 += blockDim.x * K) {
+        const uint32_t w0 = c0 + threadIdx.x * K;
+        uint32_t g[K];
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t wi = w0 + k;
+            uint32_t ng = 0;
+            if (wi < nwords) {
+                const uint32_t word = wm[wi];
+                ng = (word & 0x8000u) ? (word & WAH_MAXC) : 1u;
+            }
+            g[k] = ng;
+            sum += ng;
+        }
+        uint64_t tot;
+        uint64_t ex = gbase + block_scan_excl64(sum, s_scan, &tot);
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t wi = w0 + k;
+            if (wi < nwords && g[k]) {
+                if (!mixed) {
+                    if (ex % Gd == 0) {
+                        const uint64_t j = ex / Gd;
+                        if (j < D.n_wah) L.wah_start[D.wah_first + (uint32_t)j] = wi;
+                    }
+                } else {
+                    // first line whose cumulative offset is >= ex
+                    uint32_t lo = 0, hi = D.n_wah;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((uint64_t)L.wah_cumg[D.wah_first + mid] < ex)
+                            lo = mid + 1u;
+                        else
+                            hi = mid;
+                    }
+                    if (lo < D.n_wah && (uint64_t)L.wah_cumg[D.wah_first + lo] == ex) L.wah_start[D.wah_first + lo] = wi;
+                }
+            }
+            ex += g[k];
+        }
+        gbase += tot;
+    }
+}
+
+hipError_t launch_wah_boundaries(hipStream_t s, const uint8_t* file, const DecBlock* blocks, uint32_t n_blocks,
+                                 const DecLines& L) {
+    if (!n_blocks) return hipSuccess;
+    k_wah_boundaries<<<dim3(n_blocks), dim3(1024), 0, s>>>(file, blocks, L);
+    return hipGetLastError();
+}
+
+// sparse line starts: each list is `count, idx[count]` with no index, so the starts are a
+// pointer chase (sparse_advance_pointer, accessor_internals_new.hpp:639-653).  One wave per
+// block stages the matrix through LDS in 16 KiB tiles and lane 0 hops inside the tile.
+__global__ void __launch_bounds__(64) k_sparse_walk(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
+                                                    DecLines L) {
+    constexpr uint32_t TILE = 8192;  // uint16 units
+    __shared__ uint16_t s_tile[TILE];
+    const DecBlock& D = blocks[blockIdx.x];
+    if (D.error || D.n_sparse == 0) return;
+    const uint16_t* sm = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_sparse);
+    const uint32_t units = L.aet / 2u;  // uint16 units per A_T
+    const uint32_t lane = lane_id();
+    uint64_t pos = 0;  // in uint16 units
+    uint32_t k = 0;
+    const uint64_t sm_at = D.gt_off + D.off_sparse;
+    const uint64_t sm_units = sm_at < L.file_len ? (L.file_len - sm_at) / 2u : 0u;  // never read past the image
+    while (k < D.n_sparse) {
+        const uint64_t t0 = pos;
+        for (uint32_t i = lane; i < TILE; i += 64u) s_tile[i] = (t0 + i < sm_units) ? sm[t0 + i] : (uint16_t)0;
+        __syncthreads();
+        if (lane == 0) {
+            while (k < D.n_sparse && pos + units <= t0 + TILE) {
+                uint32_t num = s_tile[pos - t0];
+                if (units == 2u) num |= (uint32_t)s_tile[pos - t0 + 1] << 16;
+                num &= (units == 2u) ? 0x7FFFFFFFu : 0x7FFFu;
+                L.sparse_start[D.sparse_first + k] = (uint32_t)(pos * 2u);
+                pos += (uint64_t)(1u + num) * units;
+                ++k;
+            }
+            s_tile[0] = 0;
+        }
+        pos = __shfl(pos, 0, 64);
+        k = __shfl(k, 0, 64);
+        __syncthreads();
+    }
+}
+
+hipError_t launch_sparse_walk(hipStream_t s, const uint8_t* file, const DecBlock* blocks, uint32_t n_blocks,
+                              const DecLines& L) {
+    if (!n_blocks) return hipSuccess;
+    k_sparse_walk<<<dim3(n_blocks), dim3(64), 0, s>>>(file, blocks, L);
+    return hipGetLastError();
+}
+
+// expand every WAH line into its permuted bit row (wah2_extract_count_ones, wah.hpp:232-235).
+// One wave per line, row built in LDS then streamed out.
+__global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
+                                                   DecLines L, const uint32_t* __restrict__ d_totals) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* row = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t j = blockIdx.x;
+    if (j >= d_totals[1] || d_totals[3]) return;
+    const uint32_t l = L.wah_lines[j];
+    const DecBlock& D = blocks[L.line_block[l]];
+    const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
+    const uint32_t lane = lane_id();
+    const uint32_t rw = L.y_stride64 * 2u;
+    for (uint32_t i = lane; i < rw; i += 64u) row[i] = 0;
+    __syncthreads();
+    const uint32_t start = L.wah_start[j];
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah) + start;
+    uint32_t ones;
+    (void)wave_wah_expand_row(src, D.wah_words - start, nbits, row, &ones);
+    __syncthreads();
+    uint32_t* dst = reinterpret_cast<uint32_t*>(L.yrows + (size_t)j * L.y_stride64);
+    for (uint32_t i = lane; i < rw; i += 64u) dst[i] = row[i];
+    if (lane == 0) L.ones[l] = ones;
+}
+
+hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
+                             uint32_t max_wah, const uint32_t* d_totals) {
+    if (!max_wah) return hipSuccess;
+    const uint32_t lds = L.y_stride64 * 8u;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_expand),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    k_wah_expand<<<dim3(max_wah), dim3(64), lds, s>>>(file, blocks, L, d_totals);
+    return hipGetLastError();
+}
+
+// sparse lines -> bit rows (sparse_extract + the fill loops of fill_genotype_array_advance,
+// accessor_internals_new.hpp:208-219, 619-637).  apply_negation: write the ALT bit row of a
+// negated bi-allelic line (complement of the listed REF positions); otherwise the raw listed
+// positions are written and KIND_NEGATED is left for the composer.
+__global__ void __launch_bounds__(64) k_sparse_fill(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
+                                                    DecLines L, const uint32_t* __restrict__ d_totals,
+                                                    uint32_t* __restrict__ out_rows, uint32_t out_stride_w,
+                                                    int apply_negation) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* row = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t k = blockIdx.x;
+    if (k >= d_totals[2] || d_totals[3]) return;
+    const uint32_t l = L.sparse_lines[k];
+    const DecBlock& D = blocks[L.line_block[l]];
+    const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
+    const uint32_t nw = (nbits + 31u) >> 5;
+    const uint32_t lane = lane_id();
+    for (uint32_t i = lane; i < out_stride_w; i += 64u) row[i] = 0;
+    __syncthreads();
+    const uint8_t* p = file + D.gt_off + D.off_sparse + L.sparse_start[k];
+    uint32_t num = rd_at(p, L.aet);
+    const uint32_t msb = (L.aet == 2u) ? 0x8000u : 0x80000000u;
+    const bool neg = (num & msb) != 0u;
+    num &= ~msb;
+    {
+        const uint64_t at = D.gt_off + D.off_sparse + L.sparse_start[k];
+        const uint64_t room = at + L.aet <= L.file_len ? (L.file_len - at) / L.aet - 1u : 0u;
+        if (num > room) num = (uint32_t)room;  // corrupt image: stay inside it
+    }
+    for (uint32_t i = lane; i < num; i += 64u) {
+        const uint32_t idx = rd_at(p + (size_t)(1u + i) * L.aet, L.aet);
+        if (idx < nbits) atomicOr(&row[idx >> 5], 1u << (idx & 31u));
+    }
+    __syncthreads();
+    uint32_t* dst = out_rows + (size_t)l * out_stride_w;
+    for (uint32_t i = lane; i < out_stride_w; i += 64u) {
+        uint32_t v = row[i];
+        if (neg && apply_negation) {
+            v = (i < nw) ? ~v : 0u;
+            if (i == nw - 1u && (nbits & 31u)) v &= (1u << (nbits & 31u)) - 1u;
+        }
+        dst[i] = v;
+    }
+    if (lane == 0) {
+        L.ones[l] = neg ? nbits - num : num;  // sparse_extract: ones = negated ? N - num : num
+        if (neg) L.kind[l] |= KIND_NEGATED;
+    }
+}
+
+hipError_t launch_sparse_fill(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
+                              uint32_t max_sparse, const uint32_t* d_totals, uint32_t* out_rows,
+                              uint32_t out_stride_w, int apply_negation) {
+    if (!max_sparse) return hipSuccess;
+    const uint32_t lds = out_stride_w * 4u;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sparse_fill),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    k_sparse_fill<<<dim3(max_sparse), dim3(64), lds, s>>>(file, blocks, L, d_totals, out_rows, out_stride_w,
+                                                          apply_negation);
+    return hipGetLastError();
+}
+
+// ==========================================================================================
+// Synthetic haplotype matrix (definition in DESIGN.md §"Synthetic workload"; numpy mirror in
+// xsqueezeit_amd/synth.py).  Integer-only, splitmix64-based, so host and device agree exactly.
+// ==========================================================================================
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+constexpr uint32_t SYN_FOUNDERS = 256;
+constexpr uint32_t SYN_SEG = 4096;
+constexpr uint32_t SYN_MUT = 1u << 20;  // 2^32 / 4096
+
+__global__ void __launch_bounds__(256) k_synth_packed(uint64_t seed, uint64_t first_line, uint64_t n_lines,
+                                                      uint32_t n_haps, uint32_t* __restrict__ bits, uint32_t stride_w) {
+    const uint64_t row = blockIdx.y;
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_lines || w >= stride_w) return;
+    const uint32_t nw = (n_haps + 31u) >> 5;
+    uint32_t out = 0;
+    if (w < nw) {
+        const uint64_t site = first_line + row;
+        const uint64_t hs = mix64(seed * 0x9E3779B97F4A7C15ull + site + 1ull);
+        uint32_t nb = 0;
+        while ((1ull << nb) < (uint64_t)n_haps) ++nb;  // bit length of n_haps-1 (n_haps >= 2)
+        if (nb == 0) nb = 1;
+        const uint32_t e = (uint32_t)(hs & 0xFFFFull) % nb;
+        uint64_t k = (1ull << e) + ((hs >> 16) & ((1ull << e) - 1ull));
+        if (k > (uint64_t)n_haps - 1ull) k = (uint64_t)n_haps - 1ull;
+        const uint32_t t32 = (uint32_t)((k << 32) / (uint64_t)n_haps);
+        const bool rare = k * SYN_FOUNDERS < 4ull * n_haps;
+        for (uint32_t b = 0; b < 32u; ++b) {
+            const uint64_t h = (uint64_t)w * 32u + b;
+            if (h >= n_haps) break;
+            uint32_t bit;
+            if (rare) {
+                const uint64_t r = mix64(hs ^ (h * 0xD1B54A32D192ED03ull + 1ull));
+                bit = (uint32_t)(r >> 32) < t32;
+            } else {
+                const uint64_t off = mix64(seed ^ (h * 0xD1B54A32D192ED03ull + 7ull)) % SYN_SEG;
+                const uint64_t seg = (site + off) / SYN_SEG;
+                const uint64_t g = mix64(seed + h * 0x9E3779B97F4A7C15ull + seg * 0xC2B2AE3D27D4EB4Full) % SYN_FOUNDERS;
+                const uint64_t r = mix64(hs ^ (g * 0xD1B54A32D192ED03ull + 0x51EDull));
+                bit = (uint32_t)(r >> 32) < t32;
+                const uint64_t r2 = mix64(hs ^ (h * 0xD1B54A32D192ED03ull + 0xABCDull));
+                if ((uint32_t)(r2 >> 32) < SYN_MUT) bit ^= 1u;
+            }
+            out |= bit << b;
+        }
+    }
+    bits[row * stride_w + w] = out;
+}
+
+hipError_t launch_synth_packed(hipStream_t s, uint64_t seed, uint64_t first_line, uint64_t n_lines, uint32_t n_haps,
+                               uint32_t* bits, uint32_t stride_w) {
+    if (!n_lines) return hipSuccess;
+    // grid.y is limited to 65535: loop in slabs
+    const uint64_t slab = 65535;
+    for (uint64_t r0 = 0; r0 < n_lines; r0 += slab) {
+        const uint64_t n = (n_lines - r0 < slab) ? n_lines - r0 : slab;
+        k_synth_packed<<<dim3((stride_w + 255u) / 256u, (uint32_t)n), dim3(256), 0, s>>>(
+            seed, first_line + r0, n, n_haps, bits + r0 * stride_w, stride_w);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace xsi

@@ -1,0 +1,130 @@
+// xsi_kernels.hpp — launchers of the gfx950 kernels (implemented in xsi_kernels.hip).
+// All launchers enqueue on `s` and return the hipError_t of the launch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "xsi_common.hpp"
+
+namespace xsi {
+
+// ---- per-line metadata of an encode batch (device arrays, indexed by binary line) ----
+struct EncLines {
+    const uint32_t* planes;     // bit row of binary line l at planes + l*plane_stride_w (natural hap order)
+    uint32_t plane_stride_w;
+    uint32_t n_bin;
+    uint32_t N;                 // 2 * n_samples
+    uint32_t aet;               // A_T bytes of the block encoder (2 or 4)
+    uint32_t thr;               // MAC threshold
+    // general path only (nullptr on the packed fast path)
+    const uint32_t* bin_nbits;  // GT values of the parent BCF line (N or N/2)
+    const uint32_t* bin_parent; // parent BCF line
+    const uint32_t* ref_planes; // per BCF line: allele == 0 plane (stride = plane_stride_w)
+    const uint32_t* ref_cnt;    // per BCF line: count of allele == 0
+    // outputs of the classification
+    uint32_t* cnt;              // ones per binary line
+    uint8_t* kind;              // KIND_* bits
+    uint32_t* line_block;       // block of each binary line
+    uint32_t* wah_rank;         // rank among the block's WAH lines
+    uint32_t* sparse_off;       // byte offset inside the block's sparse matrix
+    uint32_t* wah_lines;        // batch-wide list of WAH binary lines, in order
+    uint32_t* wah_len;          // words per WAH line (by batch-wide rank)
+    uint32_t* wah_off;          // word offset inside the block's WAH matrix (by batch-wide rank)
+    uint64_t* yrows;            // permuted bit rows, one per WAH line (by batch-wide rank)
+    uint32_t y_stride64;
+    uint32_t* flagbits;         // [n_blocks][FV_COUNT][MAX_BIN_PER_BLOCK/32] packed flag vectors
+    uint16_t* flagwah;          // [n_blocks][FV_COUNT][FLAG_WORDS_MAX] encoded flag vectors
+};
+
+// side channels of the general path (per BCF line planes; nullptr on the fast path)
+struct EncSide {
+    const uint32_t* miss_planes;
+    const uint32_t* eov_planes;
+    const uint32_t* phase_planes;
+    const uint32_t* bcf_nbits;    // GT values per BCF line
+    const uint32_t* bcf_flags;    // bit0 missing, bit1 eov, bit2 phase, bit3 haploid
+    const uint32_t* bcf_first_bin;
+    const uint32_t* miss_cnt;
+    const uint32_t* eov_cnt;
+    uint32_t* miss_off;           // byte offset inside the block's missing matrix
+    uint32_t* eov_off;
+    uint32_t* phase_len;          // words of the phase WAH line
+    uint32_t* phase_off;
+    uint32_t n_bcf;
+    uint32_t strategy;            // WS_SPARSE or WS_WAH
+};
+
+hipError_t launch_count_rows(hipStream_t s, const uint32_t* planes, uint32_t stride_w, uint32_t nbits,
+                             uint32_t n_rows, uint32_t* cnt);
+hipError_t launch_classify(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, const EncLines& L);
+hipError_t launch_scan_blocks_wah(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, uint32_t* totals);
+hipError_t launch_build_wah_list(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L);
+hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
+                               uint32_t* scratch_a /*global-memory variant only*/);
+hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_total_wah, uint32_t max_wah);
+hipError_t launch_block_layout(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
+                               const EncSide& S, int32_t default_phased);
+hipError_t launch_scan_blocks_out(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, uint64_t capacity,
+                                  uint64_t* d_block_offsets, uint64_t* d_result /*[4]*/);
+hipError_t launch_write_headers(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
+                                int32_t default_phased, uint32_t strategy, uint8_t* out, const uint64_t* d_result);
+hipError_t launch_wah_write(hipStream_t s, const EncBlock* blocks, const EncLines& L, uint32_t max_wah,
+                            uint8_t* out, const uint64_t* d_result);
+hipError_t launch_sparse_write(hipStream_t s, const EncBlock* blocks, const EncLines& L, uint8_t* out,
+                               const uint64_t* d_result);
+
+// ---- decode ----
+struct DecLines {
+    uint32_t N;            // 2 * n_samples
+    uint32_t n_samples;
+    uint32_t aet;          // header.aet_bytes
+    uint32_t max_bin;      // capacity of the per-line arrays
+    uint8_t* kind;         // per binary line (batch-wide index)
+    uint32_t* line_block;
+    uint32_t* rank;        // rank among the block's WAH (or sparse) lines
+    uint32_t* wah_start;   // [wah rank] word offset of the line inside the block's WAH matrix
+    uint32_t* sparse_start;// [sparse rank] byte offset inside the block's sparse matrix
+    uint32_t* wah_lines;   // [wah rank] binary line
+    uint32_t* sparse_lines;
+    uint64_t* yrows;       // [wah rank] permuted rows
+    uint32_t y_stride64;
+    uint32_t* ones;        // per binary line: allele count (accessor "ones")
+    uint32_t* wah_cumg;    // [wah rank] cumulative 15-bit groups before the line (mixed-ploidy blocks)
+    uint64_t file_len;     // bytes of the file image (bounds every read)
+};
+
+hipError_t launch_parse_blocks(hipStream_t s, const uint8_t* file, uint64_t file_len, uint64_t indices_offset,
+                               uint32_t version, uint64_t first_block, uint32_t n_blocks, DecBlock* blocks,
+                               uint32_t* d_totals /*[4]: n_bin, n_wah, n_sparse, error*/);
+hipError_t launch_decode_flags(hipStream_t s, const uint8_t* file, DecBlock* blocks, uint32_t n_blocks,
+                               const DecLines& L);
+hipError_t launch_scan_dec_blocks(hipStream_t s, DecBlock* blocks, uint32_t n_blocks, uint32_t* d_totals);
+hipError_t launch_scan_dec_blocks2(hipStream_t s, DecBlock* blocks, uint32_t n_blocks, uint32_t* d_totals);
+hipError_t launch_dec_line_lists(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L);
+hipError_t launch_wah_boundaries(hipStream_t s, const uint8_t* file, const DecBlock* blocks, uint32_t n_blocks,
+                                 const DecLines& L);
+hipError_t launch_sparse_walk(hipStream_t s, const uint8_t* file, const DecBlock* blocks, uint32_t n_blocks,
+                              const DecLines& L);
+hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
+                             uint32_t max_wah, const uint32_t* d_totals);
+hipError_t launch_chain_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
+                               uint32_t* out_rows, uint32_t out_stride_w, uint32_t* scratch_a);
+hipError_t launch_sparse_fill(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
+                              uint32_t max_sparse, const uint32_t* d_totals, uint32_t* out_rows,
+                              uint32_t out_stride_w, int apply_negation);
+
+// ---- synthetic data ----
+hipError_t launch_synth_packed(hipStream_t s, uint64_t seed, uint64_t first_line, uint64_t n_lines, uint32_t n_haps,
+                               uint32_t* bits, uint32_t stride_w);
+
+// chain kernel geometry (exposed for DESIGN.md / tuning)
+struct ChainGeom {
+    int threads, chunks;       // T, E
+    uint32_t batch;            // columns prefetched per batch
+    uint32_t lds_bytes;
+    bool in_lds;
+};
+ChainGeom chain_geometry(uint32_t N, bool decode);
+
+}  // namespace xsi
