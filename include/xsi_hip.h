@@ -107,6 +107,9 @@ int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_
                       uint64_t n_lines, const uint32_t* h_ngt, const uint32_t* h_n_allele, void* d_out,
                       uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result);
 
+/* Upper bound of the blocks region for xsi_hip_encode_gt (adds the side channels). */
+uint64_t xsi_hip_encode_gt_bound(const xsi_encode_params* p, uint64_t n_bcf_lines, uint64_t n_binary_lines);
+
 /* Fill a complete 256-byte .xsi v5 header (include/compression.hpp:40-104 as written by
  * xsi_factory.hpp:468-500, 543-605).  Host-only helper, no device work. */
 typedef struct xsi_header_fields {

@@ -119,3 +119,62 @@ def numpy_chain_yrows(bits01, block_len, mac_thr):
             out.append((l, y.copy()))
             a = np.concatenate([a[y == 0], a[y == 1]])
     return out
+
+
+# ---------------- general (int32 genotype rows) path ----------------
+def rows_matrix(lines, n_samples):
+    """list of (gt, n_allele) -> (int32 [n_lines, 2*n_samples] padded, ngt, n_allele)."""
+    N = 2 * n_samples
+    m = np.zeros((len(lines), N), dtype=np.int32)
+    ngt = np.zeros(len(lines), dtype=np.uint32)
+    nal = np.zeros(len(lines), dtype=np.uint32)
+    for i, (gt, na) in enumerate(lines):
+        m[i, :len(gt)] = gt
+        ngt[i] = len(gt)
+        nal[i] = na
+    return m, ngt, nal
+
+
+def encode_gt(lines, n_samples, p):
+    torch = torch_mod()
+    L = binding.lib()
+    m, ngt, nal = rows_matrix(lines, n_samples)
+    n_lines = len(lines)
+    n_bin = int((nal - 1).sum())
+    d_gt = torch.from_numpy(m).cuda()
+    cap = int(L.xsi_hip_encode_gt_bound(ctypes.byref(p), n_lines, n_bin))
+    d_out = dev_empty(cap)
+    n_blocks = (n_lines + p.block_len - 1) // p.block_len
+    d_off = torch.zeros(n_blocks, dtype=torch.int64, device="cuda")
+    res = binding.EncodeResult()
+    binding.check(L.xsi_hip_encode_gt(ctx().handle, ctypes.byref(p), d_gt.data_ptr(), m.shape[1], n_lines,
+                                      ngt.ctypes.data, nal.ctypes.data, d_out.data_ptr(), cap, d_off.data_ptr(),
+                                      ctypes.byref(res)))
+    region = d_out[:res.blocks_bytes].cpu().numpy().tobytes()
+    return region, d_off.cpu().numpy().astype(np.uint64), res
+
+
+def decode_gt(file_bytes, n_alleles, max_alleles=None):
+    """Decode every block of the image; returns (rows list, allele counts [n_lines, max_alleles])."""
+    torch = torch_mod()
+    L = binding.lib()
+    d_file = dev_u8(np.frombuffer(file_bytes, dtype=np.uint8))
+    io, so = struct.unpack_from("<QQ", file_bytes, 72)
+    n_blocks = (so - io) // 8
+    num_samples = struct.unpack_from("<Q", file_bytes, 112)[0]
+    N = 2 * num_samples
+    nal = np.asarray(n_alleles, dtype=np.uint32)
+    n_lines = len(nal)
+    if max_alleles is None:
+        max_alleles = int(nal.max())
+    d_out = torch.zeros((n_lines, N), dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros((n_lines, max_alleles), dtype=torch.int64, device="cuda")
+    ngt = np.zeros(n_lines, dtype=np.uint32)
+    binding.check(L.xsi_hip_decode_gt(ctx().handle, d_file.data_ptr(), len(file_bytes), 0, n_blocks, nal.ctypes.data,
+                                      n_lines, d_out.data_ptr(), N, ngt.ctypes.data, d_cnt.data_ptr(), max_alleles))
+    out = d_out.cpu().numpy()
+    return [out[i, :ngt[i]] for i in range(n_lines)], d_cnt.cpu().numpy()
+
+
+def num_variants(lines):
+    return sum(na - 1 for _, na in lines)

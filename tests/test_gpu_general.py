@@ -1,0 +1,192 @@
+"""GPU parity tests of the general genotype path (int32 rows: multi-allelic, missing,
+end-of-vector, non-default phase, haploid lines) and of the file-level writer / accessor."""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from xsqueezeit_amd import binding, vcf_lite
+from test_oracle import ANCHORS, _random_lines
+
+pytestmark = pytest.mark.gpu
+
+
+def _ploidy(lines, n_samples):
+    return max(len(gt) // n_samples for gt, _ in lines)
+
+
+@pytest.mark.parametrize("name", sorted(ANCHORS))
+def test_micro_fixture_through_gpu(name, golden_dir):
+    """The reference's own fixtures: GPU-encoded bytes hit the reference's recorded SHA-256, and
+    GPU decode returns the VCF's genotypes (the reference's test criterion, verify_v4.sh)."""
+    import gpu_util as G
+    from oracle import oracle
+    samples, recs = vcf_lite.read_vcf(os.path.join(golden_dir, name + ".vcf"))
+    lines = [(r["gt"], r["n_allele"]) for r in recs]
+    n = len(samples)
+    first_ploidy = len(lines[0][0]) // n
+    p = G.params(n, 8192, int(n * first_ploidy * 0.002), oracle.default_phased_of(lines, n))
+    region, offsets, res = G.encode_gt(lines, n, p)
+    got = G.assemble_file(region, offsets, p, len(lines), G.num_variants(lines), samples, _ploidy(lines, n))
+    size, sha = ANCHORS[name]
+    assert len(got) == size
+    assert hashlib.sha256(got).hexdigest() == sha
+    assert res.max_ploidy == _ploidy(lines, n)
+    rows, counts = G.decode_gt(got, [na for _, na in lines])
+    ref = oracle.decode_file(got, [na for _, na in lines])
+    for i, (r, (gt, _)) in enumerate(zip(rows, lines)):
+        assert np.array_equal(r, gt), "line %d" % i
+        assert np.array_equal(counts[i][:lines[i][1]], ref[i][1])
+
+
+@pytest.mark.parametrize("n_samples,n_lines,block_len,maf,kw", [
+    (50, 300, 64, 0.01, {}),
+    (50, 200, 64, 0.01, dict(multi=True)),
+    (37, 150, 32, 0.01, dict(missing=True, eov=True, phase=True, multi=True)),
+    (333, 500, 128, 0.02, dict(missing=True, eov=True, phase=True, multi=True)),
+    (2504, 300, 100, 0.001, dict(missing=True, phase=True)),
+    (2504, 200, 64, 0.001, dict(multi=True, eov=True)),
+    (40000, 12, 8, 0.001, dict(multi=True)),        # u16 blocks / u32 header (encode-only window)
+    (70000, 10, 4, 0.001, dict(multi=True, missing=True, eov=True, phase=True)),  # u32, global-memory chain
+])
+def test_general_encode_bit_exact_and_decode(n_samples, n_lines, block_len, maf, kw):
+    import gpu_util as G
+    from oracle import oracle
+    rng = np.random.default_rng(n_samples * 7 + n_lines)
+    lines = _random_lines(rng, n_samples, n_lines, **kw)
+    dp = oracle.default_phased_of(lines, n_samples)
+    p = G.params(n_samples, block_len, int(2 * n_samples * maf), dp)
+    ref = oracle.encode_file(lines, n_samples, block_len=block_len, mac_thr=p.mac_threshold, default_phased=dp)
+    region, offsets, res = G.encode_gt(lines, n_samples, p)
+    names = ["S%d" % i for i in range(n_samples)]
+    got = G.assemble_file(region, offsets, p, n_lines, G.num_variants(lines), names, 2)
+    if got != ref:
+        first = next(i for i in range(min(len(got), len(ref))) if got[i] != ref[i])
+        raise AssertionError("file differs at offset %d (sizes %d vs %d)" % (first, len(got), len(ref)))
+    if 32768 <= n_samples <= 65535:
+        return
+    nal = [na for _, na in lines]
+    rows, counts = G.decode_gt(got, nal)
+    oref = oracle.decode_file(ref, nal, block_len=block_len)
+    for i in range(n_lines):
+        assert np.array_equal(rows[i], oref[i][0]), "line %d" % i
+        assert np.array_equal(rows[i], lines[i][0]), "line %d vs source" % i
+        assert np.array_equal(counts[i][:nal[i]], oref[i][1]), "allele counts line %d" % i
+
+
+def test_haploid_and_mixed_lines():
+    """Fully haploid lines interleaved with diploid ones (mixed-ploidy chrX-like input)."""
+    import gpu_util as G
+    from oracle import oracle
+    rng = np.random.default_rng(11)
+    n = 60
+    lines = []
+    for i in range(240):
+        if i % 5 == 3:
+            al = (rng.random(n) < 0.3).astype(np.int32)
+            lines.append((((al + 1) << 1).astype(np.int32), 2))
+        else:
+            lines.extend(_random_lines(rng, n, 1, eov=(i % 7 == 0)))
+    dp = oracle.default_phased_of(lines, n)
+    p = G.params(n, 64, 0, dp)
+    ref = oracle.encode_file(lines, n, block_len=64, mac_thr=0, default_phased=dp)
+    region, offsets, res = G.encode_gt(lines, n, p)
+    got = G.assemble_file(region, offsets, p, len(lines), G.num_variants(lines), ["S%d" % i for i in range(n)], 2)
+    assert got == ref
+    nal = [na for _, na in lines]
+    rows, _ = G.decode_gt(got, nal)
+    oref = oracle.decode_file(ref, nal, block_len=64)
+    for i in range(len(lines)):
+        assert np.array_equal(rows[i], oref[i][0]), "line %d" % i
+
+
+def test_wah_encode_missing_strategy():
+    import gpu_util as G
+    from oracle import oracle
+    rng = np.random.default_rng(7)
+    n = 90
+    lines = _random_lines(rng, n, 200, missing=True, eov=True)
+    dp = oracle.default_phased_of(lines, n)
+    p = G.params(n, 50, 1, dp, wah_encode_missing=1)
+    ref = oracle.encode_file(lines, n, block_len=50, mac_thr=1, default_phased=dp, wah_encode_missing=True)
+    region, offsets, _ = G.encode_gt(lines, n, p)
+    got = G.assemble_file(region, offsets, p, len(lines), G.num_variants(lines), ["S%d" % i for i in range(n)], 2)
+    assert got == ref
+    rows, _ = G.decode_gt(got, [na for _, na in lines])
+    for r, (gt, _) in zip(rows, lines):
+        assert np.array_equal(r, gt)
+
+
+def test_unknown_allele_is_an_error():
+    import gpu_util as G
+    gt = np.full(20, 2, dtype=np.int32)
+    gt[3] = (5 + 1) << 1  # allele 5 on a bi-allelic line
+    p = G.params(10, 16, 0, 0)
+    with pytest.raises(binding.XsiError):
+        G.encode_gt([(gt, 2)], 10, p)
+
+
+@pytest.mark.parametrize("kw", [{}, dict(multi=True, missing=True, eov=True, phase=True)])
+def test_writer_and_accessor_files(tmp_path, kw):
+    """File level: xsi_writer (XsiFactoryExt::append/finalize_file) output equals the oracle's file;
+    xsi_accessor (Accessor::fill_genotype_array) returns the oracle reader's rows and counts,
+    sequentially and with random jumps."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    rng = np.random.default_rng(21)
+    n, n_lines, block_len = 120, 700, 256
+    lines = _random_lines(rng, n, n_lines, **kw)
+    dp = oracle.default_phased_of(lines, n)
+    names = ["sample_%d" % i for i in range(n)]
+    mac = 2
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=mac, default_phased=dp, sample_names=names)
+    path = str(tmp_path / "out.xsi").encode()
+    p = G.params(n, block_len, mac, dp)
+    w = ctypes.c_void_p()
+    arr = (ctypes.c_char_p * n)(*[s.encode() for s in names])
+    binding.check(L.xsi_writer_open(ctypes.byref(w), G.ctx().handle, path, ctypes.byref(p), arr))
+    for gt, na in lines:
+        gt = np.ascontiguousarray(gt, dtype=np.int32)
+        binding.check(L.xsi_writer_append(w, gt.ctypes.data, gt.size, na))
+    binding.check(L.xsi_writer_finalize(w, 0))
+    L.xsi_writer_close(w)
+    got = open(path, "rb").read()
+    assert got == ref
+
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, path))
+    assert L.xsi_accessor_hap_samples(a) == 2 * n
+    assert L.xsi_accessor_num_samples(a) == n
+    assert L.xsi_accessor_sample_name(a, 5) == b"sample_5"
+    rd = oracle.Reader(ref)
+    bms = []
+    block = off = 0
+    for i, (_, na) in enumerate(lines):
+        if i and i % block_len == 0:
+            block += 1
+            off = 0
+        bms.append((block << 15) | off)
+        off += na - 1
+    buf = np.zeros(2 * n, dtype=np.int32)
+    cnt = np.zeros(8, dtype=np.uint64)
+    order = list(range(n_lines)) + [int(x) for x in rng.integers(0, n_lines, 40)]
+    for i in order:
+        na = lines[i][1]
+        r = L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, na, bms[i])
+        assert r == len(lines[i][0]), L.xsi_hip_last_error()
+        exp, ecnt = rd.fill_genotype_array(na, bms[i])
+        assert np.array_equal(buf[:r], exp), "line %d" % i
+        binding.check(L.xsi_accessor_allele_counts(a, cnt.ctypes.data, na))
+        assert np.array_equal(cnt[:na], ecnt)
+    # get_genotypes allocates like Accessor::get_genotypes (accessor.hpp:58-67)
+    pp = ctypes.c_void_p()
+    ngt_arr = ctypes.c_int(0)
+    r = L.xsi_accessor_get_genotypes(a, lines[0][1], bms[0], ctypes.byref(pp), ctypes.byref(ngt_arr))
+    assert r == len(lines[0][0]) and ngt_arr.value == 2 * n and pp.value
+    got0 = np.ctypeslib.as_array(ctypes.cast(pp, ctypes.POINTER(ctypes.c_int32)), shape=(r,)).copy()
+    assert np.array_equal(got0, lines[0][0])
+    ctypes.CDLL(None).free(pp)
+    L.xsi_accessor_close(a)

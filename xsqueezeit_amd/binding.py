@@ -43,7 +43,7 @@ class HeaderFields(ctypes.Structure):
 SYMBOLS = [
     "xsi_hip_abi_version", "xsi_hip_last_error", "xsi_hip_ctx_create", "xsi_hip_ctx_destroy",
     "xsi_hip_ctx_synchronize", "xsi_hip_ctx_workspace_bytes", "xsi_hip_encode_bound", "xsi_hip_encode_packed",
-    "xsi_hip_encode_gt", "xsi_hip_make_header", "xsi_hip_decode_packed", "xsi_hip_decode_gt",
+    "xsi_hip_encode_gt", "xsi_hip_encode_gt_bound", "xsi_hip_make_header", "xsi_hip_decode_packed", "xsi_hip_decode_gt",
     "xsi_hip_synth_packed", "xsi_hip_debug_chain_encode", "xsi_writer_open", "xsi_writer_append",
     "xsi_writer_finalize", "xsi_writer_close", "xsi_accessor_open", "xsi_accessor_fill_genotype_array",
     "xsi_accessor_get_genotypes", "xsi_accessor_allele_counts", "xsi_accessor_hap_samples",
@@ -76,6 +76,8 @@ def lib():
     L.xsi_hip_ctx_workspace_bytes.argtypes = [vp]
     L.xsi_hip_encode_bound.restype = u64
     L.xsi_hip_encode_bound.argtypes = [c.POINTER(EncodeParams), u64, u64]
+    L.xsi_hip_encode_gt_bound.restype = u64
+    L.xsi_hip_encode_gt_bound.argtypes = [c.POINTER(EncodeParams), u64, u64]
     L.xsi_hip_encode_packed.restype = c.c_int
     L.xsi_hip_encode_packed.argtypes = [vp, c.POINTER(EncodeParams), vp, u64, u32, vp, u64, vp,
                                         c.POINTER(EncodeResult)]

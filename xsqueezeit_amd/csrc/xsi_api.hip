@@ -500,8 +500,4 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
     return XSI_OK;
 }
 
-int encode_side_write(xsi_hip_ctx*, const EncBlock*, uint32_t, const EncLines&, const EncSide&, uint8_t*, const uint64_t*) {
-    return set_error(XSI_ERR_UNSUPPORTED, "side channels are written by the general encode path (xsi_gt.hip)");
-}
-
 }  // namespace xsi

@@ -43,6 +43,19 @@ struct DecodePlan {
     DecLines L{};
 };
 
+struct DecodedPlanes {
+    uint32_t* planes = nullptr;  // [n_bin][stride_w]; sparse lines hold their listed positions
+    uint32_t stride_w = 0;
+    bool has_side = false;
+    uint8_t* side = nullptr;     // per binary line: bit0 missing, bit1 eov, bit2 phase
+    uint32_t *miss_planes = nullptr, *eov_planes = nullptr, *phase_planes = nullptr;
+    uint32_t *n_miss = nullptr, *n_eov = nullptr;
+};
+
+int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, DecodedPlanes* out);
+int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D, const uint32_t* d_first_bin,
+                  const uint32_t* d_n_allele, uint32_t n_out, int32_t* d_gt_out, uint64_t gt_stride,
+                  uint32_t* d_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles);
 int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block, uint64_t n_blocks,
                    DecodePlan* P);
 int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t* out, uint32_t stride_w,

@@ -93,9 +93,11 @@ struct WahCarry {
 // all-zero / all-one groups collapse into fill words of at most 16383 groups, a saturated run
 // emits 0xBFFF / 0xFFFF and restarts.  Emits at the END of each run, so every word's position
 // is the exclusive prefix of the emit counts.
+// `next_val` = value of the group that follows this chunk (ignored when last_chunk): a run that
+// fills the chunk up to its last lane ends there iff the next group differs.
 template <bool WRITE>
-__device__ __forceinline__ void wah_encode_chunk(uint32_t val, bool valid, bool last_chunk, WahCarry& c,
-                                                 uint16_t* __restrict__ dst) {
+__device__ __forceinline__ void wah_encode_chunk(uint32_t val, bool valid, bool last_chunk, uint32_t next_val,
+                                                 WahCarry& c, uint16_t* __restrict__ dst) {
     const uint32_t lane = lane_id();
     const uint32_t t = (val == 0u) ? 0u : ((val == 0x7FFFu) ? 1u : 2u);
     uint32_t prev_t = __shfl_up(t, 1, 64);
@@ -118,7 +120,9 @@ __device__ __forceinline__ void wah_encode_chunk(uint32_t val, bool valid, bool 
     if (lane + 1u < nvalid) {
         is_end = (H >> (lane + 1u)) & 1ull;
     } else {
-        is_end = last_chunk;  // last valid lane: run stays open unless the line ends here
+        // last valid lane: the run stays open only if the next chunk continues it
+        const uint32_t nt = (next_val == 0u) ? 0u : ((next_val == 0x7FFFu) ? 1u : 2u);
+        is_end = last_chunk || nt == 2u || nt != t;
     }
     uint32_t emit = 0;
     if (valid) {
@@ -169,7 +173,9 @@ __device__ __forceinline__ uint32_t wave_wah_encode_row(const uint32_t* __restri
         const uint32_t g = g0 + lane;
         const bool valid = g < G;
         const uint32_t val = valid ? load_group15(row, g, nbits) : 0u;
-        wah_encode_chunk<WRITE>(val, valid, g0 + 64u >= G, c, dst);
+        const bool last = g0 + 64u >= G;
+        const uint32_t next_val = last ? 0u : load_group15(row, g0 + 64u, nbits);
+        wah_encode_chunk<WRITE>(val, valid, last, next_val, c, dst);
     }
     return c.out;
 }

@@ -1,0 +1,798 @@
+// xsi_gt.hip — general genotype path: htslib int32 rows <-> bit planes, plus the missing /
+// end-of-vector / phase side channels.  The heavy per-line work (PBWT chain, WAH16, sparse
+// lists) is shared with the packed path; this file only adds the conversion kernels around it.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/xsi_hip.h"
+#include "xsi_ctx.hpp"
+#include "xsi_device.hpp"
+#include "xsi_kernels.hpp"
+
+using namespace xsi;
+
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) return set_error(XSI_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                               __FILE__, __LINE__);                                          \
+    } while (0)
+#define WS(ptr, name, bytes)                          \
+    do {                                              \
+        void* _p;                                     \
+        int _rc = ws_ensure(ctx, name, (bytes), &_p); \
+        if (_rc) return _rc;                          \
+        ptr = reinterpret_cast<decltype(ptr)>(_p);    \
+    } while (0)
+
+namespace xsi {
+
+constexpr int32_t GT_INT32_MISSING = (int32_t)0x80000000;
+constexpr int32_t GT_VECTOR_END = (int32_t)0x80000001;
+
+// ------------------------------------------------------------------------------------------
+// unpack: one BCF line of int32 genotypes -> bit planes and counts (scan_genotypes,
+// gt_block.hpp:207-269, and the predicates of gt_block.hpp:76-100 / wah.hpp:431-435).
+// One workgroup of 4 waves per BCF line; every wave turns 64 consecutive values into one
+// ballot per plane, so reads are 256-byte coalesced and planes are written 8 bytes at a time.
+//   alt planes  : allele == k              (k = 1 .. n_allele-1), one per binary line
+//   ref plane   : allele == 0              (listed by negated sparse lines)
+//   miss / eov  : MissingPred / EndOfVectorPred
+//   phase       : odd index && phase bit != default (ploidy-2 lines only)
+// ------------------------------------------------------------------------------------------
+struct UnpackArgs {
+    const int32_t* gt;
+    uint64_t gt_stride;
+    const uint32_t* bcf_nbits;
+    const uint32_t* bcf_n_allele;
+    const uint32_t* bcf_first_bin;
+    uint32_t n_samples;
+    int32_t default_phased;
+    uint32_t stride_w;
+    uint32_t* planes;      // [n_bin]
+    uint32_t* ref_planes;  // [n_bcf]
+    uint32_t* miss_planes;
+    uint32_t* eov_planes;
+    uint32_t* phase_planes;
+    uint32_t* cnt;         // [n_bin]
+    uint32_t* ref_cnt;     // [n_bcf]
+    uint32_t* miss_cnt;
+    uint32_t* eov_cnt;
+    uint32_t* bcf_flags;
+    uint8_t* kind;         // [n_bin] receives KIND_HAPLOID
+    uint32_t* d_error;     // set to 1 on an allele outside [0, n_allele)
+};
+
+__global__ void __launch_bounds__(256) k_unpack_gt(UnpackArgs U) {
+    __shared__ uint32_t s_cnt[4];  // ref, missing, eov, phase-any
+    __shared__ uint32_t s_alt[64];
+    const uint32_t l = blockIdx.x;
+    const uint32_t ngt = U.bcf_nbits[l];
+    const uint32_t n_allele = U.bcf_n_allele[l];
+    const uint32_t b0 = U.bcf_first_bin[l];
+    const bool diploid = ngt == 2u * U.n_samples;
+    const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 64) s_alt[threadIdx.x] = 0;
+    __syncthreads();
+    const int32_t* row = U.gt + (size_t)l * U.gt_stride;
+    const uint32_t nchunks = U.stride_w / 2u;  // 64-bit words per plane row (all written, pad = 0)
+    uint32_t c_ref = 0, c_miss = 0, c_eov = 0, any_phase = 0;
+    for (uint32_t cgi = w; cgi < nchunks; cgi += 4u) {
+        const uint32_t i = cgi * 64u + lane;
+        const bool in = i < ngt;
+        const int32_t v = in ? row[i] : 0;
+        const bool missing = in && (((v >> 1) == 0) || v == GT_INT32_MISSING);
+        const bool eov = in && !missing && v == GT_VECTOR_END;
+        const bool called = in && !missing && !eov;
+        const int32_t allele = (v >> 1) - 1;
+        if (called && (allele < 0 || allele >= (int32_t)n_allele)) *U.d_error = 1;  // "Unknown allele error !"
+        const bool ph = in && diploid && (i & 1u) && ((v & 1) != U.default_phased);
+        const uint64_t m_ref = __ballot(called && allele == 0);
+        const uint64_t m_miss = __ballot(missing);
+        const uint64_t m_eov = __ballot(eov);
+        const uint64_t m_ph = __ballot(ph);
+        if (lane == 0) {
+            reinterpret_cast<uint64_t*>(U.ref_planes + (size_t)l * U.stride_w)[cgi] = m_ref;
+            reinterpret_cast<uint64_t*>(U.miss_planes + (size_t)l * U.stride_w)[cgi] = m_miss;
+            reinterpret_cast<uint64_t*>(U.eov_planes + (size_t)l * U.stride_w)[cgi] = m_eov;
+            reinterpret_cast<uint64_t*>(U.phase_planes + (size_t)l * U.stride_w)[cgi] = m_ph;
+        }
+        c_ref += (uint32_t)__popcll(m_ref);
+        c_miss += (uint32_t)__popcll(m_miss);
+        c_eov += (uint32_t)__popcll(m_eov);
+        any_phase |= m_ph ? 1u : 0u;
+        for (uint32_t k = 1; k < n_allele; ++k) {
+            const uint64_t m = __ballot(called && allele == (int32_t)k);
+            if (lane == 0) {
+                reinterpret_cast<uint64_t*>(U.planes + (size_t)(b0 + k - 1u) * U.stride_w)[cgi] = m;
+                if (m) atomicAdd(&s_alt[(k - 1u) & 63u], (uint32_t)__popcll(m));
+            }
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&s_cnt[0], c_ref);
+        atomicAdd(&s_cnt[1], c_miss);
+        atomicAdd(&s_cnt[2], c_eov);
+        atomicOr(&s_cnt[3], any_phase);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        U.ref_cnt[l] = s_cnt[0];
+        U.miss_cnt[l] = s_cnt[1];
+        U.eov_cnt[l] = s_cnt[2];
+        U.bcf_flags[l] = (s_cnt[1] ? 1u : 0u) | (s_cnt[2] ? 2u : 0u) | (s_cnt[3] ? 4u : 0u) | (diploid ? 0u : 8u);
+    }
+    for (uint32_t k = 1 + threadIdx.x; k < n_allele; k += blockDim.x) {
+        U.kind[b0 + k - 1u] = diploid ? 0 : (uint8_t)KIND_HAPLOID;
+    }
+    // alt counts: up to 64 alleles share the LDS counters; beyond that recount from the planes
+    for (uint32_t k = 1 + w; k < n_allele; k += 4u) {
+        uint32_t c;
+        if (n_allele <= 65u) {
+            c = s_alt[k - 1u];
+        } else {
+            const uint32_t* pr = U.planes + (size_t)(b0 + k - 1u) * U.stride_w;
+            c = 0;
+            for (uint32_t i = lane; i < U.stride_w; i += 64u) c += (uint32_t)__popc(pr[i]);
+            c = wave_sum(c);
+        }
+        if (lane == 0) U.cnt[b0 + k - 1u] = c;
+    }
+}
+
+// flag vectors of the side channels: one bit per binary line, set on the first binary line of
+// a flagged BCF line (reindex_binary_vector_from_bcf_to_binary_lines, gt_block.hpp:650-666);
+// the haploid vector has one bit per BCF line (gt_block.hpp:219-224).
+__global__ void __launch_bounds__(256) k_side_flagbits(const EncBlock* __restrict__ blocks, EncSide S,
+                                                       uint32_t* __restrict__ flagbits) {
+    const uint32_t b = blockIdx.x;
+    const EncBlock& B = blocks[b];
+    constexpr uint32_t FW = MAX_BIN_PER_BLOCK / 32;
+    uint32_t* base = flagbits + (size_t)b * FV_COUNT * FW;
+    for (uint32_t i = threadIdx.x; i < 4u * FW; i += blockDim.x) base[FW + i] = 0;  // FV_MISSING..FV_HAPLOID
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < B.n_bcf; i += blockDim.x) {
+        const uint32_t li = B.first_bcf + i;
+        const uint32_t f = S.bcf_flags[li];
+        const uint32_t rel = S.bcf_first_bin[li] - B.first_bin;
+        if (f & 1u) atomicOr(&base[FV_MISSING * FW + (rel >> 5)], 1u << (rel & 31u));
+        if (f & 2u) atomicOr(&base[FV_EOV * FW + (rel >> 5)], 1u << (rel & 31u));
+        if (f & 4u) atomicOr(&base[FV_PHASE * FW + (rel >> 5)], 1u << (rel & 31u));
+        if (f & 8u) atomicOr(&base[FV_HAPLOID * FW + (i >> 5)], 1u << (i & 31u));
+    }
+}
+
+// sizes of every flagged line's side-channel entries.  One wave per BCF line.
+__global__ void __launch_bounds__(256) k_side_sizes(EncSide S) {
+    const uint32_t l = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (l >= S.n_bcf) return;
+    const uint32_t f = S.bcf_flags[l];
+    const uint32_t nbits = S.bcf_nbits[l];
+    uint32_t ms = 0, es = 0, pl = 0;
+    if (f & 1u) {
+        if (S.strategy == WS_SPARSE)
+            ms = (1u + S.miss_cnt[l]) * S.aet;
+        else
+            ms = 2u * wave_wah_encode_row<false>(S.miss_planes + (size_t)l * S.plane_stride_w, nbits, nullptr);
+    }
+    if (f & 2u) {
+        if (S.strategy == WS_SPARSE)
+            es = (1u + S.eov_cnt[l]) * S.aet;
+        else
+            es = 2u * wave_wah_encode_row<false>(S.eov_planes + (size_t)l * S.plane_stride_w, nbits, nullptr);
+    }
+    if (f & 4u) pl = wave_wah_encode_row<false>(S.phase_planes + (size_t)l * S.plane_stride_w, nbits, nullptr);
+    if (lane_id() == 0) {
+        S.miss_size[l] = ms;
+        S.eov_size[l] = es;
+        S.phase_len[l] = pl;
+    }
+}
+
+__device__ __forceinline__ void store_at16(uint8_t* p, uint32_t v, uint32_t aet) {
+    uint16_t* q = reinterpret_cast<uint16_t*>(p);
+    q[0] = (uint16_t)v;
+    if (aet == 4u) q[1] = (uint16_t)(v >> 16);
+}
+
+// Sparse<A_T, Pred> list of a plane (block.hpp:54-76), no MSB flag.
+__device__ __forceinline__ void wave_list_emit(const uint32_t* __restrict__ row, uint32_t nbits, uint32_t aet,
+                                               uint8_t* __restrict__ dst) {
+    const uint32_t lane = lane_id();
+    const uint32_t nw = (nbits + 31u) >> 5;
+    uint32_t base = 0;
+    for (uint32_t w0 = 0; w0 < nw; w0 += 64u) {
+        const uint32_t w = w0 + lane;
+        uint32_t v = 0;
+        if (w < nw) {
+            v = row[w];
+            if (w == nw - 1u && (nbits & 31u)) v &= (1u << (nbits & 31u)) - 1u;
+        }
+        const uint32_t c = (uint32_t)__popc(v);
+        const uint32_t inc = wave_scan_incl(c);
+        uint32_t pos = base + inc - c;
+        while (v) {
+            const uint32_t bpos = (uint32_t)__ffs((int)v) - 1u;
+            v &= v - 1u;
+            store_at16(dst + (size_t)(1u + pos) * aet, w * 32u + bpos, aet);
+            ++pos;
+        }
+        base += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) store_at16(dst, base, aet);
+}
+
+// write the side-channel matrices (gt_block.hpp:565-629).  One wave per BCF line.
+__global__ void __launch_bounds__(256) k_side_write(const EncBlock* __restrict__ blocks,
+                                                    const uint32_t* __restrict__ line_block, EncSide S,
+                                                    uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result) {
+    if (d_result[3]) return;
+    const uint32_t l = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (l >= S.n_bcf) return;
+    const uint32_t f = S.bcf_flags[l];
+    if (!(f & 7u)) return;
+    const EncBlock& B = blocks[line_block[S.bcf_first_bin[l]]];
+    const uint32_t nbits = S.bcf_nbits[l];
+    uint8_t* gt = out + B.out_off + 16u;
+    if (f & 1u) {
+        uint8_t* dst = gt + B.off_miss + S.miss_off[l];
+        const uint32_t* row = S.miss_planes + (size_t)l * S.plane_stride_w;
+        if (S.strategy == WS_SPARSE)
+            wave_list_emit(row, nbits, S.aet, dst);
+        else
+            (void)wave_wah_encode_row<true>(row, nbits, reinterpret_cast<uint16_t*>(dst));
+    }
+    if (f & 2u) {
+        uint8_t* dst = gt + B.off_eov + S.eov_off[l];
+        const uint32_t* row = S.eov_planes + (size_t)l * S.plane_stride_w;
+        if (S.strategy == WS_SPARSE)
+            wave_list_emit(row, nbits, S.aet, dst);
+        else
+            (void)wave_wah_encode_row<true>(row, nbits, reinterpret_cast<uint16_t*>(dst));
+    }
+    if (f & 4u) {
+        uint16_t* dst = reinterpret_cast<uint16_t*>(gt + B.off_phase) + S.phase_off[l];
+        (void)wave_wah_encode_row<true>(S.phase_planes + (size_t)l * S.plane_stride_w, nbits, dst);
+    }
+}
+
+int encode_side_write(xsi_hip_ctx* ctx, const EncBlock* d_blocks, uint32_t n_blocks, const EncLines& L,
+                      const EncSide& S, uint8_t* out, const uint64_t* d_result) {
+    (void)n_blocks;
+    if (!S.n_bcf) return XSI_OK;
+    k_side_write<<<dim3((S.n_bcf + 3u) / 4u), dim3(256), 0, ctx->stream>>>(d_blocks, L.line_block, S, out, d_result);
+    HIP_TRY(hipGetLastError());
+    return XSI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// decode side: flag vectors -> per-binary-line bits; pointer walk over the side matrices;
+// planes of the flagged lines; int32 composer.
+// ------------------------------------------------------------------------------------------
+struct DecSide {
+    uint8_t* side;          // per binary line: bit0 missing, bit1 eov, bit2 phase (set on the BCF line's first binary line)
+    uint32_t* miss_start;   // per binary line: byte offset (rel. GT block) of the line's missing entry
+    uint32_t* eov_start;
+    uint32_t* phase_start;
+    uint32_t* miss_planes;  // per binary line (rows of flagged first binary lines are filled)
+    uint32_t* eov_planes;
+    uint32_t* phase_planes;
+    uint32_t* n_miss;       // per binary line
+    uint32_t* n_eov;
+    uint32_t stride_w;
+};
+
+__global__ void __launch_bounds__(64) k_dec_side_flags(const uint8_t* __restrict__ file,
+                                                       const DecBlock* __restrict__ blocks, DecLines L, DecSide S) {
+    __shared__ uint32_t s_row[3][MAX_BIN_PER_BLOCK / 32 + 2];
+    const DecBlock& D = blocks[blockIdx.x];
+    if (D.error) return;
+    const uint32_t lane = lane_id();
+    const uint32_t nb = D.n_bin, nw = (nb + 31u) >> 5;
+    for (uint32_t v = 0; v < 3; ++v)
+        for (uint32_t i = lane; i < nw + 1u; i += 64u) s_row[v][i] = 0;
+    __syncthreads();
+    const uint32_t offs[3] = {D.off_line_missing, D.off_line_eov, D.off_line_phase};
+    for (uint32_t v = 0; v < 3; ++v) {
+        if (offs[v] == VAL_UNDEFINED) continue;
+        const uint64_t at = D.gt_off + offs[v];
+        uint32_t maxw = 0;
+        if (at < L.file_len) {
+            const uint64_t left = (L.file_len - at) / 2u;
+            maxw = left < FLAG_WORDS_MAX ? (uint32_t)left : FLAG_WORDS_MAX;
+        }
+        uint32_t ones;
+        (void)wave_wah_expand_row(reinterpret_cast<const uint16_t*>(file + at), maxw, nb, s_row[v], &ones);
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < nb; i += 64u) {
+        uint32_t f = 0;
+        for (uint32_t v = 0; v < 3; ++v) f |= ((s_row[v][i >> 5] >> (i & 31u)) & 1u) << v;
+        S.side[D.first_bin + i] = (uint8_t)f;
+    }
+}
+
+// Sequential cursor walk of the side matrices (weirdness_advance / phase_advance,
+// accessor_internals_new.hpp:478-546): entry starts per flagged binary line.  Lane 0 of one wave
+// per block; side channels are rare so no tiling.
+__global__ void __launch_bounds__(64) k_dec_side_walk(const uint8_t* __restrict__ file,
+                                                      const DecBlock* __restrict__ blocks, DecLines L, DecSide S) {
+    const DecBlock& D = blocks[blockIdx.x];
+    if (D.error || lane_id() != 0) return;
+    const uint8_t* gt = file + D.gt_off;
+    const uint64_t room = L.file_len - D.gt_off;
+    const uint32_t msb = (L.aet == 2u) ? 0x8000u : 0x80000000u;
+    auto rd = [&](uint64_t off) -> uint32_t {
+        if (off + L.aet > room) return 0u;
+        const uint16_t* q = reinterpret_cast<const uint16_t*>(gt + off);
+        uint32_t v = q[0];
+        if (L.aet == 4u) v |= (uint32_t)q[1] << 16;
+        return v;
+    };
+    auto wah_skip = [&](uint64_t off, uint32_t nbits) -> uint64_t {  // wah2_advance_pointer, wah.hpp:158-174
+        uint32_t pos = 0;
+        while (pos < nbits && off + 2u <= room) {
+            const uint32_t word = *reinterpret_cast<const uint16_t*>(gt + off);
+            pos += (word & 0x8000u) ? (word & WAH_MAXC) * WAH_BITS : WAH_BITS;
+            off += 2u;
+        }
+        return off;
+    };
+    uint64_t pm = (D.strategy == WS_SPARSE) ? D.off_miss_sparse : D.off_miss_wah;
+    uint64_t pe = (D.strategy == WS_SPARSE) ? D.off_eov_sparse : D.off_eov_wah;
+    uint64_t pp = D.off_phase;
+    for (uint32_t i = 0; i < D.n_bin; ++i) {
+        const uint32_t l = D.first_bin + i;
+        const uint32_t f = S.side[l];
+        const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
+        if ((f & 1u) && D.off_line_missing != VAL_UNDEFINED && pm != VAL_UNDEFINED) {
+            S.miss_start[l] = (uint32_t)pm;
+            if (D.strategy == WS_SPARSE)
+                pm += (uint64_t)(1u + (rd(pm) & ~msb)) * L.aet;
+            else
+                pm = wah_skip(pm, nbits);
+        }
+        if ((f & 2u) && D.off_line_eov != VAL_UNDEFINED && pe != VAL_UNDEFINED) {
+            S.eov_start[l] = (uint32_t)pe;
+            if (D.strategy == WS_SPARSE)
+                pe += (uint64_t)(1u + (rd(pe) & ~msb)) * L.aet;
+            else
+                pe = wah_skip(pe, nbits);
+        }
+        if ((f & 4u) && pp != VAL_UNDEFINED) {
+            S.phase_start[l] = (uint32_t)pp;
+            pp = wah_skip(pp, nbits);
+        }
+    }
+}
+
+// planes of one flagged line's side channels.  One wave per binary line, row built in LDS.
+__global__ void __launch_bounds__(64) k_dec_side_planes(const uint8_t* __restrict__ file,
+                                                        const DecBlock* __restrict__ blocks, DecLines L, DecSide S,
+                                                        uint32_t n_bin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* row = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t l = blockIdx.x;
+    if (l >= n_bin) return;
+    const uint32_t f = S.side[l];
+    const uint32_t lane = lane_id();
+    if (lane == 0) {
+        S.n_miss[l] = 0;
+        S.n_eov[l] = 0;
+    }
+    if (!(f & 7u)) return;
+    const DecBlock& D = blocks[L.line_block[l]];
+    const uint8_t* gt = file + D.gt_off;
+    const uint64_t room = L.file_len - D.gt_off;
+    const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
+    const uint32_t msb = (L.aet == 2u) ? 0x8000u : 0x80000000u;
+    for (uint32_t ch = 0; ch < 3; ++ch) {
+        if (!(f & (1u << ch))) continue;
+        uint32_t* dst = (ch == 0 ? S.miss_planes : ch == 1 ? S.eov_planes : S.phase_planes) + (size_t)l * S.stride_w;
+        const uint32_t start = ch == 0 ? S.miss_start[l] : ch == 1 ? S.eov_start[l] : S.phase_start[l];
+        for (uint32_t i = lane; i < S.stride_w; i += 64u) row[i] = 0;
+        __syncthreads();
+        uint32_t count = 0;
+        const bool as_list = (ch < 2u) && D.strategy == WS_SPARSE;
+        if (as_list) {
+            const uint16_t* q = reinterpret_cast<const uint16_t*>(gt + start);
+            uint32_t num = q[0];
+            if (L.aet == 4u) num |= (uint32_t)q[1] << 16;
+            num &= ~msb;
+            const uint64_t fit = (start + (uint64_t)L.aet <= room) ? (room - start) / L.aet - 1u : 0u;
+            if (num > fit) num = (uint32_t)fit;
+            for (uint32_t i = lane; i < num; i += 64u) {
+                const uint16_t* e = reinterpret_cast<const uint16_t*>(gt + start + (size_t)(1u + i) * L.aet);
+                uint32_t idx = e[0];
+                if (L.aet == 4u) idx |= (uint32_t)e[1] << 16;
+                if (idx < nbits) atomicOr(&row[idx >> 5], 1u << (idx & 31u));
+            }
+            count = num;
+        } else {
+            const uint64_t left = (room - start) / 2u;
+            (void)wave_wah_expand_row(reinterpret_cast<const uint16_t*>(gt + start),
+                                      left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left, nbits, row, &count);
+        }
+        __syncthreads();
+        for (uint32_t i = lane; i < S.stride_w; i += 64u) dst[i] = row[i];
+        if (lane == 0) {
+            if (ch == 0) S.n_miss[l] = count;
+            if (ch == 1) S.n_eov[l] = count;
+        }
+        __syncthreads();
+    }
+}
+
+// int32 rows as Accessor::fill_genotype_array writes them (fill_genotype_array_advance,
+// accessor_internals_new.hpp:198-384), bug-compatible: the per-haplotype sequence of overwrites
+// is replayed exactly (REF / first ALT, extra ALTs incl. the negated-sparse overwrite/restore of
+// :243-256 and the haploid "allele 1" of :269, then missing, end-of-vector, phase toggle).
+// One workgroup per BCF line, one haplotype per thread per iteration, 4-byte coalesced stores.
+struct ComposeArgs {
+    const uint32_t* planes;   // [n_bin] decoded planes (sparse: listed positions, raw)
+    uint32_t stride_w;
+    const uint8_t* kind;      // per binary line
+    const uint8_t* side;      // per binary line (nullptr: no side channels)
+    const uint32_t* ones;     // per binary line
+    DecSide S;
+    const uint32_t* bcf_first_bin;
+    const uint32_t* bcf_n_allele;
+    const uint32_t* line_block;
+    const DecBlock* blocks;
+    uint32_t N, n_samples;
+    int32_t* out;
+    uint64_t out_stride;
+    uint32_t* line_ngt;       // per BCF line
+    uint64_t* allele_counts;  // [n_bcf][max_alleles] or nullptr
+    uint32_t max_alleles;
+};
+
+__global__ void __launch_bounds__(256) k_compose_gt(ComposeArgs C) {
+    const uint32_t li = blockIdx.x;
+    const uint32_t start = C.bcf_first_bin[li];
+    const uint32_t n_allele = C.bcf_n_allele[li];
+    const uint32_t k0 = C.kind[start];
+    const uint32_t Nl = (k0 & KIND_HAPLOID) ? C.n_samples : C.N;
+    const int32_t DP = (int32_t)C.blocks[C.line_block[start]].default_phasing;
+    const uint32_t f = C.side ? C.side[start] : 0u;
+    const uint32_t* mp = C.S.miss_planes ? C.S.miss_planes + (size_t)start * C.S.stride_w : nullptr;
+    const uint32_t* ep = C.S.eov_planes ? C.S.eov_planes + (size_t)start * C.S.stride_w : nullptr;
+    const uint32_t* pp = C.S.phase_planes ? C.S.phase_planes + (size_t)start * C.S.stride_w : nullptr;
+    int32_t* orow = C.out + (size_t)li * C.out_stride;
+    for (uint32_t i = threadIdx.x; i < Nl; i += blockDim.x) {
+        const int32_t ph = (int32_t)(i & 1u) & DP;
+        const uint32_t wi = i >> 5, bi = i & 31u;
+        int32_t gt;
+        {
+            const uint32_t bit = (C.planes[(size_t)start * C.stride_w + wi] >> bi) & 1u;
+            if (!(k0 & KIND_WAH)) {
+                const bool neg = (k0 & KIND_NEGATED) != 0u;
+                const int32_t allele = neg ? (bit ? 0 : 1) : (bit ? 1 : 0);
+                gt = ((allele + 1) << 1) | ph;
+            } else if (k0 & KIND_HAPLOID) {
+                gt = ((int32_t)bit + 1) << 1;  // haploids carry no phase bit (:225)
+            } else {
+                gt = (((int32_t)bit + 1) << 1) | ph;
+            }
+        }
+        for (uint32_t alt = 2; alt < n_allele; ++alt) {
+            const uint32_t pos = start + alt - 1u;
+            const uint32_t k = C.kind[pos];
+            const uint32_t bit = (C.planes[(size_t)pos * C.stride_w + wi] >> bi) & 1u;
+            if (!(k & KIND_WAH)) {
+                if (k & KIND_NEGATED) {
+                    if (((gt >> 1) - 1) == 0) gt = (((int32_t)alt + 1) << 1) | ph;
+                    if (bit && ((gt >> 1) - 1) == (int32_t)alt) gt = ((0 + 1) << 1) | ph;
+                } else if (bit) {
+                    gt = (((int32_t)alt + 1) << 1) | ph;
+                }
+            } else if (bit) {
+                if (k & KIND_HAPLOID)
+                    gt = (1 + 1) << 1;  // sic: bcf_gt_unphased(y[i]) with y[i] == 1 (:269)
+                else
+                    gt = (((int32_t)alt + 1) << 1) | ph;
+            }
+        }
+        if ((f & 1u) && mp && ((mp[wi] >> bi) & 1u)) gt = 0 | ph;                       // bcf_gt_missing | phase
+        if ((f & 2u) && ep && ((ep[wi] >> bi) & 1u)) gt = GT_VECTOR_END;
+        if ((f & 4u) && pp && ((pp[wi] >> bi) & 1u) && gt != GT_VECTOR_END) gt ^= (int32_t)(i & 1u);
+        orow[i] = gt;
+    }
+    if (threadIdx.x == 0) {
+        C.line_ngt[li] = Nl;
+        if (C.allele_counts) {
+            uint64_t total = 0;
+            for (uint32_t alt = 1; alt < n_allele && alt < C.max_alleles; ++alt) {
+                const uint64_t o = C.ones[start + alt - 1u];
+                C.allele_counts[(size_t)li * C.max_alleles + alt] = o;
+                total += o;
+            }
+            const uint64_t nm = (f & 1u) ? C.S.n_miss[start] : 0u, ne = (f & 2u) ? C.S.n_eov[start] : 0u;
+            C.allele_counts[(size_t)li * C.max_alleles] = (uint64_t)Nl - (total + nm + ne);
+        }
+    }
+}
+
+}  // namespace xsi
+
+namespace xsi {
+
+// Planes of every binary line of the parsed blocks, plus the side-channel planes when present.
+int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, DecodedPlanes* out) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n_bin = P.n_bin;
+    const uint32_t stride_w = P.L.y_stride64 * 2u;
+    out->stride_w = stride_w;
+    WS(out->planes, "gt.planes", 4ull * stride_w * (size_t)(n_bin ? n_bin : 1));
+    int rc = decode_planes(ctx, d_file, P, out->planes, stride_w, /*apply_negation=*/0);
+    if (rc) return rc;
+    bool side = false;
+    for (auto& b : P.blocks_h) {
+        if (b.off_line_missing != VAL_UNDEFINED || b.off_line_eov != VAL_UNDEFINED || b.off_line_phase != VAL_UNDEFINED) side = true;
+        if ((b.off_line_missing != VAL_UNDEFINED || b.off_line_eov != VAL_UNDEFINED) && b.strategy == WS_PBWT_WAH)
+            return set_error(XSI_ERR_UNSUPPORTED, "weirdness strategy WS_PBWT_WAH (format v4 files) is not supported");
+    }
+    out->has_side = side;
+    WS(out->n_miss, "gt.n_miss", 4ull * n_bin + 64);
+    WS(out->n_eov, "gt.n_eov", 4ull * n_bin + 64);
+    if (side) {
+        DecSide S{};
+        S.stride_w = stride_w;
+        WS(S.side, "gt.side", (size_t)n_bin + 64);
+        WS(S.miss_start, "gt.miss_start", 4ull * n_bin + 64);
+        WS(S.eov_start, "gt.eov_start", 4ull * n_bin + 64);
+        WS(S.phase_start, "gt.phase_start", 4ull * n_bin + 64);
+        WS(S.miss_planes, "gt.dmiss_planes", 4ull * stride_w * (size_t)n_bin);
+        WS(S.eov_planes, "gt.deov_planes", 4ull * stride_w * (size_t)n_bin);
+        WS(S.phase_planes, "gt.dphase_planes", 4ull * stride_w * (size_t)n_bin);
+        S.n_miss = out->n_miss;
+        S.n_eov = out->n_eov;
+        k_dec_side_flags<<<dim3(P.n_blocks), dim3(64), 0, s>>>((const uint8_t*)d_file, P.d_blocks, P.L, S);
+        HIP_TRY(hipGetLastError());
+        k_dec_side_walk<<<dim3(P.n_blocks), dim3(64), 0, s>>>((const uint8_t*)d_file, P.d_blocks, P.L, S);
+        HIP_TRY(hipGetLastError());
+        const uint32_t lds = stride_w * 4u;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_side_planes),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_dec_side_planes<<<dim3(n_bin), dim3(64), lds, s>>>((const uint8_t*)d_file, P.d_blocks, P.L, S, n_bin);
+        HIP_TRY(hipGetLastError());
+        out->side = S.side;
+        out->miss_planes = S.miss_planes;
+        out->eov_planes = S.eov_planes;
+        out->phase_planes = S.phase_planes;
+    } else {
+        HIP_TRY(hipMemsetAsync(out->n_miss, 0, 4ull * n_bin + 64, s));
+        HIP_TRY(hipMemsetAsync(out->n_eov, 0, 4ull * n_bin + 64, s));
+        out->side = nullptr;
+        out->miss_planes = out->eov_planes = out->phase_planes = nullptr;
+    }
+    return XSI_OK;
+}
+
+// int32 rows for n_out BCF lines given (first binary line, n_allele) per line (device arrays).
+int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D, const uint32_t* d_first_bin,
+                  const uint32_t* d_n_allele, uint32_t n_out, int32_t* d_gt_out, uint64_t gt_stride,
+                  uint32_t* d_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles) {
+    if (!n_out) return XSI_OK;
+    ComposeArgs C{};
+    C.planes = D.planes;
+    C.stride_w = D.stride_w;
+    C.kind = P.L.kind;
+    C.side = D.side;
+    C.ones = P.L.ones;
+    C.S.stride_w = D.stride_w;
+    C.S.miss_planes = D.miss_planes;
+    C.S.eov_planes = D.eov_planes;
+    C.S.phase_planes = D.phase_planes;
+    C.S.n_miss = D.n_miss;
+    C.S.n_eov = D.n_eov;
+    C.bcf_first_bin = d_first_bin;
+    C.bcf_n_allele = d_n_allele;
+    C.line_block = P.L.line_block;
+    C.blocks = P.d_blocks;
+    C.N = P.L.N;
+    C.n_samples = P.L.n_samples;
+    C.out = d_gt_out;
+    C.out_stride = gt_stride;
+    C.line_ngt = d_line_ngt;
+    C.allele_counts = d_allele_counts;
+    C.max_alleles = max_alleles;
+    k_compose_gt<<<dim3(n_out), dim3(256), 0, ctx->stream>>>(C);
+    HIP_TRY(hipGetLastError());
+    return XSI_OK;
+}
+
+}  // namespace xsi
+
+extern "C" {
+
+int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_t* d_gt, uint64_t gt_stride,
+                      uint64_t n_lines, const uint32_t* h_ngt, const uint32_t* h_n_allele, void* d_out,
+                      uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result) {
+    if (!ctx || !p || !d_gt || !h_ngt || !h_n_allele || !d_out) return set_error(XSI_ERR_ARG, "encode_gt: null argument");
+    if (!p->n_samples || !p->block_len) return set_error(XSI_ERR_ARG, "encode_gt: n_samples and block_len must be > 0");
+    if (n_lines == 0 || n_lines > 0x7FFFFFFFull) return set_error(XSI_ERR_ARG, "n_lines out of range");
+    const uint32_t N = 2u * p->n_samples;
+    if (gt_stride < N) return set_error(XSI_ERR_ARG, "gt_stride %llu < 2*n_samples", (unsigned long long)gt_stride);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t n_bcf = (uint32_t)n_lines;
+    const uint32_t n_blocks = (uint32_t)((n_lines + p->block_len - 1) / p->block_len);
+    // host-side line bookkeeping
+    std::vector<uint32_t> first_bin(n_bcf), parent, nbits_bin;
+    std::vector<EncBlock> blocks(n_blocks);
+    uint64_t n_bin64 = 0;
+    uint32_t max_ploidy = 0;
+    for (uint32_t l = 0; l < n_bcf; ++l) {
+        if (h_n_allele[l] < 2)
+            return set_error(XSI_ERR_UNSUPPORTED, "line %u has %u alleles: lines without an ALT allele corrupt the reference's "
+                             "flag reindexing (gt_block.hpp:650-666) and are rejected", l, h_n_allele[l]);
+        if (h_ngt[l] != p->n_samples && h_ngt[l] != N) return set_error(XSI_ERR_ARG, "PLOIDY ERROR: line %u has %u values", l, h_ngt[l]);
+        const uint32_t pl = h_ngt[l] / p->n_samples;
+        if (pl > max_ploidy) max_ploidy = pl;
+        first_bin[l] = (uint32_t)n_bin64;
+        for (uint32_t k = 1; k < h_n_allele[l]; ++k) {
+            parent.push_back(l);
+            nbits_bin.push_back(h_ngt[l]);
+        }
+        n_bin64 += h_n_allele[l] - 1;
+        if (n_bin64 > 0x7FFFFFFFull) return set_error(XSI_ERR_ARG, "too many binary lines in one call");
+    }
+    const uint32_t n_bin = (uint32_t)n_bin64;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        memset(&blocks[b], 0, sizeof(EncBlock));
+        const uint32_t f = b * p->block_len;
+        const uint32_t e = (uint32_t)(((uint64_t)f + p->block_len < n_lines) ? f + p->block_len : n_lines);
+        blocks[b].first_bcf = f;
+        blocks[b].n_bcf = e - f;
+        blocks[b].first_bin = first_bin[f];
+        blocks[b].n_bin = (e < n_bcf ? first_bin[e] : n_bin) - first_bin[f];
+        if (blocks[b].n_bin > MAX_BIN_PER_BLOCK)
+            return set_error(XSI_ERR_UNSUPPORTED, "Variant BCF generation error, BM bits: block %u has %u binary lines", b,
+                             blocks[b].n_bin);
+    }
+    const uint32_t stride_w = ((N + 63u) / 64u) * 2u;
+    // device metadata
+    uint32_t *d_nbits, *d_nallele, *d_first_bin, *d_parent, *d_bin_nbits;
+    WS(d_nbits, "gt.bcf_nbits", 4ull * n_bcf);
+    WS(d_nallele, "gt.bcf_nallele", 4ull * n_bcf);
+    WS(d_first_bin, "gt.bcf_first_bin", 4ull * n_bcf);
+    WS(d_parent, "gt.bin_parent", 4ull * n_bin);
+    WS(d_bin_nbits, "gt.bin_nbits", 4ull * n_bin);
+    HIP_TRY(hipMemcpyAsync(d_nbits, h_ngt, 4ull * n_bcf, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_nallele, h_n_allele, 4ull * n_bcf, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_first_bin, first_bin.data(), 4ull * n_bcf, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_parent, parent.data(), 4ull * n_bin, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_bin_nbits, nbits_bin.data(), 4ull * n_bin, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // the host vectors above go out of scope with this call
+
+    UnpackArgs U{};
+    U.gt = d_gt;
+    U.gt_stride = gt_stride;
+    U.bcf_nbits = d_nbits;
+    U.bcf_n_allele = d_nallele;
+    U.bcf_first_bin = d_first_bin;
+    U.n_samples = p->n_samples;
+    U.default_phased = p->default_phased;
+    U.stride_w = stride_w;
+    WS(U.planes, "gt.planes", 4ull * stride_w * (size_t)n_bin);
+    WS(U.ref_planes, "gt.ref_planes", 4ull * stride_w * (size_t)n_bcf);
+    WS(U.miss_planes, "gt.miss_planes", 4ull * stride_w * (size_t)n_bcf);
+    WS(U.eov_planes, "gt.eov_planes", 4ull * stride_w * (size_t)n_bcf);
+    WS(U.phase_planes, "gt.phase_planes", 4ull * stride_w * (size_t)n_bcf);
+    WS(U.cnt, "enc.cnt", 4ull * n_bin);
+    WS(U.ref_cnt, "gt.ref_cnt", 4ull * n_bcf);
+    WS(U.miss_cnt, "gt.miss_cnt", 4ull * n_bcf);
+    WS(U.eov_cnt, "gt.eov_cnt", 4ull * n_bcf);
+    WS(U.bcf_flags, "gt.bcf_flags", 4ull * n_bcf);
+    WS(U.kind, "enc.kind", (size_t)n_bin);
+    WS(U.d_error, "gt.error", 64);
+    HIP_TRY(hipMemsetAsync(U.d_error, 0, 4, s));
+    k_unpack_gt<<<dim3(n_bcf), dim3(256), 0, s>>>(U);
+    HIP_TRY(hipGetLastError());
+
+    EncLines L{};
+    L.planes = U.planes;
+    L.plane_stride_w = stride_w;
+    L.n_bin = n_bin;
+    L.N = N;
+    L.aet = p->n_samples <= 65535u ? 2u : 4u;
+    L.thr = p->mac_threshold;
+    L.bin_nbits = d_bin_nbits;
+    L.bin_parent = d_parent;
+    L.ref_planes = U.ref_planes;
+    L.ref_cnt = U.ref_cnt;
+    L.cnt = U.cnt;
+    L.kind = U.kind;
+
+    EncSide S{};
+    S.miss_planes = U.miss_planes;
+    S.eov_planes = U.eov_planes;
+    S.phase_planes = U.phase_planes;
+    S.bcf_nbits = d_nbits;
+    S.bcf_flags = U.bcf_flags;
+    S.bcf_first_bin = d_first_bin;
+    S.miss_cnt = U.miss_cnt;
+    S.eov_cnt = U.eov_cnt;
+    S.n_bcf = n_bcf;
+    S.plane_stride_w = stride_w;
+    S.aet = L.aet;
+    S.strategy = p->wah_encode_missing ? WS_WAH : WS_SPARSE;
+    WS(S.miss_size, "gt.miss_size", 4ull * n_bcf);
+    WS(S.eov_size, "gt.eov_size", 4ull * n_bcf);
+    WS(S.phase_len, "gt.phase_len", 4ull * n_bcf);
+    WS(S.miss_off, "gt.miss_off", 4ull * n_bcf);
+    WS(S.eov_off, "gt.eov_off", 4ull * n_bcf);
+    WS(S.phase_off, "gt.phase_off", 4ull * n_bcf);
+    k_side_sizes<<<dim3((n_bcf + 3u) / 4u), dim3(256), 0, s>>>(S);
+    HIP_TRY(hipGetLastError());
+    // flag vectors need the block table on the device: encode_run uploads it, so stage a copy here
+    EncBlock* d_blocks;
+    WS(d_blocks, "enc.blocks", sizeof(EncBlock) * (size_t)n_blocks);
+    uint32_t* flagbits;
+    WS(flagbits, "enc.flagbits", 4ull * (MAX_BIN_PER_BLOCK / 32) * FV_COUNT * (size_t)n_blocks);
+    HIP_TRY(hipMemcpyAsync(d_blocks, blocks.data(), sizeof(EncBlock) * (size_t)n_blocks, hipMemcpyHostToDevice, s));
+    k_side_flagbits<<<dim3(n_blocks), dim3(256), 0, s>>>(d_blocks, S, flagbits);
+    HIP_TRY(hipGetLastError());
+
+    int rc = encode_run(ctx, p, L, S, blocks, d_out, out_capacity, d_block_offsets, h_result);
+    if (rc) return rc;
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, U.d_error, 4, hipMemcpyDeviceToHost));
+    if (err) return set_error(XSI_ERR_ARG, "Unknown allele error !");
+    if (h_result) h_result->max_ploidy = max_ploidy;
+    return XSI_OK;
+}
+
+int xsi_hip_decode_gt(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block,
+                      uint64_t n_blocks64, const uint32_t* h_n_allele, uint64_t n_lines, int32_t* d_gt_out,
+                      uint64_t gt_stride, uint32_t* h_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles) {
+    if (!ctx || !d_file || !h_n_allele || !d_gt_out) return set_error(XSI_ERR_ARG, "decode_gt: null argument");
+    if (file_len < 256) return set_error(XSI_ERR_FORMAT, "file image shorter than the 256-byte header");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DecodePlan P;
+    int rc = decode_prepare(ctx, d_file, file_len, first_block, n_blocks64, &P);
+    if (rc) return rc;
+    if (P.n_bcf != n_lines)
+        return set_error(XSI_ERR_ARG, "decode_gt: blocks hold %u BCF lines, caller passed %llu", P.n_bcf, (unsigned long long)n_lines);
+    if (gt_stride < P.L.N) return set_error(XSI_ERR_ARG, "gt_stride %llu < %u haplotypes", (unsigned long long)gt_stride, P.L.N);
+    const uint32_t n_bcf = P.n_bcf, n_bin = P.n_bin;
+    // BCF line -> first binary line; must agree with every block's dictionary
+    std::vector<uint32_t> first_bin(n_bcf);
+    {
+        uint32_t l = 0;
+        for (uint32_t b = 0; b < P.n_blocks; ++b) {
+            uint32_t acc = P.blocks_h[b].first_bin;
+            for (uint32_t i = 0; i < P.blocks_h[b].n_bcf; ++i, ++l) {
+                if (h_n_allele[l] < 2) return set_error(XSI_ERR_ARG, "decode_gt: line %u has fewer than 2 alleles", l);
+                first_bin[l] = acc;
+                acc += h_n_allele[l] - 1;
+            }
+            if (acc != P.blocks_h[b].first_bin + P.blocks_h[b].n_bin)
+                return set_error(XSI_ERR_ARG, "decode_gt: allele numbers of block %u add up to %u binary lines, the block has %u", b,
+                                 acc - P.blocks_h[b].first_bin, P.blocks_h[b].n_bin);
+        }
+    }
+    const uint32_t stride_w = P.L.y_stride64 * 2u;
+    uint32_t *d_first_bin, *d_nallele, *d_line_ngt;
+    WS(d_first_bin, "gt.bcf_first_bin", 4ull * n_bcf);
+    WS(d_nallele, "gt.bcf_nallele", 4ull * n_bcf);
+    WS(d_line_ngt, "gt.line_ngt", 4ull * n_bcf);
+    HIP_TRY(hipMemcpyAsync(d_first_bin, first_bin.data(), 4ull * n_bcf, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_nallele, h_n_allele, 4ull * n_bcf, hipMemcpyHostToDevice, s));
+    DecodedPlanes DPn;
+    rc = decode_all_planes(ctx, d_file, P, &DPn);
+    if (rc) return rc;
+    rc = compose_lines(ctx, P, DPn, d_first_bin, d_nallele, n_bcf, d_gt_out, gt_stride, d_line_ngt, d_allele_counts,
+                       max_alleles);
+    if (rc) return rc;
+    if (h_line_ngt) HIP_TRY(hipMemcpyAsync(h_line_ngt, d_line_ngt, 4ull * n_bcf, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return XSI_OK;
+}
+
+}  // extern "C"

@@ -1,32 +1,463 @@
-// xsi_host.hip — file-level writer / accessor (placeholder until the general path lands).
+// xsi_host.hip — file-level writer and accessor: the host-side mirror of the reference's
+// XsiFactoryExt (include/xsi_factory.hpp:435-639) and Accessor (include/accessor.hpp:31-124,
+// accessor.cpp:26-88) on top of the GPU block codec.
+//
+// The reference encodes and decodes one line per call on the CPU.  A GPU cannot work a line at
+// a time, so both classes batch per block behind the same per-line interface:
+//   writer  : append() stages int32 rows, ships them to HBM in chunks, and when block_len lines
+//             are in, encodes the whole block on the GPU and appends the bytes to the file;
+//   accessor: the first touch of a block decodes ALL its binary lines to bit planes on the GPU;
+//             int32 rows are then composed on the GPU per window of lines (bi-allelic blocks) or
+//             per requested line (blocks with multi-allelic lines, whose grouping the accessor only
+//             learns from each call's n_alleles, accessor.hpp:48-50) and served from pinned memory.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
 #include "../../include/xsi_hip.h"
 #include "xsi_ctx.hpp"
 
 using namespace xsi;
 
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) return set_error(XSI_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                               __FILE__, __LINE__);                                          \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// writer
+// ------------------------------------------------------------------------------------------
+struct xsi_writer {
+    xsi_hip_ctx* ctx = nullptr;
+    xsi_encode_params p{};
+    FILE* f = nullptr;
+    std::vector<std::string> names;
+    uint64_t N = 0;
+    // current block
+    int32_t* d_rows = nullptr;   // [block_len][N]
+    int32_t* h_chunk = nullptr;  // pinned staging
+    uint32_t chunk_rows = 0, chunk_fill = 0;
+    uint32_t lines_in_block = 0, lines_on_device = 0;
+    std::vector<uint32_t> ngt, n_allele;
+    uint8_t* d_out = nullptr;
+    uint64_t out_cap = 0;
+    std::vector<uint8_t> h_out;
+    std::vector<uint64_t> indices;
+    uint64_t entry_counter = 0, variant_counter = 0;
+    uint32_t max_ploidy_seen = 0;
+    uint64_t file_pos = 0;
+};
+
+static int writer_ship_chunk(xsi_writer* w) {
+    if (!w->chunk_fill) return XSI_OK;
+    HIP_TRY(hipMemcpyAsync(w->d_rows + (size_t)w->lines_on_device * w->N, w->h_chunk,
+                           (size_t)w->chunk_fill * w->N * sizeof(int32_t), hipMemcpyHostToDevice, w->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(w->ctx->stream));  // the staging buffer is reused right away
+    w->lines_on_device += w->chunk_fill;
+    w->chunk_fill = 0;
+    return XSI_OK;
+}
+
+static int writer_flush_block(xsi_writer* w) {
+    if (!w->lines_in_block) return XSI_OK;
+    int rc = writer_ship_chunk(w);
+    if (rc) return rc;
+    uint64_t n_bin = 0;
+    for (uint32_t a : w->n_allele) n_bin += a - 1;
+    const uint64_t need = xsi_hip_encode_gt_bound(&w->p, w->lines_in_block, n_bin);
+    if (need > w->out_cap) {
+        if (w->d_out) (void)hipFree(w->d_out);
+        w->d_out = nullptr;
+        HIP_TRY(hipMalloc((void**)&w->d_out, need));
+        w->out_cap = need;
+    }
+    xsi_encode_result res{};
+    rc = xsi_hip_encode_gt(w->ctx, &w->p, w->d_rows, w->N, w->lines_in_block, w->ngt.data(), w->n_allele.data(), w->d_out,
+                           w->out_cap, nullptr, &res);
+    if (rc) return rc;
+    w->h_out.resize(res.blocks_bytes);
+    HIP_TRY(hipMemcpy(w->h_out.data(), w->d_out, res.blocks_bytes, hipMemcpyDeviceToHost));
+    w->indices.push_back(w->file_pos);  // xsi_factory.hpp:533
+    if (fwrite(w->h_out.data(), 1, w->h_out.size(), w->f) != w->h_out.size()) return set_error(XSI_ERR_IO, "short write");
+    w->file_pos += w->h_out.size();
+    w->lines_in_block = w->lines_on_device = 0;
+    w->ngt.clear();
+    w->n_allele.clear();
+    return XSI_OK;
+}
+
 extern "C" {
-int xsi_hip_encode_gt(xsi_hip_ctx*, const xsi_encode_params*, const int32_t*, uint64_t, uint64_t, const uint32_t*,
-                      const uint32_t*, void*, uint64_t, uint64_t*, xsi_encode_result*) {
-    return set_error(XSI_ERR_UNSUPPORTED, "encode_gt: not built yet");
+
+uint64_t xsi_hip_encode_gt_bound(const xsi_encode_params* p, uint64_t n_bcf_lines, uint64_t n_binary_lines) {
+    if (!p) return 0;
+    const uint64_t N = 2ull * p->n_samples;
+    const uint64_t aet = p->n_samples <= 65535u ? 2 : 4;
+    const uint64_t G = (N + 14) / 15;
+    // per BCF line: missing + end-of-vector entries share at most N positions (2 counts), or two WAH
+    // lines with --wah-encode-missing; plus one phase WAH line
+    uint64_t side = 2 * aet + N * aet;
+    if (p->wah_encode_missing && 2 * G * 2 > side) side = 2 * G * 2;
+    side += G * 2;
+    return xsi_hip_encode_bound(p, n_bcf_lines, n_binary_lines) + n_bcf_lines * side;
 }
-int xsi_hip_decode_gt(xsi_hip_ctx*, const void*, uint64_t, uint64_t, uint64_t, const uint32_t*, uint64_t, int32_t*,
-                      uint64_t, uint32_t*, uint64_t*, uint32_t) {
-    return set_error(XSI_ERR_UNSUPPORTED, "decode_gt: not built yet");
+
+int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const xsi_encode_params* p,
+                    const char* const* sample_names) {
+    if (!out || !ctx || !path || !p) return set_error(XSI_ERR_ARG, "writer_open: null argument");
+    if (!p->n_samples || !p->block_len || p->block_len > MAX_BIN_PER_BLOCK)
+        return set_error(XSI_ERR_ARG, "writer_open: bad n_samples / block_len");
+    HIP_TRY(hipSetDevice(ctx->device));
+    xsi_writer* w = new xsi_writer();
+    w->ctx = ctx;
+    w->p = *p;
+    w->N = 2ull * p->n_samples;
+    for (uint32_t i = 0; i < p->n_samples; ++i) w->names.emplace_back(sample_names ? sample_names[i] : "");
+    w->f = fopen(path, "wb");
+    if (!w->f) {
+        delete w;
+        return set_error(XSI_ERR_IO, "Failed to open file %s", path);
+    }
+    // provisional header, rewritten by finalize (xsi_factory.hpp:468-511)
+    uint8_t zero[256] = {0};
+    fwrite(zero, 1, 256, w->f);
+    w->file_pos = 256;
+    const size_t row_bytes = (size_t)w->N * sizeof(int32_t);
+    hipError_t e = hipMalloc((void**)&w->d_rows, row_bytes * p->block_len);
+    if (e != hipSuccess) {
+        fclose(w->f);
+        delete w;
+        return set_error(XSI_ERR_HIP, "hipMalloc block rows: %s", hipGetErrorString(e));
+    }
+    size_t chunk_bytes = 64ull << 20;
+    w->chunk_rows = (uint32_t)(chunk_bytes / row_bytes);
+    if (w->chunk_rows < 1) w->chunk_rows = 1;
+    if (w->chunk_rows > p->block_len) w->chunk_rows = p->block_len;
+    e = hipHostMalloc((void**)&w->h_chunk, row_bytes * w->chunk_rows, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipFree(w->d_rows);
+        fclose(w->f);
+        delete w;
+        return set_error(XSI_ERR_HIP, "hipHostMalloc staging: %s", hipGetErrorString(e));
+    }
+    *out = w;
+    return XSI_OK;
 }
-int xsi_writer_open(xsi_writer**, xsi_hip_ctx*, const char*, const xsi_encode_params*, const char* const*) {
-    return set_error(XSI_ERR_UNSUPPORTED, "writer: not built yet");
+
+int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t n_allele) {
+    if (!w || !h_gt) return set_error(XSI_ERR_ARG, "writer_append: null argument");
+    if (ngt != w->p.n_samples && ngt != 2u * w->p.n_samples)
+        return set_error(XSI_ERR_ARG, "PLOIDY ERROR: %u values for %u samples", ngt, w->p.n_samples);
+    if (n_allele < 2) return set_error(XSI_ERR_UNSUPPORTED, "lines without an ALT allele are rejected (see xsi_hip_encode_gt)");
+    // check_flush_block, xsi_factory.hpp:527-539
+    if (w->lines_in_block == w->p.block_len) {
+        int rc = writer_flush_block(w);
+        if (rc) return rc;
+    }
+    int32_t* dst = w->h_chunk + (size_t)w->chunk_fill * w->N;
+    memcpy(dst, h_gt, (size_t)ngt * sizeof(int32_t));
+    w->chunk_fill++;
+    w->lines_in_block++;
+    w->ngt.push_back(ngt);
+    w->n_allele.push_back(n_allele);
+    const uint32_t pl = ngt / w->p.n_samples;
+    if (pl > w->max_ploidy_seen) w->max_ploidy_seen = pl;
+    w->variant_counter += n_allele - 1;
+    w->entry_counter++;
+    if (w->chunk_fill == w->chunk_rows) return writer_ship_chunk(w);
+    return XSI_OK;
 }
-int xsi_writer_append(xsi_writer*, const int32_t*, uint32_t, uint32_t) { return XSI_ERR_UNSUPPORTED; }
-int xsi_writer_finalize(xsi_writer*, uint32_t) { return XSI_ERR_UNSUPPORTED; }
-void xsi_writer_close(xsi_writer*) {}
-int xsi_accessor_open(xsi_accessor**, xsi_hip_ctx*, const char*) {
-    return set_error(XSI_ERR_UNSUPPORTED, "accessor: not built yet");
+
+int xsi_writer_finalize(xsi_writer* w, uint32_t max_ploidy) {
+    if (!w || !w->f) return set_error(XSI_ERR_ARG, "writer_finalize: null / closed writer");
+    int rc = writer_flush_block(w);
+    if (rc) return rc;
+    // xsi_factory.hpp:558-605
+    while (w->file_pos % 8) {
+        fputc(0, w->f);
+        w->file_pos++;
+    }
+    xsi_header_fields hf{};
+    hf.n_samples = w->p.n_samples;
+    hf.max_ploidy = max_ploidy ? max_ploidy : w->max_ploidy_seen;
+    hf.block_len = w->p.block_len;
+    hf.mac_threshold = w->p.mac_threshold;
+    hf.default_phased = w->p.default_phased;
+    hf.zstd = 0;
+    hf.num_variants = w->variant_counter;
+    hf.xcf_entries = w->entry_counter;
+    hf.indices_offset = w->file_pos;
+    if (!w->indices.empty() && fwrite(w->indices.data(), 8, w->indices.size(), w->f) != w->indices.size())
+        return set_error(XSI_ERR_IO, "short write");
+    w->file_pos += 8 * w->indices.size();
+    hf.samples_offset = w->file_pos;
+    for (auto& s : w->names) fwrite(s.c_str(), 1, s.size() + 1, w->f);
+    uint8_t h[256];
+    xsi_hip_make_header(&hf, h);
+    fflush(w->f);
+    fseek(w->f, 0, SEEK_SET);
+    if (fwrite(h, 1, 256, w->f) != 256) return set_error(XSI_ERR_IO, "short write");
+    fclose(w->f);
+    w->f = nullptr;
+    return XSI_OK;
 }
-int64_t xsi_accessor_fill_genotype_array(xsi_accessor*, int32_t*, uint64_t, uint32_t, uint64_t) { return XSI_ERR_UNSUPPORTED; }
-int64_t xsi_accessor_get_genotypes(xsi_accessor*, uint32_t, uint64_t, void**, int*) { return XSI_ERR_UNSUPPORTED; }
-int xsi_accessor_allele_counts(xsi_accessor*, uint64_t*, uint32_t) { return XSI_ERR_UNSUPPORTED; }
-uint64_t xsi_accessor_hap_samples(const xsi_accessor*) { return 0; }
-uint64_t xsi_accessor_num_samples(const xsi_accessor*) { return 0; }
-const char* xsi_accessor_sample_name(const xsi_accessor*, uint64_t) { return nullptr; }
-void xsi_accessor_close(xsi_accessor*) {}
+
+void xsi_writer_close(xsi_writer* w) {
+    if (!w) return;
+    if (w->f) fclose(w->f);
+    if (w->d_rows) (void)hipFree(w->d_rows);
+    if (w->d_out) (void)hipFree(w->d_out);
+    if (w->h_chunk) (void)hipHostFree(w->h_chunk);
+    delete w;
 }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// accessor
+// ------------------------------------------------------------------------------------------
+struct xsi_accessor {
+    xsi_hip_ctx* ctx = nullptr;  // private context (own stream + workspace) on the caller's device
+    std::vector<uint8_t> file;
+    uint8_t* d_file = nullptr;
+    uint32_t version = 0, aet = 0, ploidy = 0;
+    uint64_t hap_samples = 0, num_samples = 0, n_blocks = 0;
+    std::vector<std::string> names;
+    // current block
+    int64_t cur_block = -1;
+    DecodePlan P;
+    DecodedPlanes D;
+    bool biallelic = false;
+    // composed window of a bi-allelic block, or the single last composed line
+    int32_t* d_rows = nullptr;
+    int32_t* h_rows = nullptr;  // pinned
+    uint64_t* d_counts = nullptr;
+    uint64_t* h_counts = nullptr;  // pinned [win][2] or [1][max]
+    uint32_t* d_meta = nullptr;    // first_bin / n_allele / line_ngt
+    uint32_t* h_meta = nullptr;    // pinned
+    uint32_t win_rows = 0, win_first = 0, win_n = 0;
+    uint32_t counts_cap = 0;
+    std::vector<uint64_t> last_counts;
+};
+
+static int accessor_load_block(xsi_accessor* a, uint64_t block) {
+    if (block >= a->n_blocks) return set_error(XSI_ERR_ARG, "block %llu beyond the %llu blocks of the file",
+                                               (unsigned long long)block, (unsigned long long)a->n_blocks);
+    int rc = decode_prepare(a->ctx, a->d_file, a->file.size(), block, 1, &a->P);
+    if (rc) return rc;
+    rc = decode_all_planes(a->ctx, a->d_file, a->P, &a->D);
+    if (rc) return rc;
+    a->biallelic = a->P.n_bin == a->P.n_bcf;
+    a->cur_block = (int64_t)block;
+    a->win_n = 0;
+    return XSI_OK;
+}
+
+// compose `n` lines starting at binary line `first` (bi-allelic window) or one line with n_alleles
+static int accessor_compose(xsi_accessor* a, uint32_t first, uint32_t n, uint32_t n_alleles) {
+    hipStream_t s = a->ctx->stream;
+    const uint32_t N = a->P.L.N;
+    const uint32_t max_al = n_alleles;
+    if ((uint64_t)n * max_al > a->counts_cap) {
+        if (a->d_counts) (void)hipFree(a->d_counts);
+        if (a->h_counts) (void)hipHostFree(a->h_counts);
+        a->d_counts = a->h_counts = nullptr;
+        a->counts_cap = (uint32_t)((uint64_t)n * max_al + 64);
+        HIP_TRY(hipMalloc((void**)&a->d_counts, 8ull * a->counts_cap));
+        HIP_TRY(hipHostMalloc((void**)&a->h_counts, 8ull * a->counts_cap, hipHostMallocDefault));
+    }
+    uint32_t* fb = a->h_meta;
+    uint32_t* na = a->h_meta + a->win_rows;
+    for (uint32_t i = 0; i < n; ++i) {
+        fb[i] = first + i * (n_alleles - 1);
+        na[i] = n_alleles;
+    }
+    HIP_TRY(hipMemcpyAsync(a->d_meta, a->h_meta, 8ull * a->win_rows, hipMemcpyHostToDevice, s));
+    int rc = compose_lines(a->ctx, a->P, a->D, a->d_meta, a->d_meta + a->win_rows, n, a->d_rows, N,
+                           a->d_meta + 2ull * a->win_rows, a->d_counts, max_al);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(a->h_rows, a->d_rows, (size_t)n * N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(a->h_counts, a->d_counts, 8ull * n * max_al, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(a->h_meta + 2ull * a->win_rows, a->d_meta + 2ull * a->win_rows, 4ull * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return XSI_OK;
+}
+
+extern "C" {
+
+int xsi_accessor_open(xsi_accessor** out, xsi_hip_ctx* ctx, const char* path) {
+    if (!out || !ctx || !path) return set_error(XSI_ERR_ARG, "accessor_open: null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return set_error(XSI_ERR_IO, "Failed to open file %s", path);
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 256) {
+        fclose(f);
+        return set_error(XSI_ERR_FORMAT, "Bad magic");
+    }
+    xsi_accessor* a = new xsi_accessor();
+    a->file.resize((size_t)sz);
+    if (fread(a->file.data(), 1, (size_t)sz, f) != (size_t)sz) {
+        fclose(f);
+        delete a;
+        return set_error(XSI_ERR_IO, "short read of %s", path);
+    }
+    fclose(f);
+    const uint8_t* h = a->file.data();
+    auto get = [&](size_t off, int bytes) {
+        uint64_t v = 0;
+        for (int i = 0; i < bytes; ++i) v |= (uint64_t)h[off + i] << (8 * i);
+        return v;
+    };
+    // accessor.cpp:36-51
+    if (get(4, 4) != 0xfeed1767u || get(252, 4) != 0xfeed1767u) {
+        delete a;
+        return set_error(XSI_ERR_FORMAT, "Bad magic");
+    }
+    a->version = (uint32_t)get(8, 4);
+    if (a->version != 4 && a->version != 5) {
+        delete a;
+        return set_error(XSI_ERR_FORMAT, a->version == 2 || a->version == 3 ? "Unsupported version" : "Bad version");
+    }
+    a->ploidy = h[12];
+    a->aet = h[14];
+    a->hap_samples = get(32, 8);
+    a->num_samples = get(112, 8);
+    if (a->aet != 2 && a->aet != 4) {
+        delete a;
+        return set_error(XSI_ERR_FORMAT, "Unsupported A_T");
+    }
+    if (a->ploidy == 0) {
+        delete a;
+        return set_error(XSI_ERR_FORMAT, "PLOIDY ERROR");
+    }
+    if (h[17] & 4u) {
+        delete a;
+        return set_error(XSI_ERR_UNSUPPORTED, "zstd-compressed .xsi files are not supported yet");
+    }
+    const uint64_t io = get(72, 8), so = get(80, 8);
+    if (io > (uint64_t)sz || so > (uint64_t)sz || so < io) {
+        delete a;
+        return set_error(XSI_ERR_FORMAT, "index outside the file");
+    }
+    a->n_blocks = (so - io) / (a->version >= 5 ? 8 : 4);
+    // sample list, accessor.cpp:53-60
+    {
+        const uint64_t want = a->hap_samples / a->ploidy;
+        size_t pos = (size_t)so;
+        while (pos < (size_t)sz && a->names.size() < want) {
+            const void* z = memchr(h + pos, 0, (size_t)sz - pos);
+            if (!z) break;
+            a->names.emplace_back((const char*)h + pos);
+            pos = (const uint8_t*)z - h + 1;
+        }
+    }
+    int rc = xsi_hip_ctx_create(&a->ctx, ctx->device, nullptr);
+    if (rc) {
+        delete a;
+        return rc;
+    }
+    hipError_t e = hipMalloc((void**)&a->d_file, (size_t)sz);
+    if (e == hipSuccess) e = hipMemcpy(a->d_file, h, (size_t)sz, hipMemcpyHostToDevice);
+    const uint64_t N = a->num_samples ? a->num_samples * 2 : a->hap_samples;
+    // window of composed rows: <= 64 MiB of int32
+    uint64_t win = N ? (64ull << 20) / (N * 4) : 1;
+    if (win < 1) win = 1;
+    if (win > MAX_BIN_PER_BLOCK) win = MAX_BIN_PER_BLOCK;
+    a->win_rows = (uint32_t)win;
+    if (e == hipSuccess) e = hipMalloc((void**)&a->d_rows, (size_t)win * N * 4);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&a->h_rows, (size_t)win * N * 4, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&a->d_meta, 12ull * win);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&a->h_meta, 12ull * win, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        xsi_accessor_close(a);
+        return set_error(XSI_ERR_HIP, "accessor buffers: %s", hipGetErrorString(e));
+    }
+    *out = a;
+    return XSI_OK;
+}
+
+int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_t gt_size, uint32_t n_alleles,
+                                         uint64_t position) {
+    if (!a || !h_gt) return set_error(XSI_ERR_ARG, "fill_genotype_array: null argument");
+    if (n_alleles < 2) return set_error(XSI_ERR_ARG, "fill_genotype_array: n_alleles < 2");
+    // AccessorInternalsNewTemplate::seek, accessor_internals_new.hpp:722-738
+    const uint64_t block = (position & 0xFFFFFFFFull) >> BM_BLOCK_BITS;
+    const uint32_t offset = (uint32_t)(position & ((1u << BM_BLOCK_BITS) - 1u));
+    if (a->cur_block < 0 || (uint64_t)a->cur_block != block) {
+        int rc = accessor_load_block(a, block);
+        if (rc) return rc;
+    }
+    if (offset + (n_alleles - 1) > a->P.n_bin)
+        return set_error(XSI_ERR_ARG, "position offset %u (+%u alleles) beyond the %u binary lines of block %llu", offset,
+                         n_alleles - 1, a->P.n_bin, (unsigned long long)block);
+    const uint32_t N = a->P.L.N;
+    uint32_t row = 0;
+    if (a->biallelic && n_alleles == 2) {
+        if (!(a->win_n && offset >= a->win_first && offset < a->win_first + a->win_n)) {
+            uint32_t n = a->P.n_bin - offset;
+            if (n > a->win_rows) n = a->win_rows;
+            int rc = accessor_compose(a, offset, n, 2);
+            if (rc) return rc;
+            a->win_first = offset;
+            a->win_n = n;
+        }
+        row = offset - a->win_first;
+    } else {
+        int rc = accessor_compose(a, offset, 1, n_alleles);
+        if (rc) return rc;
+        a->win_n = 0;
+        row = 0;
+    }
+    const uint32_t ngt = a->h_meta[2ull * a->win_rows + row];
+    if (gt_size < ngt) return set_error(XSI_ERR_CAPACITY, "gt array holds %llu values, line has %u", (unsigned long long)gt_size, ngt);
+    memcpy(h_gt, a->h_rows + (size_t)row * N, (size_t)ngt * sizeof(int32_t));
+    a->last_counts.assign(a->h_counts + (size_t)row * n_alleles, a->h_counts + (size_t)(row + 1) * n_alleles);
+    return (int64_t)ngt;
+}
+
+int64_t xsi_accessor_get_genotypes(xsi_accessor* a, uint32_t n_alleles, uint64_t position, void** h_gt, int* ngt_arr) {
+    if (!a || !h_gt || !ngt_arr) return set_error(XSI_ERR_ARG, "get_genotypes: null argument");
+    const uint64_t ngt = a->hap_samples;  // accessor.hpp:59
+    if (!*h_gt) {
+        *h_gt = malloc(sizeof(int) * (ngt ? ngt : 1));
+        if (!*h_gt) return set_error(XSI_ERR_ARG, "malloc failed");
+    }
+    *ngt_arr = (int)ngt;
+    return xsi_accessor_fill_genotype_array(a, (int32_t*)*h_gt, ngt, n_alleles, position);
+}
+
+int xsi_accessor_allele_counts(xsi_accessor* a, uint64_t* h_counts, uint32_t n_alleles) {
+    if (!a || !h_counts) return set_error(XSI_ERR_ARG, "allele_counts: null argument");
+    if (a->last_counts.size() < n_alleles) return set_error(XSI_ERR_ARG, "no fill with %u alleles precedes this call", n_alleles);
+    memcpy(h_counts, a->last_counts.data(), 8ull * n_alleles);
+    return XSI_OK;
+}
+
+uint64_t xsi_accessor_hap_samples(const xsi_accessor* a) { return a ? a->hap_samples : 0; }
+uint64_t xsi_accessor_num_samples(const xsi_accessor* a) { return a ? a->names.size() : 0; }
+const char* xsi_accessor_sample_name(const xsi_accessor* a, uint64_t i) {
+    return (a && i < a->names.size()) ? a->names[i].c_str() : nullptr;
+}
+
+void xsi_accessor_close(xsi_accessor* a) {
+    if (!a) return;
+    if (a->ctx) (void)hipStreamSynchronize(a->ctx->stream);
+    if (a->d_file) (void)hipFree(a->d_file);
+    if (a->d_rows) (void)hipFree(a->d_rows);
+    if (a->h_rows) (void)hipHostFree(a->h_rows);
+    if (a->d_counts) (void)hipFree(a->d_counts);
+    if (a->h_counts) (void)hipHostFree(a->h_counts);
+    if (a->d_meta) (void)hipFree(a->d_meta);
+    if (a->h_meta) (void)hipHostFree(a->h_meta);
+    if (a->ctx) xsi_hip_ctx_destroy(a->ctx);
+    delete a;
+}
+
+}  // extern "C"

@@ -865,8 +865,8 @@ __global__ void __launch_bounds__(64) k_block_layout(EncBlock* __restrict__ bloc
             const uint32_t f = valid ? S.bcf_flags[li] : 0u;
             uint32_t mb = 0, ebb = 0, pw = 0;
             if (valid) {
-                if (f & 1u) mb = (S.strategy == WS_SPARSE) ? (1u + S.miss_cnt[li]) * L.aet : S.phase_len[S.n_bcf + li] * 2u;
-                if (f & 2u) ebb = (S.strategy == WS_SPARSE) ? (1u + S.eov_cnt[li]) * L.aet : S.phase_len[2u * S.n_bcf + li] * 2u;
+                if (f & 1u) mb = S.miss_size[li];
+                if (f & 2u) ebb = S.eov_size[li];
                 if (f & 4u) pw = S.phase_len[li];
             }
             const uint32_t im = wave_scan_incl(mb), ie = wave_scan_incl(ebb), ip = wave_scan_incl(pw);

@@ -37,21 +37,25 @@ struct EncLines {
     uint16_t* flagwah;          // [n_blocks][FV_COUNT][FLAG_WORDS_MAX] encoded flag vectors
 };
 
-// side channels of the general path (per BCF line planes; nullptr on the fast path)
+// side channels of the general path (per BCF line; all nullptr on the packed fast path)
 struct EncSide {
-    const uint32_t* miss_planes;
-    const uint32_t* eov_planes;
-    const uint32_t* phase_planes;
-    const uint32_t* bcf_nbits;    // GT values per BCF line
+    const uint32_t* miss_planes;  // [n_bcf][plane_stride_w] missing positions (MissingPred, gt_block.hpp:76-81)
+    const uint32_t* eov_planes;   // end-of-vector positions (EndOfVectorPred, gt_block.hpp:82-87)
+    const uint32_t* phase_planes; // odd index && phase bit != default (NonDefaultPhasingPred, gt_block.hpp:93-100)
+    const uint32_t* bcf_nbits;    // GT values per BCF line (n_samples or 2*n_samples)
     const uint32_t* bcf_flags;    // bit0 missing, bit1 eov, bit2 phase, bit3 haploid
-    const uint32_t* bcf_first_bin;
+    const uint32_t* bcf_first_bin;// first binary line of the BCF line (batch-wide)
     const uint32_t* miss_cnt;
     const uint32_t* eov_cnt;
+    uint32_t* miss_size;          // bytes of the line's entry in the missing matrix (0 if none)
+    uint32_t* eov_size;
+    uint32_t* phase_len;          // words of the line's phase WAH line (0 if none)
     uint32_t* miss_off;           // byte offset inside the block's missing matrix
     uint32_t* eov_off;
-    uint32_t* phase_len;          // words of the phase WAH line
-    uint32_t* phase_off;
+    uint32_t* phase_off;          // word offset inside the block's phase matrix
     uint32_t n_bcf;
+    uint32_t plane_stride_w;
+    uint32_t aet;
     uint32_t strategy;            // WS_SPARSE or WS_WAH
 };
 
