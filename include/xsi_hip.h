@@ -58,6 +58,13 @@ int xsi_hip_ctx_synchronize(xsi_hip_ctx* ctx);
 /* Bytes of device workspace currently held by the context. */
 uint64_t xsi_hip_ctx_workspace_bytes(const xsi_hip_ctx* ctx);
 
+/* Per-stage device timing with HIP events recorded on the context's stream (used by bench.py for
+ * the roofline of the dominant kernel).  get_timing fills h_ms[i] / h_launches[i] for stage i and
+ * returns the number of stages; xsi_hip_stage_name(i) names them. */
+int xsi_hip_ctx_set_timing(xsi_hip_ctx* ctx, int on);
+int xsi_hip_ctx_get_timing(xsi_hip_ctx* ctx, double* h_ms, uint64_t* h_launches, int n);
+const char* xsi_hip_stage_name(int i);
+
 /* Parameters of one encode job (the arguments of XsiFactoryExt's constructor that reach
  * GtBlock: include/xsi_factory.hpp:439-449, include/gt_block.hpp:159-181). */
 typedef struct xsi_encode_params {

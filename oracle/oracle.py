@@ -40,6 +40,10 @@ def lib():
     L.xo_writer_new.argtypes = [c.c_uint32, c.c_uint32, c.c_uint32, c.c_int32, c.c_int, c.POINTER(c.c_char_p)]
     L.xo_writer_append.restype = c.c_int
     L.xo_writer_append.argtypes = [c.c_void_p, c.c_void_p, c.c_int32, c.c_int32]
+    L.xo_writer_append_rows.restype = c.c_int
+    L.xo_writer_append_rows.argtypes = [c.c_void_p, c.c_void_p, c.c_size_t, c.c_size_t, c.c_int32, c.c_int32]
+    L.xo_reader_fill_rows.restype = c.c_int64
+    L.xo_reader_fill_rows.argtypes = [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint64, c.c_size_t, c.c_uint32]
     L.xo_writer_finalize.restype = c.c_int
     L.xo_writer_finalize.argtypes = [c.c_void_p, c.c_uint32, c.POINTER(c.c_void_p), c.POINTER(c.c_size_t)]
     L.xo_writer_free.restype = None
@@ -110,6 +114,13 @@ class Writer:
         if rc:
             raise ValueError("xo_writer_append rc=%d" % rc)
 
+    def append_rows(self, gt2d, n_allele=2):
+        gt2d = np.ascontiguousarray(gt2d, dtype=np.int32)
+        rc = lib().xo_writer_append_rows(self._h, gt2d.ctypes.data, gt2d.shape[0], gt2d.shape[1], gt2d.shape[1],
+                                         n_allele)
+        if rc:
+            raise ValueError("xo_writer_append_rows rc=%d" % rc)
+
     def finalize(self, max_ploidy=2):
         p = ctypes.c_void_p()
         n = ctypes.c_size_t()
@@ -161,6 +172,15 @@ class Reader:
             raise ValueError("fill_genotype_array rc=%d" % n)
         counts = np.ctypeslib.as_array(lib().xo_reader_allele_counts(self._h), shape=(n_alleles,)).copy()
         return gt[:n].copy(), counts
+
+    def fill_rows(self, first_line, n_rows, block_len, out=None):
+        """n_rows consecutive bi-allelic diploid lines -> int32 [n_rows, N]."""
+        if out is None:
+            out = np.empty((n_rows, self._n), dtype=np.int32)
+        n = lib().xo_reader_fill_rows(self._h, out.ctypes.data, out.shape[1], first_line, n_rows, block_len)
+        if n < 0:
+            raise ValueError("fill_rows rc=%d" % n)
+        return out
 
     def fill_allele_counts(self, n_alleles, bm):
         rc = lib().xo_reader_fill_allele_counts(self._h, n_alleles, bm)

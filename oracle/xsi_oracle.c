@@ -620,6 +620,14 @@ int xo_writer_append(xo_writer* w, const int32_t* gt, int32_t ngt, int32_t n_all
     return 0;
 }
 
+int xo_writer_append_rows(xo_writer* w, const int32_t* gt, size_t n_rows, size_t stride, int32_t ngt, int32_t n_allele) {
+    for (size_t r = 0; r < n_rows; ++r) {
+        int rc = xo_writer_append(w, gt + r * stride, ngt, n_allele);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 static void put_le(uint8_t* p, uint64_t v, int bytes) {
     for (int i = 0; i < bytes; ++i) p[i] = (uint8_t)(v >> (8 * i));
 }
@@ -1095,6 +1103,17 @@ int64_t xo_reader_fill_genotype_array(xo_reader* r, int32_t* gt, size_t gt_size,
     }
     r->allele_counts[0] = N - (total_alt + n_missing + n_eovs);
     return (int64_t)N;
+}
+
+int64_t xo_reader_fill_rows(xo_reader* r, int32_t* gt, size_t stride, uint64_t first_line, size_t n_rows,
+                            uint32_t block_len) {
+    for (size_t i = 0; i < n_rows; ++i) {
+        const uint64_t line = first_line + i;
+        const uint64_t bm = ((line / block_len) << 15) | (line % block_len);
+        int64_t n = xo_reader_fill_genotype_array(r, gt + i * stride, stride, 2, bm);
+        if (n < 0) return n;
+    }
+    return (int64_t)n_rows;
 }
 
 /* fill_allele_counts_advance, accessor_internals_new.hpp:407-438 */

@@ -57,6 +57,8 @@ xo_writer* xo_writer_new(uint32_t n_samples, uint32_t block_len, uint32_t mac_th
                          const char* const* sample_names);
 /* One BCF line: gt[ngt] in htslib encoding, ngt = n_samples * line ploidy (1 or 2). 0 on success. */
 int xo_writer_append(xo_writer* w, const int32_t* gt, int32_t ngt, int32_t n_allele);
+/* n_rows lines of the same shape: row r at gt + r*stride, each ngt values, n_allele alleles. */
+int xo_writer_append_rows(xo_writer* w, const int32_t* gt, size_t n_rows, size_t stride, int32_t ngt, int32_t n_allele);
 /* Finish; returns malloc'd file image (free with xo_free). (xsi_factory.hpp:543-606) */
 int xo_writer_finalize(xo_writer* w, uint32_t max_ploidy, uint8_t** out, size_t* out_len);
 void xo_writer_free(xo_writer* w);
@@ -72,6 +74,10 @@ xo_reader* xo_reader_open(const uint8_t* file, size_t len);
  * Returns the number of GT values of the line (N_HAPS or N_SAMPLES), <0 on error. */
 int64_t xo_reader_fill_genotype_array(xo_reader* r, int32_t* gt, size_t gt_size,
                                       uint32_t n_alleles, uint64_t bm);
+/* n_rows consecutive bi-allelic lines starting at BCF line first_line (block_len lines per block):
+ * row r to gt + r*stride.  Returns rows decoded or <0. */
+int64_t xo_reader_fill_rows(xo_reader* r, int32_t* gt, size_t stride, uint64_t first_line, size_t n_rows,
+                            uint32_t block_len);
 /* fill_allele_counts(n_alleles, bm) (accessor_internals_new.hpp:407-438). */
 int xo_reader_fill_allele_counts(xo_reader* r, uint32_t n_alleles, uint64_t bm);
 /* allele counts of the last fill (n_alleles entries). */

@@ -42,7 +42,8 @@ class HeaderFields(ctypes.Structure):
 # every symbol include/xsi_hip.h declares; tests check the library exports all of them
 SYMBOLS = [
     "xsi_hip_abi_version", "xsi_hip_last_error", "xsi_hip_ctx_create", "xsi_hip_ctx_destroy",
-    "xsi_hip_ctx_synchronize", "xsi_hip_ctx_workspace_bytes", "xsi_hip_encode_bound", "xsi_hip_encode_packed",
+    "xsi_hip_ctx_synchronize", "xsi_hip_ctx_workspace_bytes", "xsi_hip_ctx_set_timing",
+    "xsi_hip_ctx_get_timing", "xsi_hip_stage_name", "xsi_hip_encode_bound", "xsi_hip_encode_packed",
     "xsi_hip_encode_gt", "xsi_hip_encode_gt_bound", "xsi_hip_make_header", "xsi_hip_decode_packed", "xsi_hip_decode_gt",
     "xsi_hip_synth_packed", "xsi_hip_debug_chain_encode", "xsi_writer_open", "xsi_writer_append",
     "xsi_writer_finalize", "xsi_writer_close", "xsi_accessor_open", "xsi_accessor_fill_genotype_array",
@@ -74,6 +75,12 @@ def lib():
     L.xsi_hip_ctx_synchronize.argtypes = [vp]
     L.xsi_hip_ctx_workspace_bytes.restype = u64
     L.xsi_hip_ctx_workspace_bytes.argtypes = [vp]
+    L.xsi_hip_ctx_set_timing.restype = c.c_int
+    L.xsi_hip_ctx_set_timing.argtypes = [vp, c.c_int]
+    L.xsi_hip_ctx_get_timing.restype = c.c_int
+    L.xsi_hip_ctx_get_timing.argtypes = [vp, c.POINTER(c.c_double), c.POINTER(u64), c.c_int]
+    L.xsi_hip_stage_name.restype = c.c_char_p
+    L.xsi_hip_stage_name.argtypes = [c.c_int]
     L.xsi_hip_encode_bound.restype = u64
     L.xsi_hip_encode_bound.argtypes = [c.POINTER(EncodeParams), u64, u64]
     L.xsi_hip_encode_gt_bound.restype = u64
@@ -139,6 +146,17 @@ class Context:
 
     def synchronize(self):
         check(lib().xsi_hip_ctx_synchronize(self.handle))
+
+    def set_timing(self, on=True):
+        check(lib().xsi_hip_ctx_set_timing(self.handle, 1 if on else 0))
+
+    def timing(self):
+        """{stage name: (total ms, launches)} since set_timing(True)."""
+        n = 32
+        ms = (ctypes.c_double * n)()
+        cnt = (ctypes.c_uint64 * n)()
+        k = check(lib().xsi_hip_ctx_get_timing(self.handle, ms, cnt, n))
+        return {lib().xsi_hip_stage_name(i).decode(): (ms[i], int(cnt[i])) for i in range(k)}
 
     def workspace_bytes(self):
         return int(lib().xsi_hip_ctx_workspace_bytes(self.handle))

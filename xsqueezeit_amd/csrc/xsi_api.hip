@@ -78,6 +78,7 @@ void xsi_hip_ctx_destroy(xsi_hip_ctx* c) {
     for (auto& kv : c->bufs)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -93,6 +94,33 @@ uint64_t xsi_hip_ctx_workspace_bytes(const xsi_hip_ctx* c) {
     if (c)
         for (auto& kv : c->bufs) t += kv.second.cap;
     return t;
+}
+
+int xsi_hip_ctx_set_timing(xsi_hip_ctx* c, int on) {
+    if (!c) return set_error(XSI_ERR_ARG, "null context");
+    c->timing = on != 0;
+    c->ev_used = 0;
+    for (int i = 0; i < XSI_STAGE_COUNT; ++i) {
+        c->stage_ms[i] = 0;
+        c->stage_n[i] = 0;
+    }
+    return XSI_OK;
+}
+
+int xsi_hip_ctx_get_timing(xsi_hip_ctx* c, double* h_ms, uint64_t* h_launches, int n) {
+    if (!c || !h_ms || !h_launches) return set_error(XSI_ERR_ARG, "get_timing: null argument");
+    for (int i = 0; i < n; ++i) {
+        h_ms[i] = i < XSI_STAGE_COUNT ? c->stage_ms[i] : 0.0;
+        h_launches[i] = i < XSI_STAGE_COUNT ? c->stage_n[i] : 0;
+    }
+    return XSI_STAGE_COUNT;
+}
+
+const char* xsi_hip_stage_name(int i) {
+    static const char* names[XSI_STAGE_COUNT] = {"count_rows", "classify_scan", "chain_encode", "wah_size", "block_layout",
+                                                 "write_blocks", "dec_parse_flags", "dec_wah_boundaries", "dec_wah_expand",
+                                                 "chain_decode", "dec_sparse", "gt_unpack", "gt_compose"};
+    return (i >= 0 && i < XSI_STAGE_COUNT) ? names[i] : "";
 }
 
 uint64_t xsi_hip_encode_bound(const xsi_encode_params* p, uint64_t n_bcf_lines, uint64_t n_binary_lines) {
@@ -150,6 +178,33 @@ int xsi_hip_make_header(const xsi_header_fields* f, uint8_t h[256]) {
 }  // extern "C"
 
 namespace xsi {
+
+void stage_mark(xsi_hip_ctx* c, int stage) {
+    if (!c->timing) return;
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->ev_pool.push_back(e);
+        c->ev_stage.push_back(-1);
+    }
+    c->ev_stage[c->ev_used] = stage;
+    (void)hipEventRecord(c->ev_pool[c->ev_used], c->stream);
+    c->ev_used++;
+}
+
+void stage_collect(xsi_hip_ctx* c) {
+    if (!c->timing) return;
+    for (size_t i = 0; i + 1 < c->ev_used; ++i) {
+        const int st = c->ev_stage[i];
+        if (st < 0 || st >= XSI_STAGE_COUNT) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[i], c->ev_pool[i + 1]) == hipSuccess) {
+            c->stage_ms[st] += ms;
+            c->stage_n[st] += 1;
+        }
+    }
+    c->ev_used = 0;
+}
 
 int ws_ensure(xsi_hip_ctx* c, const char* name, size_t bytes, void** out) {
     auto& b = c->bufs[name];
@@ -222,14 +277,19 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     if (!g.in_lds) WS(scratch_a, "chain.a", 4ull * 2ull * (((size_t)N + 63u) & ~(size_t)63u) * n_blocks);
 
     HIP_TRY(hipMemcpyAsync(d_blocks, blocks_h.data(), sizeof(EncBlock) * (size_t)n_blocks, hipMemcpyHostToDevice, s));
+    stage_mark(ctx, XSI_ST_CLASSIFY);
     HIP_TRY(launch_classify(s, d_blocks, n_blocks, L));
     HIP_TRY(launch_scan_blocks_wah(s, d_blocks, n_blocks, d_totals));
     HIP_TRY(launch_build_wah_list(s, d_blocks, n_blocks, L));
+    stage_mark(ctx, XSI_ST_CHAIN_ENC);
     HIP_TRY(launch_chain_encode(s, d_blocks, n_blocks, L, scratch_a));
+    stage_mark(ctx, XSI_ST_WAH_SIZE);
     HIP_TRY(launch_wah_sizes(s, L, d_totals, n_bin));
+    stage_mark(ctx, XSI_ST_LAYOUT);
     HIP_TRY(launch_block_layout(s, d_blocks, n_blocks, L, S, p->default_phased));
     HIP_TRY(launch_scan_blocks_out(s, d_blocks, n_blocks, out_capacity, d_block_offsets, d_result));
     const uint32_t strategy = p->wah_encode_missing ? WS_WAH : WS_SPARSE;
+    stage_mark(ctx, XSI_ST_WRITE);
     HIP_TRY(launch_write_headers(s, d_blocks, n_blocks, L, p->default_phased, strategy, (uint8_t*)d_out, d_result));
     HIP_TRY(launch_wah_write(s, d_blocks, L, n_bin, (uint8_t*)d_out, d_result));
     HIP_TRY(launch_sparse_write(s, d_blocks, L, (uint8_t*)d_out, d_result));
@@ -237,9 +297,11 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
         int rc = encode_side_write(ctx, d_blocks, n_blocks, L, S, (uint8_t*)d_out, d_result);
         if (rc) return rc;
     }
+    stage_mark(ctx, -1);
     uint64_t res[4];
     HIP_TRY(hipMemcpyAsync(res, d_result, sizeof(res), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    stage_collect(ctx);
     if (res[3]) return set_error(XSI_ERR_CAPACITY, "encode: output needs %llu bytes, capacity is %llu",
                                  (unsigned long long)res[0], (unsigned long long)out_capacity);
     if (h_result) {
@@ -292,6 +354,7 @@ int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const vo
     WS(L.cnt, "enc.cnt", 4ull * n_bin);
     WS(L.kind, "enc.kind", (size_t)n_bin);
     HIP_TRY(hipMemsetAsync(L.kind, 0, n_bin, s));
+    stage_mark(ctx, XSI_ST_COUNT);
     HIP_TRY(launch_count_rows(s, L.planes, L.plane_stride_w, N, n_bin, L.cnt));
     EncSide S{};
     return encode_run(ctx, p, L, S, blocks, d_out, out_capacity, d_block_offsets, h_result);
@@ -379,6 +442,7 @@ int xsi_hip_decode_packed(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_le
     if (rc) return rc;
     if (d_counts) HIP_TRY(hipMemcpyAsync(d_counts, P.L.ones, 4ull * P.n_bin, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
+    stage_collect(ctx);
     if (h_rows_written) *h_rows_written = P.n_bin;
     return XSI_OK;
 }
@@ -443,12 +507,15 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
     L.file_len = file_len;
     WS(P->d_blocks, "dec.blocks", sizeof(DecBlock) * (size_t)n_blocks);
     WS(P->d_totals, "dec.totals", 64);
+    stage_mark(ctx, XSI_ST_DEC_PARSE);
     HIP_TRY(launch_parse_blocks(s, (const uint8_t*)d_file, file_len, indices_offset, version, first_block, n_blocks,
                                 P->d_blocks, P->d_totals));
     HIP_TRY(launch_scan_dec_blocks(s, P->d_blocks, n_blocks, P->d_totals));
     uint32_t tot[8];
+    stage_mark(ctx, -1);
     HIP_TRY(hipMemcpyAsync(tot, P->d_totals, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    stage_collect(ctx);
     if (tot[3]) return set_error(XSI_ERR_FORMAT, "corrupt block dictionary in the requested range");
     P->n_bin = tot[0];
     P->n_bcf = tot[4];
@@ -463,14 +530,17 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
     WS(L.sparse_lines, "dec.sparse_lines", 4ull * n_bin + 64);
     WS(L.ones, "dec.ones", 4ull * n_bin + 64);
     WS(L.wah_cumg, "dec.wah_cumg", 4ull * n_bin + 64);
+    stage_mark(ctx, XSI_ST_DEC_PARSE);
     HIP_TRY(launch_decode_flags(s, (const uint8_t*)d_file, P->d_blocks, n_blocks, L));
     HIP_TRY(launch_scan_dec_blocks2(s, P->d_blocks, n_blocks, P->d_totals));
     HIP_TRY(launch_dec_line_lists(s, P->d_blocks, n_blocks, L));
     // host copy of the block descriptors: side-channel presence decides the path
     P->blocks_h.resize(n_blocks);
     HIP_TRY(hipMemcpyAsync(P->blocks_h.data(), P->d_blocks, sizeof(DecBlock) * (size_t)n_blocks, hipMemcpyDeviceToHost, s));
+    stage_mark(ctx, -1);
     HIP_TRY(hipMemcpyAsync(tot, P->d_totals, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    stage_collect(ctx);
     P->n_wah = tot[1];
     P->n_sparse = tot[2];
     P->has_side = false;
@@ -492,11 +562,16 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
     uint32_t* scratch_a = nullptr;
     if (!chain_geometry(L.N, true).in_lds)
         WS(scratch_a, "chain.a", 4ull * 2ull * (((size_t)L.N + 63u) & ~(size_t)63u) * P.n_blocks);
+    stage_mark(ctx, XSI_ST_DEC_BOUND);
     HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
+    stage_mark(ctx, XSI_ST_DEC_EXPAND);
     HIP_TRY(launch_wah_expand(s, f, P.d_blocks, L, P.n_wah, P.d_totals));
+    stage_mark(ctx, XSI_ST_CHAIN_DEC);
     HIP_TRY(launch_chain_decode(s, P.d_blocks, P.n_blocks, L, out, stride_w, scratch_a));
+    stage_mark(ctx, XSI_ST_DEC_SPARSE);
     HIP_TRY(launch_sparse_walk(s, f, P.d_blocks, P.n_blocks, L));
     HIP_TRY(launch_sparse_fill(s, f, P.d_blocks, L, P.n_sparse, P.d_totals, out, stride_w, apply_negation));
+    stage_mark(ctx, -1);
     return XSI_OK;
 }
 

@@ -10,6 +10,23 @@
 
 #include "xsi_kernels.hpp"
 
+enum {
+    XSI_ST_COUNT = 0,      // row popcount
+    XSI_ST_CLASSIFY,       // classify + scans + WAH line list
+    XSI_ST_CHAIN_ENC,      // PBWT chain (encode)
+    XSI_ST_WAH_SIZE,       // WAH16 sizing pass
+    XSI_ST_LAYOUT,         // block layout + offsets
+    XSI_ST_WRITE,          // dictionary + WAH + sparse writers
+    XSI_ST_DEC_PARSE,      // dictionaries, flag vectors, line lists
+    XSI_ST_DEC_BOUND,      // WAH line boundaries
+    XSI_ST_DEC_EXPAND,     // WAH16 expand
+    XSI_ST_CHAIN_DEC,      // PBWT chain (decode)
+    XSI_ST_DEC_SPARSE,     // sparse walk + fill
+    XSI_ST_GT_UNPACK,      // int32 rows -> planes (+ side sizing)
+    XSI_ST_GT_COMPOSE,     // planes -> int32 rows (+ side planes)
+    XSI_STAGE_COUNT
+};
+
 struct xsi_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -21,6 +38,13 @@ struct xsi_hip_ctx {
     std::map<std::string, Buf> bufs;  // named device workspace, grown on demand, reused across calls
     void* pinned = nullptr;           // pinned host staging
     size_t pinned_cap = 0;
+    // optional per-stage timing with HIP events recorded on `stream` (bench.py roofline leg)
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_stage;        // stage that STARTS at event i (-1 = end marker)
+    size_t ev_used = 0;
+    double stage_ms[XSI_STAGE_COUNT] = {0};
+    uint64_t stage_n[XSI_STAGE_COUNT] = {0};
 };
 
 struct xsi_encode_params;
@@ -29,6 +53,10 @@ struct xsi_encode_result;
 namespace xsi {
 
 int set_error(int code, const char* fmt, ...);
+// mark the start of `stage` on the stream (no-op unless timing is on); stage -1 ends the last one
+void stage_mark(xsi_hip_ctx* c, int stage);
+// after a stream sync: fold the recorded events into stage_ms / stage_n
+void stage_collect(xsi_hip_ctx* c);
 int ws_ensure(xsi_hip_ctx* c, const char* name, size_t bytes, void** out);
 int pinned_ensure(xsi_hip_ctx* c, size_t bytes, void** out);
 

@@ -600,6 +600,7 @@ int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D,
     C.line_ngt = d_line_ngt;
     C.allele_counts = d_allele_counts;
     C.max_alleles = max_alleles;
+    stage_mark(ctx, XSI_ST_GT_COMPOSE);
     k_compose_gt<<<dim3(n_out), dim3(256), 0, ctx->stream>>>(C);
     HIP_TRY(hipGetLastError());
     return XSI_OK;
@@ -691,6 +692,7 @@ int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_
     WS(U.kind, "enc.kind", (size_t)n_bin);
     WS(U.d_error, "gt.error", 64);
     HIP_TRY(hipMemsetAsync(U.d_error, 0, 4, s));
+    stage_mark(ctx, XSI_ST_GT_UNPACK);
     k_unpack_gt<<<dim3(n_bcf), dim3(256), 0, s>>>(U);
     HIP_TRY(hipGetLastError());
 
@@ -790,8 +792,10 @@ int xsi_hip_decode_gt(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, u
     rc = compose_lines(ctx, P, DPn, d_first_bin, d_nallele, n_bcf, d_gt_out, gt_stride, d_line_ngt, d_allele_counts,
                        max_alleles);
     if (rc) return rc;
+    stage_mark(ctx, -1);
     if (h_line_ngt) HIP_TRY(hipMemcpyAsync(h_line_ngt, d_line_ngt, 4ull * n_bcf, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    stage_collect(ctx);
     return XSI_OK;
 }
 
