@@ -1,0 +1,204 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol the header declares, host
+helpers agree with the oracle, the synthetic generator is frozen, and the multi-rank gather /
+assemble path (gloo, world_size 2) reproduces the single-process file."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+import socket
+import struct
+
+import numpy as np
+import pytest
+
+from xsqueezeit_amd import binding, dist as xdist, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "xsi_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(xsi_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(binding.SYMBOLS), declared ^ set(binding.SYMBOLS)
+    L = binding.lib()
+    for s in sorted(declared):
+        assert hasattr(L, s), s
+    assert L.xsi_hip_abi_version() == 1
+
+
+def test_no_gpu_means_error_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(binding.XsiError) as e:
+        binding.Context(0)
+    assert e.value.code == binding.XSI_ERR_HIP
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_make_header_matches_oracle():
+    from oracle import oracle
+    n = 30
+    rng = np.random.default_rng(1)
+    lines = []
+    for _ in range(70):
+        al = (rng.random(2 * n) < 0.2).astype(np.int32)
+        gt = (al + 1) << 1
+        gt[1::2] |= 1
+        lines.append((gt.astype(np.int32), 2))
+    ref = oracle.encode_file(lines, n, block_len=32, mac_thr=3, default_phased=1)
+    io, so = struct.unpack_from("<QQ", ref, 72)
+    hf = binding.HeaderFields(n, 2, 32, 3, 1, 0, 70, 70, io, so)
+    h = (ctypes.c_uint8 * 256)()
+    binding.check(binding.lib().xsi_hip_make_header(ctypes.byref(hf), h))
+    assert bytes(h) == ref[:256]
+
+
+def test_encode_bound_covers_oracle_output():
+    from oracle import oracle
+    for n_haps, n_lines, bl, thr, seed in ((200, 300, 64, 0, 1), (5008, 600, 256, 5, 2), (5008, 300, 64, 2000, 3)):
+        bits = synth.synth_bits(seed, 0, n_lines, n_haps)
+        w = oracle.Writer(n_haps // 2, bl, thr, 1)
+        w.append_rows(synth.bits_to_gt(bits, 1), 2)
+        data = w.finalize(2)
+        io = struct.unpack_from("<Q", data, 72)[0]
+        p = binding.EncodeParams(n_haps // 2, bl, thr, 1, 0, 0)
+        assert binding.lib().xsi_hip_encode_bound(ctypes.byref(p), n_lines, n_lines) >= io - 256
+
+
+def test_synth_generator_is_frozen():
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "synth_manifest.json")))
+    for name in ("h20_l64", "h200_l700", "h5008_l3000"):
+        m = man[name]
+        bits = synth.synth_bits(m["seed"], m["first_line"], m["n_lines"], m["n_haps"])
+        assert hashlib.sha256(bits.tobytes()).hexdigest() == m["bits_sha256"]
+
+
+def test_oracle_matches_synth_manifest():
+    from oracle import oracle
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "synth_manifest.json")))
+    for name in ("h20_l64", "h200_l700", "h5008_l3000"):
+        m = man[name]
+        bits = synth.synth_bits(m["seed"], m["first_line"], m["n_lines"], m["n_haps"])
+        w = oracle.Writer(m["n_haps"] // 2, m["block_len"], m["mac_thr"], 1)
+        w.append_rows(synth.bits_to_gt(bits, 1), 2)
+        data = w.finalize(2)
+        assert len(data) == m["size"] and hashlib.sha256(data).hexdigest() == m["sha256"]
+
+
+def test_pack_unpack_rows():
+    rng = np.random.default_rng(0)
+    b = (rng.random((7, 5008)) < 0.3).astype(np.uint8)
+    st = synth.row_stride_bytes(5008)
+    assert st == 640 and st % 128 == 0
+    p = synth.pack_rows(b, st)
+    assert np.array_equal(synth.unpack_rows(p, 5008), b)
+    assert p[:, 626:].sum() == 0
+
+
+def test_shard_blocks_partition():
+    for nb in (1, 7, 123, 1221):
+        for w in (1, 2, 3, 8):
+            seen = []
+            for r in range(w):
+                lo, hi = xdist.shard_blocks(nb, w, r)
+                seen.extend(range(lo, hi))
+            assert seen == list(range(nb))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, n_haps, n_lines, bl, thr, q):
+    import torch
+    import torch.distributed as tdist
+    from oracle import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    n_blocks = (n_lines + bl - 1) // bl
+    lo, hi = xdist.shard_blocks(n_blocks, world, rank)
+    l0, l1 = lo * bl, min(hi * bl, n_lines)
+    # this rank's blocks, produced by the oracle standing in for the GPU encoder
+    bits = synth.synth_bits(5, l0, l1 - l0, n_haps)
+    w = oracle.Writer(n_haps // 2, bl, thr, 1)
+    w.append_rows(synth.bits_to_gt(bits, 1), 2)
+    data = w.finalize(2)
+    io, so = struct.unpack_from("<QQ", data, 72)
+    offs = np.frombuffer(data, dtype="<u8", count=(so - io) // 8, offset=io).astype(np.int64) - 256
+    end = io
+    while end > 256 and (end - 256) % 4 == 0 and False:
+        end -= 1
+    # blocks region without the final pad-to-8 (each block already padded to 4)
+    last_len = None
+    region = np.frombuffer(data, dtype=np.uint8, count=io - 256, offset=256)
+    # strip the region's pad to 8: block sizes are multiples of 4, so at most 4 zero bytes were added
+    n_real = int(offs[-1]) + _block_len(data, 256 + int(offs[-1]))
+    region = region[:n_real]
+    got = xdist.gather_block_streams(torch.from_numpy(region.copy()), torch.from_numpy(offs.copy()), tdist)
+    if rank == 0:
+        q.put((got[0].numpy().tobytes(), got[1].numpy().tolist()))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def _block_len(data, off):
+    """Length of the block at file offset `off`, padded to 4 (walk its GT dictionary)."""
+    n = struct.unpack_from("<I", data, off + 4)[0]
+    gt = off + [struct.unpack_from("<II", data, off + 8 + 8 * i) for i in range(n)][0][1]
+    nk = struct.unpack_from("<I", data, gt + 4)[0]
+    d = dict(struct.unpack_from("<II", data, gt + 8 + 8 * i) for i in range(nk))
+    # bi-allelic, no side channels: the sparse matrix is last; walk it
+    p = gt + d[0x21]
+    n_bin = d[1]
+    is_wah = _wah_bits(data, gt + d[0x10], n_bin)
+    aet = 2 if struct.unpack_from("<Q", data, 112)[0] <= 65535 else 4
+    for k in range(n_bin):
+        if not is_wah[k]:
+            num = struct.unpack_from("<H" if aet == 2 else "<I", data, p)[0] & (0x7FFF if aet == 2 else 0x7FFFFFFF)
+            p += (1 + num) * aet
+    return ((p - off) + 3) // 4 * 4
+
+
+def _wah_bits(data, off, n):
+    from oracle import oracle
+    words = np.frombuffer(data, dtype="<u2", count=min((len(data) - off) // 2, n // 15 + 2), offset=off)
+    return oracle.wah_extract(words, n)[0]
+
+
+def test_two_rank_gather_reproduces_single_process_file():
+    import torch.multiprocessing as mp
+    from oracle import oracle
+    n_haps, n_lines, bl, thr = 200, 1000, 128, 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, n_haps, n_lines, bl, thr, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    region, offs = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    bits = synth.synth_bits(5, 0, n_lines, n_haps)
+    names = ["S%d" % i for i in range(n_haps // 2)]
+    w = oracle.Writer(n_haps // 2, bl, thr, 1, False, names)
+    w.append_rows(synth.bits_to_gt(bits, 1), 2)
+    ref = w.finalize(2)
+
+    def hdr(io, so):
+        hf = binding.HeaderFields(n_haps // 2, 2, bl, thr, 1, 0, n_lines, n_lines, io, so)
+        h = (ctypes.c_uint8 * 256)()
+        binding.check(binding.lib().xsi_hip_make_header(ctypes.byref(hf), h))
+        return bytes(h)
+
+    got = xdist.assemble_file(region, offs, hdr, names)
+    assert got == ref

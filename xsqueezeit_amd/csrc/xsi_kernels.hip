@@ -7,6 +7,9 @@
 // Reference behaviour restated per kernel (paths relative to the reference tree).
 #include "xsi_kernels.hpp"
 
+#include <cstdlib>
+#include <type_traits>
+
 #include "xsi_device.hpp"
 
 namespace xsi {
@@ -205,19 +208,211 @@ struct ChainArgs {
 
 constexpr int CHAIN_RMAX = 4;
 
+// 16-lane inclusive prefix sum with DPP row shifts (v_add_u32_dpp row_shr:1/2/4/8, bound_ctrl:0).
+__device__ __forceinline__ uint32_t row16_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    return v;
+}
+
+// v_writelane_b32 with a constant lane select: put a wave-uniform value into one lane of a VGPR
+// (no clang builtin exists).  The lane select is an inline constant, so the VALU-writes-SGPR ->
+// lane-select hazard does not arise; the SGPR data operand is interlocked like any VALU source.
+template <int LANE>
+__device__ __forceinline__ uint32_t write_lane(uint32_t vdst, uint32_t sval) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(vdst) : "s"(sval), "n"(LANE));
+    return vdst;
+}
+
+// Per-lane key bits of up to 64 chunks, kept as two 32-bit halves so every access is one VALU op.
+template <int E>
+struct KeyBits {
+    uint32_t lo = 0, hi = 0;
+    template <int e>
+    __device__ __forceinline__ void set(uint32_t bit01) {
+        if (e < 32)
+            lo |= bit01 << (e & 31);
+        else
+            hi |= bit01 << (e & 31);
+    }
+    template <int e>
+    __device__ __forceinline__ uint32_t get() const {
+        return ((e < 32 ? lo : hi) >> (e & 31)) & 1u;
+    }
+};
+
+// compile-time loop
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Stable partition of `a` by the per-lane key bits; zc = zeros of my wave.  Shared by the fast
+// and the haploid paths.  `nvalid_total` = N for the haploid path (pads excluded), na otherwise.
+template <int T, int E, bool PADS_ARE_ONES>
+__device__ __forceinline__ void chain_scatter(uint16_t* a, uint32_t* wcnt, const uint32_t (&av)[E],
+                                              const KeyBits<E>& keys, uint32_t zc, uint32_t w, uint32_t lane,
+                                              uint32_t N, uint32_t na) {
+    constexpr int W = T / 64;
+    if (lane == 0) wcnt[w] = zc;
+    __syncthreads();
+    uint32_t sc = row16_scan_incl(lane < (uint32_t)W ? wcnt[lane] : 0u);
+    const uint32_t tz = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
+    uint32_t zb = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
+    uint32_t before = w * E * 64u;
+    if (!PADS_ARE_ONES && before > N) before = N;
+    uint32_t ob = tz + before - zb;  // destination of my wave's first one
+    static_for<0, E>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        const uint32_t base = (w * E + (uint32_t)e) * 64u;
+        if (base < (PADS_ARE_ONES ? na : N)) {
+            const uint32_t bit = keys.template get<e>();
+            uint64_t om = __ballot(bit);
+            uint32_t nv = 64u;
+            if (!PADS_ARE_ONES) {
+                nv = (N - base >= 64u) ? 64u : (N - base);
+                if (nv < 64u) om &= (1ull << nv) - 1ull;
+            }
+            const uint64_t zm = PADS_ARE_ONES ? ~om : (~om & (nv < 64u ? (1ull << nv) - 1ull : ~0ull));
+            const uint32_t zpre = mbcnt64(zm);
+            const uint32_t opre = PADS_ARE_ONES ? lane - zpre : mbcnt64(om);
+            const uint32_t dest = bit ? ob + opre : zb + zpre;
+            if (PADS_ARE_ONES || lane < nv) a[dest] = (uint16_t)av[e];
+            const uint32_t nz = (uint32_t)__popcll(zm);
+            zb += nz;
+            ob += (PADS_ARE_ONES ? 64u : nv) - nz;
+        }
+    });
+    __syncthreads();
+}
+
+// Fully haploid line (ngt == n_samples): gt_block.hpp:304-309 + pbwt_sort1
+// (internal_gt_record.hpp:55-58); accessor_internals_new.hpp:222-226, 548-571.  y (n_samples
+// bits) is ordered by a1 = even members of a, halved (interfaces.hpp:318-333); the partition key
+// of a[i] is the bit of sample a[i]/2.  Rare, kept out of line so it costs the fast path nothing.
+// LDS arrays are passed as byte offsets into the dynamic LDS segment: handing LDS pointers to an
+// out-of-line function makes hipcc (ROCm 7.2) cast them to flat and trip over its own null check.
+template <int T, int E, bool DECODE>
+__device__ __attribute__((noinline)) void chain_step_haploid(uint32_t a_off, uint32_t c_off, uint32_t xrow_off,
+                                                             uint32_t wcnt_off, uint32_t N, uint32_t na, uint32_t cw,
+                                                             uint32_t* orow, uint32_t orow_words) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* a = reinterpret_cast<uint16_t*>(smem + a_off);
+    const uint32_t* c = reinterpret_cast<const uint32_t*>(smem + c_off);
+    uint32_t* xrow = reinterpret_cast<uint32_t*>(smem + xrow_off);
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem + wcnt_off);
+    constexpr int W = T / 64;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    uint32_t* ev = wcnt + W;
+    uint32_t av[E];
+    KeyBits<E> evens, keys;
+    uint32_t ec = 0;
+    static_for<0, E>([&](auto ecn) {
+        constexpr int e = decltype(ecn)::value;
+        const uint32_t base = (w * E + (uint32_t)e) * 64u;
+        av[e] = 1;
+        if (base < N) {
+            const uint32_t idx = base + lane;
+            const uint32_t v = idx < N ? (uint32_t)a[idx] : 1u;
+            av[e] = v;
+            const uint32_t even = (idx < N && !(v & 1u)) ? 1u : 0u;
+            evens.template set<e>(even);
+            ec += (uint32_t)__popcll(__ballot(even));
+        }
+    });
+    if (lane == 0) ev[w] = ec;
+    __syncthreads();
+    uint32_t eb = 0;
+    for (uint32_t i = 0; i < w; ++i) eb += ev[i];
+    if (DECODE) {
+        // x[a1[p]] = y[p]
+        uint32_t ebw = eb;
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            const uint32_t base = (w * E + (uint32_t)e) * 64u;
+            if (base < N) {
+                const uint32_t even = evens.template get<e>();
+                const uint64_t evm = __ballot(even);
+                const uint32_t p = ebw + mbcnt64(evm);
+                if (even && ((c[p >> 5] >> (p & 31u)) & 1u)) {
+                    const uint32_t sidx = av[e] >> 1;
+                    atomicOr(&xrow[sidx >> 5], 1u << (sidx & 31u));
+                }
+                ebw += (uint32_t)__popcll(evm);
+            }
+        });
+        __syncthreads();
+    }
+    const uint32_t* keycol = DECODE ? xrow : c;
+    uint32_t zc = 0;
+    static_for<0, E>([&](auto ecn) {
+        constexpr int e = decltype(ecn)::value;
+        const uint32_t base = (w * E + (uint32_t)e) * 64u;
+        if (base < N) {
+            const bool valid = base + lane < N;
+            const uint32_t sidx = av[e] >> 1;
+            const uint32_t bit = valid ? ((keycol[sidx >> 5] >> (sidx & 31u)) & 1u) : 0u;
+            keys.template set<e>(bit);
+            const uint32_t nv = (N - base >= 64u) ? 64u : (N - base);
+            zc += nv - (uint32_t)__popcll(__ballot(bit));
+        }
+    });
+    if (DECODE) {
+        __syncthreads();  // every wave has read its keys from xrow
+    } else {
+        // y[p] = key of the p-th even member
+        uint32_t ebw = eb;
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            const uint32_t base = (w * E + (uint32_t)e) * 64u;
+            if (base < N) {
+                const uint32_t even = evens.template get<e>();
+                const uint64_t evm = __ballot(even);
+                const uint32_t p = ebw + mbcnt64(evm);
+                if (even && keys.template get<e>()) atomicOr(&xrow[p >> 5], 1u << (p & 31u));
+                ebw += (uint32_t)__popcll(evm);
+            }
+        });
+        __syncthreads();
+    }
+    // publish xrow (decode: x by sample; encode: y in a1 order), n_samples bits
+    const uint32_t nbits = N >> 1;
+    for (uint32_t i = tid; i < orow_words; i += T) {
+        uint32_t v = 0;
+        if (i < cw) {
+            v = xrow[i];
+            xrow[i] = 0;
+            const uint32_t b0 = i * 32u;
+            if (b0 + 32u > nbits) v &= (b0 >= nbits) ? 0u : ((1u << (nbits - b0)) - 1u);
+        }
+        orow[i] = v;
+    }
+    chain_scatter<T, E, false>(a, wcnt, av, keys, zc, w, lane, N, na);
+}
+
 template <int T, int E, bool DECODE>
 __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eblocks,
                                                  const DecBlock* __restrict__ dblocks, ChainArgs A) {
     constexpr int W = T / 64;
-    static_assert(E <= 64, "per-lane bitfields are 64 bits wide");
+    constexpr uint32_t NA = (uint32_t)T * E;  // capacity: N real members + (NA - N) padding members
+    constexpr uint32_t CW = NA / 32u;         // words per staged column
+    static_assert(E <= 64 && W <= 16, "per-lane bitfields are 64 bits wide; counts scanned in one DPP row");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t N = A.N, cw = A.cw;
-    const uint32_t na = (N + 63u) & ~63u;
+    const uint32_t N = A.N;
     uint16_t* a = reinterpret_cast<uint16_t*>(smem);
-    uint32_t* col = reinterpret_cast<uint32_t*>(smem + (((size_t)na * 2u + 15u) & ~(size_t)15u));
-    uint32_t* xrow = col + 2u * A.batch * cw;  // cw words (decode scatter target / haploid scratch)
-    uint32_t* wcnt = xrow + cw;                // 2*W words
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    uint32_t* col = reinterpret_cast<uint32_t*>(smem + (size_t)NA * 2u);
+    uint32_t* xrow = col + 2u * A.batch * CW;  // CW words (decode scatter target / haploid scratch)
+    uint32_t* wcnt = xrow + CW;                // 2*W words
+    uint32_t* linfo = wcnt + 2 * W;            // 3 x 16: binary line | haploid<<31, two batches ahead
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    // the wave index is uniform: telling the compiler so turns per-wave arithmetic into SALU
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 
     uint32_t wah_first, n_wah;
     if (DECODE) {
@@ -229,15 +424,30 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
     }
     if (n_wah == 0) return;
 
-    for (uint32_t i = tid; i < na; i += T) a[i] = (uint16_t)i;
-    for (uint32_t i = tid; i < cw; i += T) xrow[i] = 0;
+    for (uint32_t i = tid; i < NA; i += T) a[i] = (uint16_t)i;
+    for (uint32_t i = tid; i < CW; i += T) xrow[i] = 0;
 
     const uint32_t B = A.batch;
     const uint32_t cwp_mask = (1u << A.log2_cwp) - 1u;
     const uint32_t src_words = (N + 31u) >> 5;
+    const uint32_t n_batches = (n_wah + B - 1u) / B;
     uint32_t R[CHAIN_RMAX];
+    uint32_t Rinfo = 0;
 
-    auto load_batch = [&](uint32_t bt) {
+    // Nothing in the serial chain may wait on HBM.  Line ids (+ haploid flag) are fetched two
+    // batches ahead into an LDS ring; with them the bit columns are fetched one batch ahead into
+    // registers while the current batch is processed, then parked in LDS.
+    auto load_info = [&](uint32_t bt) {
+        Rinfo = 0;
+        if (tid < B && bt < n_batches && bt * B + tid < n_wah) {
+            const uint32_t line = A.wah_lines[wah_first + bt * B + tid];
+            Rinfo = line | ((A.kind && (A.kind[line] & KIND_HAPLOID)) ? 0x80000000u : 0u);
+        }
+    };
+    auto store_info = [&](uint32_t bt) {
+        if (tid < B) linfo[(bt % 3u) * 16u + tid] = Rinfo;
+    };
+    auto load_cols = [&](uint32_t bt) {
 #pragma unroll
         for (int r = 0; r < CHAIN_RMAX; ++r) {
             const uint32_t idx = (uint32_t)r * T + tid;
@@ -245,228 +455,130 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
             const uint32_t j = bt * B + jj;
             uint32_t v = 0;
             if (jj < B && j < n_wah && wi < src_words) {
-                const uint32_t rank = wah_first + j;
-                const size_t row = DECODE ? (size_t)rank : (size_t)A.wah_lines[rank];
+                const size_t row = DECODE ? (size_t)(wah_first + j) : (size_t)(linfo[(bt % 3u) * 16u + jj] & 0x7FFFFFFFu);
                 v = A.src[row * A.src_stride_w + wi];
             }
             R[r] = v;
         }
     };
-    auto store_batch = [&](uint32_t buf) {
+    auto store_cols = [&](uint32_t buf) {
 #pragma unroll
         for (int r = 0; r < CHAIN_RMAX; ++r) {
             const uint32_t idx = (uint32_t)r * T + tid;
             const uint32_t jj = idx >> A.log2_cwp, wi = idx & cwp_mask;
-            if (jj < B && wi < cw) {
-                // positions [N, na) of `a` hold padding members whose key is always 1, so they stay
+            if (jj < B && wi < CW) {
+                // positions [N, NA) of `a` hold padding members whose key is always 1, so they stay
                 // behind every real member (stable partition) and never need a validity test
                 uint32_t v = R[r];
                 const uint32_t b0 = wi * 32u;
                 if (b0 + 32u > N) v |= (b0 >= N) ? 0xFFFFFFFFu : (0xFFFFFFFFu << (N - b0));
-                col[(buf * B + jj) * cw + wi] = v;
+                col[(buf * B + jj) * CW + wi] = v;
             }
-        }
-    };
-    // stable partition of `a` by the per-lane key bits (bit e of `keys` = key of my element in
-    // chunk e); av[] holds my elements, zc my wave's zero count.  Two barriers.
-    auto partition = [&](const uint32_t (&av)[E], uint64_t keys, uint32_t zc) {
-        if (lane == 0) wcnt[w] = zc;
-        __syncthreads();
-        uint32_t zb = 0, tz = 0;
-#pragma unroll
-        for (int i = 0; i < W; ++i) {
-            const uint32_t cz = wcnt[i];
-            tz += cz;
-            if ((uint32_t)i < w) zb += cz;
-        }
-        const uint32_t before = (w * E * 64u < N) ? w * E * 64u : N;
-        uint32_t ob = before - zb;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint32_t base = (w * E + (uint32_t)e) * 64u;
-            if (base < N) {
-                const bool valid = base + lane < N;
-                const uint32_t bit = (uint32_t)(keys >> e) & 1u;
-                const uint64_t vm = (N - base >= 64u) ? ~0ull : ((1ull << (N - base)) - 1ull);
-                const uint64_t om = __ballot(bit) & vm, zm = ~om & vm;
-                const uint32_t dest = bit ? tz + ob + mbcnt64(om) : zb + mbcnt64(zm);
-                if (valid) a[dest] = (uint16_t)av[e];
-                zb += (uint32_t)__popcll(zm);
-                ob += (uint32_t)__popcll(om);
-            }
-        }
-        __syncthreads();
-    };
-    auto flush_xrow = [&](uint32_t* orow, uint32_t nbits) {
-        for (uint32_t i = tid; i < A.dst_stride_w; i += T) {
-            uint32_t v = 0;
-            if (i < cw) {
-                v = xrow[i];
-                xrow[i] = 0;
-                const uint32_t b0 = i * 32u;
-                if (b0 + 32u > nbits) v &= (b0 >= nbits) ? 0u : ((1u << (nbits - b0)) - 1u);
-            }
-            orow[i] = v;
         }
     };
 
-    load_batch(0);
-    store_batch(0);
+    load_info(0);
+    store_info(0);
+    load_info(1);
+    store_info(1);
+    __syncthreads();
+    load_cols(0);
+    store_cols(0);
     __syncthreads();
 
-    const uint32_t n_batches = (n_wah + B - 1u) / B;
+    uint16_t* aw = a + w * (E * 64u) + lane;  // my element of chunk e is aw[e*64]
     for (uint32_t bt = 0; bt < n_batches; ++bt) {
         const bool more = bt + 1u < n_batches;
-        if (more) load_batch(bt + 1u);
+        load_info(bt + 2u);
+        if (more) load_cols(bt + 1u);
         const uint32_t jn = (n_wah - bt * B) < B ? (n_wah - bt * B) : B;
         for (uint32_t jj = 0; jj < jn; ++jj) {
             const uint32_t rank = wah_first + bt * B + jj;
-            const uint32_t* c = col + ((bt & 1u) * B + jj) * cw;
-            const uint32_t line = A.wah_lines[rank];
-            const bool hap = A.kind && (A.kind[line] & KIND_HAPLOID);
-            uint32_t av[E];
-            uint64_t keys = 0;
-            uint32_t zc = 0;
-            if (!hap) {
-                uint64_t mine = 0;  // encode: lane e collects chunk e's 64 permuted bits
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const uint32_t base = (w * E + (uint32_t)e) * 64u;
-                    av[e] = 0;
-                    if (base < na) {
-                        const uint32_t v = (uint32_t)a[base + lane];
-                        av[e] = v;
-                        uint64_t m;
-                        if (DECODE) {
-                            // y is already in permuted order: the chunk's 64 key bits are one 64-bit word
-                            const uint32_t lo = __builtin_amdgcn_readfirstlane(c[(base >> 5)]);
-                            const uint32_t hi = __builtin_amdgcn_readfirstlane(c[(base >> 5) + 1u]);
-                            m = ((uint64_t)hi << 32) | lo;
-                            if ((m >> lane) & 1ull) atomicOr(&xrow[v >> 5], 1u << (v & 31u));
-                        } else {
-                            m = __ballot((c[v >> 5] >> (v & 31u)) & 1u);
-                            if (lane == (uint32_t)e) mine = m;
-                        }
-                        keys |= ((m >> lane) & 1ull) << e;
-                        zc += (uint32_t)__popcll(~m);
-                    }
-                }
-                if (!DECODE) {
-                    // 8*E contiguous bytes per wave; bits at or beyond N are padding (ignored downstream)
-                    const uint32_t cg = w * E + lane;
-                    if (lane < (uint32_t)E && cg * 64u < na) {
-                        uint64_t* yr = reinterpret_cast<uint64_t*>(A.dst + (size_t)rank * A.dst_stride_w);
-                        yr[cg] = mine;
-                    }
-                }
-                if (lane == 0) wcnt[w] = zc;
-                __syncthreads();
-                if (DECODE) flush_xrow(A.dst + (size_t)(line - A.out_row_base) * A.dst_stride_w, N);
-                uint32_t zb = 0, tz = 0;
-#pragma unroll
-                for (int i = 0; i < W; ++i) {
-                    const uint32_t cz = wcnt[i];
-                    tz += cz;
-                    if ((uint32_t)i < w) zb += cz;
-                }
-                uint32_t ob = w * E * 64u - zb;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const uint32_t base = (w * E + (uint32_t)e) * 64u;
-                    if (base < na) {
-                        const uint32_t bit = (uint32_t)(keys >> e) & 1u;
-                        const uint64_t om = __ballot(bit), zm = ~om;
-                        const uint32_t dest = bit ? tz + ob + mbcnt64(om) : zb + mbcnt64(zm);
-                        a[dest] = (uint16_t)av[e];
-                        zb += (uint32_t)__popcll(zm);
-                        ob += (uint32_t)__popcll(om);
-                    }
-                }
-                __syncthreads();
-            } else {
-                // ---- fully haploid line (ngt == n_samples): gt_block.hpp:304-309 + pbwt_sort1;
-                //      accessor_internals_new.hpp:222-226, 548-571.  Rare, so written for clarity.
-                //      y (n_samples bits) is in the order a1 = even members of a, halved
-                //      (interfaces.hpp:318-333); the partition key of a[i] is the bit of sample a[i]/2.
-                uint32_t* ev = wcnt + W;  // per-wave count of even members
-                uint64_t evens = 0;       // bit e: my element of chunk e is even
-                uint32_t ec = 0;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const uint32_t base = (w * E + (uint32_t)e) * 64u;
-                    av[e] = 1;
-                    if (base < N) {
-                        const uint32_t idx = base + lane;
-                        const uint32_t v = idx < N ? (uint32_t)a[idx] : 1u;
-                        av[e] = v;
-                        const uint32_t even = (idx < N && !(v & 1u)) ? 1u : 0u;
-                        evens |= (uint64_t)even << e;
-                        ec += (uint32_t)__popcll(__ballot(even));
-                    }
-                }
-                if (lane == 0) ev[w] = ec;
-                __syncthreads();
-                uint32_t eb = 0;
-#pragma unroll
-                for (int i = 0; i < W; ++i)
-                    if ((uint32_t)i < w) eb += ev[i];
-                if (DECODE) {
-                    // x[a1[p]] = y[p]
-                    uint32_t ebw = eb;
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const uint32_t base = (w * E + (uint32_t)e) * 64u;
-                        if (base < N) {
-                            const uint32_t even = (uint32_t)(evens >> e) & 1u;
-                            const uint64_t evm = __ballot(even);
-                            const uint32_t p = ebw + mbcnt64(evm);
-                            if (even && ((c[p >> 5] >> (p & 31u)) & 1u)) {
-                                const uint32_t sidx = av[e] >> 1;
-                                atomicOr(&xrow[sidx >> 5], 1u << (sidx & 31u));
-                            }
-                            ebw += (uint32_t)__popcll(evm);
-                        }
-                    }
-                    __syncthreads();
-                }
-                const uint32_t* keycol = DECODE ? xrow : c;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const uint32_t base = (w * E + (uint32_t)e) * 64u;
-                    if (base < N) {
-                        const bool valid = base + lane < N;
-                        const uint32_t sidx = av[e] >> 1;
-                        const uint32_t bit = valid ? ((keycol[sidx >> 5] >> (sidx & 31u)) & 1u) : 0u;
-                        const uint64_t vm = (N - base >= 64u) ? ~0ull : ((1ull << (N - base)) - 1ull);
-                        keys |= (uint64_t)bit << e;
-                        zc += (uint32_t)__popcll(~__ballot(bit) & vm);
-                    }
-                }
-                if (DECODE) {
-                    // every wave has read its keys from xrow: publish the row, then partition
-                    __syncthreads();
-                    flush_xrow(A.dst + (size_t)(line - A.out_row_base) * A.dst_stride_w, N >> 1);
-                } else {
-                    // y[p] = key of the p-th even member
-                    uint32_t ebw = eb;
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const uint32_t base = (w * E + (uint32_t)e) * 64u;
-                        if (base < N) {
-                            const uint32_t even = (uint32_t)(evens >> e) & 1u;
-                            const uint64_t evm = __ballot(even);
-                            const uint32_t p = ebw + mbcnt64(evm);
-                            if (even && ((keys >> e) & 1ull)) atomicOr(&xrow[p >> 5], 1u << (p & 31u));
-                            ebw += (uint32_t)__popcll(evm);
-                        }
-                    }
-                    __syncthreads();
-                    flush_xrow(A.dst + (size_t)rank * A.dst_stride_w, N >> 1);
-                }
-                partition(av, keys, zc);
+            const uint32_t* c = col + ((bt & 1u) * B + jj) * CW;
+            const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)linfo[(bt % 3u) * 16u + jj]);
+            const uint32_t line = info & 0x7FFFFFFFu;
+            if (info >> 31) {
+                uint32_t* orow = DECODE ? A.dst + (size_t)(line - A.out_row_base) * A.dst_stride_w
+                                        : A.dst + (size_t)rank * A.dst_stride_w;
+                chain_step_haploid<T, E, DECODE>(0u, (uint32_t)((const unsigned char*)c - smem),
+                                                 (uint32_t)((unsigned char*)xrow - smem),
+                                                 (uint32_t)((unsigned char*)wcnt - smem), N, NA, CW, orow,
+                                                 A.dst_stride_w);
+                continue;
             }
+            uint32_t av[E];
+            KeyBits<E> keys;
+            uint32_t ones = 0;
+            uint32_t mine_lo = 0, mine_hi = 0;  // encode: lane e collects chunk e's 64 permuted bits
+            static_for<0, E>([&](auto ecn) {
+                constexpr int e = decltype(ecn)::value;
+                av[e] = (uint32_t)aw[e * 64];
+            });
+            static_for<0, E>([&](auto ecn) {
+                constexpr int e = decltype(ecn)::value;
+                const uint32_t v = av[e];
+                uint32_t bit;
+                if (DECODE) {
+                    // y is already in permuted order: the chunk's 64 key bits are one 64-bit word
+                    const uint32_t cgw = (w * E + (uint32_t)e) * 2u;
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)c[cgw]);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)c[cgw + 1u]);
+                    bit = (uint32_t)(((lane < 32u ? lo : hi) >> (lane & 31u)) & 1u);
+                    if (bit) atomicOr(&xrow[v >> 5], 1u << (v & 31u));
+                    ones += (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
+                } else {
+                    bit = (c[v >> 5] >> (v & 31u)) & 1u;
+                    const uint64_t m = __ballot(bit);
+                    if (lane == (uint32_t)e) {
+                        mine_lo = (uint32_t)m;
+                        mine_hi = (uint32_t)(m >> 32);
+                    }
+                    ones += (uint32_t)__popcll(m);
+                }
+                keys.template set<e>(bit);
+            });
+            if (!DECODE) {
+                // 8*E contiguous bytes per wave; bits at or beyond N are padding (ignored downstream)
+                const uint32_t cg = w * E + lane;
+                if (lane < (uint32_t)E && cg < A.dst_stride_w / 2u) {
+                    uint2* yr = reinterpret_cast<uint2*>(A.dst + (size_t)rank * A.dst_stride_w);
+                    yr[cg] = make_uint2(mine_lo, mine_hi);
+                }
+            }
+            if (lane == 0) wcnt[w] = E * 64u - ones;
+            __syncthreads();
+            if (DECODE) {
+                uint32_t* orow = A.dst + (size_t)(line - A.out_row_base) * A.dst_stride_w;
+                for (uint32_t i = tid; i < A.dst_stride_w; i += T) {
+                    uint32_t v = 0;
+                    if (i < CW) {
+                        v = xrow[i];
+                        xrow[i] = 0;
+                        const uint32_t b0 = i * 32u;
+                        if (b0 + 32u > N) v &= (b0 >= N) ? 0u : ((1u << (N - b0)) - 1u);
+                    }
+                    orow[i] = v;
+                }
+            }
+            uint32_t sc = row16_scan_incl(lane < (uint32_t)W ? wcnt[lane] : 0u);
+            const uint32_t tz = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
+            uint32_t zb = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
+            uint32_t ob = tz + w * (E * 64u) - zb;  // destination of my wave's first one
+            static_for<0, E>([&](auto ecn) {
+                constexpr int e = decltype(ecn)::value;
+                const uint32_t bit = keys.template get<e>();
+                const uint64_t om = __ballot(bit);
+                const uint32_t zpre = mbcnt64(~om);
+                const uint32_t dest = bit ? ob + (lane - zpre) : zb + zpre;
+                a[dest] = (uint16_t)av[e];
+                const uint32_t no = (uint32_t)__popcll(om);
+                zb += 64u - no;
+                ob += no;
+            });
+            __syncthreads();
         }
-        if (more) store_batch((bt + 1u) & 1u);
+        if (more) store_cols((bt + 1u) & 1u);
+        store_info(bt + 2u);
         __syncthreads();
     }
 }
@@ -618,12 +730,15 @@ static uint32_t next_pow2_log2(uint32_t v) {
     return l;
 }
 
+// E values the LDS chain kernel is instantiated for (T = 1024); N <= 1024*E
+static const int k_chain_E[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64};
+
 ChainGeom chain_geometry(uint32_t N, bool decode) {
     (void)decode;
     ChainGeom g{};
     g.in_lds = N <= 65536u;
-    const uint32_t cw = (((N + 31u) >> 5) + 1u) & ~1u;
     if (!g.in_lds) {
+        const uint32_t cw = (((N + 31u) >> 5) + 1u) & ~1u;
         g.threads = 1024;
         g.chunks = 0;
         g.batch = 1;
@@ -639,21 +754,26 @@ ChainGeom chain_geometry(uint32_t N, bool decode) {
         E = 4;
     } else {
         T = 1024;
-        E = 2;
-        while ((uint32_t)(T * E) < N) E *= 2;
+        E = 64;
+        for (int e : k_chain_E)
+            if ((uint32_t)(T * e) >= N) {
+                E = e;
+                break;
+            }
     }
-    const uint32_t na = (N + 63u) & ~63u;
-    const uint32_t a_bytes = (na * 2u + 15u) & ~15u;
+    const uint32_t NA = (uint32_t)T * E;
+    const uint32_t cw = NA / 32u;
     const uint32_t cwp = 1u << next_pow2_log2(cw);
     uint32_t B = (uint32_t)(CHAIN_RMAX * T) / cwp;
     if (B > 16u) B = 16u;
     if (B < 1u) B = 1u;
     const uint32_t lds_max = 160u * 1024u;
-    while (B > 1u && a_bytes + (2u * B * cw + cw + 64u) * 4u > lds_max) B >>= 1;
+    auto need = [&](uint32_t b) { return NA * 2u + (2u * b * cw + cw + 2u * 16u + 48u) * 4u; };
+    while (B > 1u && need(B) > lds_max) B >>= 1;
     g.threads = T;
     g.chunks = E;
     g.batch = B;
-    g.lds_bytes = a_bytes + (2u * B * cw + cw + 64u) * 4u;
+    g.lds_bytes = need(B);
     return g;
 }
 
@@ -662,7 +782,7 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
                                ChainArgs A, uint32_t* scratch_a) {
     if (!n_blocks) return hipSuccess;
     const ChainGeom g = chain_geometry(A.N, DECODE);
-    A.cw = (((A.N + 31u) >> 5) + 1u) & ~1u;
+    A.cw = g.in_lds ? (uint32_t)(g.threads * g.chunks) / 32u : ((((A.N + 31u) >> 5) + 1u) & ~1u);
     A.log2_cwp = next_pow2_log2(A.cw);
     A.batch = g.batch;
     if (!g.in_lds) {
@@ -684,10 +804,20 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
     XSI_CHAIN_CASE(256, 1)
     XSI_CHAIN_CASE(256, 4)
     XSI_CHAIN_CASE(1024, 2)
+    XSI_CHAIN_CASE(1024, 3)
     XSI_CHAIN_CASE(1024, 4)
+    XSI_CHAIN_CASE(1024, 5)
+    XSI_CHAIN_CASE(1024, 6)
+    XSI_CHAIN_CASE(1024, 7)
     XSI_CHAIN_CASE(1024, 8)
+    XSI_CHAIN_CASE(1024, 10)
+    XSI_CHAIN_CASE(1024, 12)
     XSI_CHAIN_CASE(1024, 16)
+    XSI_CHAIN_CASE(1024, 20)
+    XSI_CHAIN_CASE(1024, 24)
     XSI_CHAIN_CASE(1024, 32)
+    XSI_CHAIN_CASE(1024, 40)
+    XSI_CHAIN_CASE(1024, 48)
     XSI_CHAIN_CASE(1024, 64)
 #undef XSI_CHAIN_CASE
     return hipErrorInvalidValue;
