@@ -549,7 +549,9 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
             b.off_line_haploid != VAL_UNDEFINED)
             P->has_side = true;
     L.y_stride64 = (L.N + 63u) / 64u;
-    WS(L.yrows, "dec.yrows", 8ull * L.y_stride64 * (size_t)(P->n_wah ? P->n_wah : 1));
+    L.yp_stride = L.y_stride64 * 2u;
+    WS(L.yp, "dec.yp", 8ull * L.yp_stride * (size_t)(P->n_wah ? P->n_wah : 1));
+    WS(L.wah_z, "dec.wah_z", 4ull * (P->n_wah ? P->n_wah : 1) + 64);
     return XSI_OK;
 }
 
@@ -560,14 +562,17 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
     const uint8_t* f = (const uint8_t*)d_file;
     DecLines& L = P.L;
     uint32_t* scratch_a = nullptr;
-    if (!chain_geometry(L.N, true).in_lds)
+    bool any_haploid = false;
+    for (auto& b : P.blocks_h)
+        if (b.off_line_haploid != VAL_UNDEFINED) any_haploid = true;
+    if (any_haploid && !chain_geometry(L.N, true).in_lds)
         WS(scratch_a, "chain.a", 4ull * 2ull * (((size_t)L.N + 63u) & ~(size_t)63u) * P.n_blocks);
     stage_mark(ctx, XSI_ST_DEC_BOUND);
     HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
     stage_mark(ctx, XSI_ST_DEC_EXPAND);
     HIP_TRY(launch_wah_expand(s, f, P.d_blocks, L, P.n_wah, P.d_totals));
     stage_mark(ctx, XSI_ST_CHAIN_DEC);
-    HIP_TRY(launch_chain_decode(s, P.d_blocks, P.n_blocks, L, out, stride_w, scratch_a));
+    HIP_TRY(launch_chain_decode(s, P.d_blocks, P.n_blocks, L, out, stride_w, scratch_a, any_haploid));
     stage_mark(ctx, XSI_ST_DEC_SPARSE);
     HIP_TRY(launch_sparse_walk(s, f, P.d_blocks, P.n_blocks, L));
     HIP_TRY(launch_sparse_fill(s, f, P.d_blocks, L, P.n_sparse, P.d_totals, out, stride_w, apply_negation));

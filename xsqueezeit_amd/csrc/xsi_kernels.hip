@@ -197,6 +197,7 @@ struct ChainArgs {
     const uint8_t* kind;         // per binary line
     const uint32_t* src;         // encode: planes (by binary line); decode: yrows as uint32 (by rank)
     uint32_t src_stride_w;
+    uint32_t src_elem_shift;     // 0: src rows are plain words; 1: {word, prefix} pairs (decode)
     uint32_t* dst;               // encode: yrows as uint32 (by rank); decode: output rows (by binary line)
     uint32_t dst_stride_w;
     uint32_t N;
@@ -204,6 +205,7 @@ struct ChainArgs {
     uint32_t log2_cwp;           // log2 of next pow2 >= cw
     uint32_t batch;              // columns per prefetch batch
     uint32_t out_row_base;       // decode: first output row of the batch (binary line numbering offset)
+    uint32_t only_haploid_blocks;// decode: skip blocks the element-major kernel already handled
 };
 
 constexpr int CHAIN_RMAX = 4;
@@ -416,6 +418,8 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
 
     uint32_t wah_first, n_wah;
     if (DECODE) {
+        if (dblocks[blockIdx.x].error) return;
+        if (A.only_haploid_blocks && dblocks[blockIdx.x].off_line_haploid == VAL_UNDEFINED) return;
         wah_first = dblocks[blockIdx.x].wah_first;
         n_wah = dblocks[blockIdx.x].n_wah;
     } else {
@@ -456,7 +460,7 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
             uint32_t v = 0;
             if (jj < B && j < n_wah && wi < src_words) {
                 const size_t row = DECODE ? (size_t)(wah_first + j) : (size_t)(linfo[(bt % 3u) * 16u + jj] & 0x7FFFFFFFu);
-                v = A.src[row * A.src_stride_w + wi];
+                v = A.src[row * A.src_stride_w + ((size_t)wi << A.src_elem_shift)];
             }
             R[r] = v;
         }
@@ -506,7 +510,11 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
                                                  A.dst_stride_w);
                 continue;
             }
+            // ---- pass 1: keys of my E chunks.  For E <= 8 the E ballot masks stay in SGPRs for the
+            //      scatter pass; for larger E they would spill, so a per-lane bitfield carries the keys.
+            constexpr bool MASKS_IN_SGPR = (E <= 8);
             uint32_t av[E];
+            uint64_t ms[MASKS_IN_SGPR ? E : 1];
             KeyBits<E> keys;
             uint32_t ones = 0;
             uint32_t mine_lo = 0, mine_hi = 0;  // encode: lane e collects chunk e's 64 permuted bits
@@ -517,25 +525,28 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
             static_for<0, E>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
                 const uint32_t v = av[e];
-                uint32_t bit;
+                uint64_t m;
                 if (DECODE) {
                     // y is already in permuted order: the chunk's 64 key bits are one 64-bit word
                     const uint32_t cgw = (w * E + (uint32_t)e) * 2u;
                     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)c[cgw]);
                     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)c[cgw + 1u]);
-                    bit = (uint32_t)(((lane < 32u ? lo : hi) >> (lane & 31u)) & 1u);
+                    m = ((uint64_t)hi << 32) | lo;
+                    const uint32_t bit = __builtin_amdgcn_ubfe(lane < 32u ? lo : hi, lane, 1u);
                     if (bit) atomicOr(&xrow[v >> 5], 1u << (v & 31u));
-                    ones += (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
+                    if (!MASKS_IN_SGPR) keys.template set<e>(bit);
                 } else {
-                    bit = (c[v >> 5] >> (v & 31u)) & 1u;
-                    const uint64_t m = __ballot(bit);
+                    // v_bfe_u32 uses only the low 5 bits of its offset operand: no explicit v & 31
+                    const uint32_t bit = __builtin_amdgcn_ubfe(c[v >> 5], v, 1u);
+                    m = __ballot(bit != 0u);
                     if (lane == (uint32_t)e) {
                         mine_lo = (uint32_t)m;
                         mine_hi = (uint32_t)(m >> 32);
                     }
-                    ones += (uint32_t)__popcll(m);
+                    if (!MASKS_IN_SGPR) keys.template set<e>(bit);
                 }
-                keys.template set<e>(bit);
+                if (MASKS_IN_SGPR) ms[e] = m;
+                ones += (uint32_t)__popcll(m);
             });
             if (!DECODE) {
                 // 8*E contiguous bytes per wave; bits at or beyond N are padding (ignored downstream)
@@ -560,20 +571,27 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
                     orow[i] = v;
                 }
             }
+            // ---- pass 2: stable scatter.  Destinations are formed directly as LDS byte addresses.
             uint32_t sc = row16_scan_incl(lane < (uint32_t)W ? wcnt[lane] : 0u);
             const uint32_t tz = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
-            uint32_t zb = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
-            uint32_t ob = tz + w * (E * 64u) - zb;  // destination of my wave's first one
+            uint32_t zb2 = (w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u) * 2u;
+            uint32_t ob2 = (tz + w * (E * 64u)) * 2u - zb2;  // byte address of my wave's first one
+            unsigned char* abytes = reinterpret_cast<unsigned char*>(a);
             static_for<0, E>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
-                const uint32_t bit = keys.template get<e>();
-                const uint64_t om = __ballot(bit);
+                uint64_t om;
+                if (MASKS_IN_SGPR)
+                    om = ms[e];
+                else
+                    om = __ballot(keys.template get<e>() != 0u);
                 const uint32_t zpre = mbcnt64(~om);
-                const uint32_t dest = bit ? ob + (lane - zpre) : zb + zpre;
-                a[dest] = (uint16_t)av[e];
-                const uint32_t no = (uint32_t)__popcll(om);
-                zb += 64u - no;
-                ob += no;
+                const uint32_t d0 = zb2 + (zpre << 1);
+                const uint32_t d1 = ob2 + ((lane - zpre) << 1);
+                const uint32_t addr = ((om >> lane) & 1ull) ? d1 : d0;
+                *reinterpret_cast<uint16_t*>(abytes + addr) = (uint16_t)av[e];
+                const uint32_t no2 = (uint32_t)__popcll(om) * 2u;
+                zb2 += 128u - no2;
+                ob2 += no2;
             });
             __syncthreads();
         }
@@ -600,6 +618,8 @@ __global__ void __launch_bounds__(1024) k_chain_global(const EncBlock* __restric
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     uint32_t wah_first, n_wah;
     if (DECODE) {
+        if (dblocks[blockIdx.x].error) return;
+        if (A.only_haploid_blocks && dblocks[blockIdx.x].off_line_haploid == VAL_UNDEFINED) return;
         wah_first = dblocks[blockIdx.x].wah_first;
         n_wah = dblocks[blockIdx.x].n_wah;
     } else {
@@ -622,7 +642,7 @@ __global__ void __launch_bounds__(1024) k_chain_global(const EncBlock* __restric
         const uint32_t line = A.wah_lines[rank];
         const bool hap = A.kind && (A.kind[line] & KIND_HAPLOID);
         const uint32_t* srow = A.src + (DECODE ? (size_t)rank : (size_t)line) * A.src_stride_w;
-        for (uint32_t i = tid; i < cw; i += T) col[i] = i < src_words ? srow[i] : 0u;
+        for (uint32_t i = tid; i < cw; i += T) col[i] = i < src_words ? srow[(size_t)i << A.src_elem_shift] : 0u;
         __syncthreads();
         const uint32_t* ain = (j & 1u) ? a1 : a0;
         uint32_t* aout = (j & 1u) ? a0 : a1;
@@ -823,6 +843,248 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
     return hipErrorInvalidValue;
 }
 
+// ------------------------------------------------------------------------------------------
+// PBWT chain, decode side, element-major ("rank tracking").
+//
+// The position-major kernel above moves the prefix array `a` around and needs two workgroup
+// barriers per line.  Decode does not need `a` at all.  Let r_k(h) be the position of haplotype
+// h in a_k (the inverse permutation, r_0(h) = h).  Then, with y_k the stored permuted row,
+//     x_k(h)     = y_k[r_k(h)]                                   (accessor_internals_new.hpp:228-230)
+//     r_{k+1}(h) = x_k(h) ? Z_k + ones_k(r_k(h)) : r_k(h) - ones_k(r_k(h))      (gt_block.hpp:124-136)
+// where ones_k(r) = number of set bits of y_k before position r and Z_k = zeros of y_k: the stable
+// partition moves a zero at position r to (zeros before r) and a one to Z + (ones before r).
+// Every haplotype's rank evolves on its own from read-only data (y_k plus a per-32-bit prefix
+// popcount, both produced by k_wah_expand), so there is NO communication between threads: no
+// barrier per line, no scatter, no atomics, and the haplotypes of one block can be split over
+// several workgroups to fill all 256 CUs even when there are fewer blocks than CUs.
+// 64 consecutive haplotypes live in one wave chunk, so their decoded bits are one ballot = one
+// 64-bit word of the natural-order output row.
+// Blocks that contain fully haploid lines keep the position-major kernel (a haploid line orders
+// y by the even members of `a`, which needs the permutation itself).
+// ------------------------------------------------------------------------------------------
+struct RankArgs {
+    const DecBlock* blocks;
+    const uint32_t* wah_lines;  // [rank] binary line
+    const uint2* yp;            // [rank][yp_stride] {bits, ones before}
+    uint32_t yp_stride;
+    const uint32_t* wah_z;      // [rank] zeros of the line
+    uint32_t* out;              // output rows by binary line
+    uint32_t out_stride_w;
+    uint32_t N;
+    uint32_t batch;             // lines staged per LDS batch
+    uint32_t log2_cwp;
+};
+
+constexpr int RANK_RP = 6;  // {bits, prefix} pairs a thread carries while a batch is in flight
+
+template <int T, int E, bool STAGE>
+__global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
+    constexpr int W = T / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DecBlock& D = A.blocks[blockIdx.x];
+    if (D.error || D.n_wah == 0 || D.off_line_haploid != VAL_UNDEFINED) return;
+    const uint32_t N = A.N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t cg0 = (blockIdx.y * W + w) * E;  // first chunk of my wave
+    const uint32_t wah_first = D.wah_first, n_wah = D.n_wah;
+    const uint32_t CWP = A.yp_stride;
+
+    uint32_t r[E];
+    static_for<0, E>([&](auto ecn) {
+        constexpr int e = decltype(ecn)::value;
+        r[e] = (cg0 + (uint32_t)e) * 64u + lane;
+        if (r[e] >= N) r[e] = 0;  // haplotypes beyond N idle on position 0; their output is masked
+    });
+    // lane e (< E) stores chunk cg0+e's word; valid-bit mask of that chunk for the row tail
+    uint32_t vm_lo = 0, vm_hi = 0;
+    {
+        const uint64_t base = (uint64_t)(cg0 + lane) * 64u;
+        if (lane < (uint32_t)E && base < N) {
+            const uint32_t nv = (N - base >= 64u) ? 64u : (uint32_t)(N - base);
+            const uint64_t vm = nv == 64u ? ~0ull : ((1ull << nv) - 1ull);
+            vm_lo = (uint32_t)vm;
+            vm_hi = (uint32_t)(vm >> 32);
+        }
+    }
+    const bool store_lane = lane < (uint32_t)E && (uint64_t)(cg0 + lane) * 64u < N;
+    // rows are padded (e.g. to 128 bytes): the words past the last chunk must read as zero
+    const uint32_t row_words = ((N + 63u) / 64u) * 2u;
+    const bool pad_writer = blockIdx.y == 0 && A.out_stride_w > row_words;
+
+    if (!STAGE) {
+        // rows too long for LDS (N > 65536): rank-select straight from L2
+        for (uint32_t j = 0; j < n_wah; ++j) {
+            const uint32_t rank = wah_first + j;
+            const uint2* row = A.yp + (size_t)rank * CWP;
+            const uint32_t Z = A.wah_z[rank];
+            const uint32_t line = A.wah_lines[rank];
+            uint32_t mine_lo = 0, mine_hi = 0;
+            static_for<0, E>([&](auto ecn) {
+                constexpr int e = decltype(ecn)::value;
+                const uint2 pr = row[r[e] >> 5];
+                const uint32_t bit = __builtin_amdgcn_ubfe(pr.x, r[e], 1u);
+                const uint32_t ob = pr.y + (uint32_t)__popc(pr.x & ((1u << (r[e] & 31u)) - 1u));
+                r[e] = bit ? Z + ob : r[e] - ob;
+                const uint64_t m = __ballot(bit != 0u);
+                if (lane == (uint32_t)e) {
+                    mine_lo = (uint32_t)m;
+                    mine_hi = (uint32_t)(m >> 32);
+                }
+            });
+            if (store_lane) {
+                uint2* orow = reinterpret_cast<uint2*>(A.out + (size_t)line * A.out_stride_w);
+                orow[cg0 + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
+            }
+            if (pad_writer)
+                for (uint32_t i = row_words + tid; i < A.out_stride_w; i += T) A.out[(size_t)line * A.out_stride_w + i] = 0;
+        }
+        return;
+    }
+
+    uint2* stage = reinterpret_cast<uint2*>(smem);                       // 2 x B x CWP pairs
+    const uint32_t B = A.batch;
+    uint32_t* meta = reinterpret_cast<uint32_t*>(stage + 2u * B * CWP);  // 2 x B x {line, Z}
+    const uint32_t cwp_mask = (1u << A.log2_cwp) - 1u;
+    const uint32_t n_batches = (n_wah + B - 1u) / B;
+    uint2 R[RANK_RP];
+    uint2 Rm = make_uint2(0, 0);
+    auto load_batch = [&](uint32_t bt) {
+        if (tid < B && bt * B + tid < n_wah) {
+            const uint32_t rank = wah_first + bt * B + tid;
+            Rm = make_uint2(A.wah_lines[rank], A.wah_z[rank]);
+        }
+#pragma unroll
+        for (int q = 0; q < RANK_RP; ++q) {
+            const uint32_t idx = (uint32_t)q * T + tid;
+            const uint32_t jj = idx >> A.log2_cwp, wi = idx & cwp_mask;
+            const uint32_t j = bt * B + jj;
+            uint2 v = make_uint2(0, 0);
+            if (jj < B && j < n_wah && wi < CWP) v = A.yp[(size_t)(wah_first + j) * CWP + wi];
+            R[q] = v;
+        }
+    };
+    auto store_batch = [&](uint32_t buf) {
+        if (tid < B) {
+            meta[(buf * B + tid) * 2u] = Rm.x;
+            meta[(buf * B + tid) * 2u + 1u] = Rm.y;
+        }
+#pragma unroll
+        for (int q = 0; q < RANK_RP; ++q) {
+            const uint32_t idx = (uint32_t)q * T + tid;
+            const uint32_t jj = idx >> A.log2_cwp, wi = idx & cwp_mask;
+            if (jj < B && wi < CWP) stage[(buf * B + jj) * CWP + wi] = R[q];
+        }
+    };
+    load_batch(0);
+    store_batch(0);
+    __syncthreads();
+    for (uint32_t bt = 0; bt < n_batches; ++bt) {
+        const bool more = bt + 1u < n_batches;
+        if (more) load_batch(bt + 1u);
+        const uint32_t jn = (n_wah - bt * B) < B ? (n_wah - bt * B) : B;
+        for (uint32_t jj = 0; jj < jn; ++jj) {
+            const uint2* row = stage + ((bt & 1u) * B + jj) * CWP;
+            const uint32_t line = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[((bt & 1u) * B + jj) * 2u]);
+            const uint32_t Z = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[((bt & 1u) * B + jj) * 2u + 1u]);
+            uint2 pr[E];
+            static_for<0, E>([&](auto ecn) {
+                constexpr int e = decltype(ecn)::value;
+                pr[e] = row[r[e] >> 5];
+            });
+            uint32_t mine_lo = 0, mine_hi = 0;
+            static_for<0, E>([&](auto ecn) {
+                constexpr int e = decltype(ecn)::value;
+                const uint32_t bit = __builtin_amdgcn_ubfe(pr[e].x, r[e], 1u);
+                const uint32_t ob = pr[e].y + (uint32_t)__popc(pr[e].x & ((1u << (r[e] & 31u)) - 1u));
+                r[e] = bit ? Z + ob : r[e] - ob;
+                const uint64_t m = __ballot(bit != 0u);
+                if (lane == (uint32_t)e) {
+                    mine_lo = (uint32_t)m;
+                    mine_hi = (uint32_t)(m >> 32);
+                }
+            });
+            if (store_lane) {
+                uint2* orow = reinterpret_cast<uint2*>(A.out + (size_t)line * A.out_stride_w);
+                orow[cg0 + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
+            }
+            if (pad_writer)
+                for (uint32_t i = row_words + tid; i < A.out_stride_w; i += T) A.out[(size_t)line * A.out_stride_w + i] = 0;
+        }
+        if (more) store_batch((bt + 1u) & 1u);
+        __syncthreads();
+    }
+}
+
+struct RankGeom {
+    int T, E;
+    uint32_t splits, batch, lds_bytes, log2_cwp;
+    bool stage;
+};
+
+static RankGeom rank_geometry(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
+    RankGeom g{};
+    g.T = 256;
+    const uint32_t nch = (N + 63u) / 64u;
+    g.stage = N <= 65536u;
+    // chunks per wave: enough workgroups to cover the chip about twice, at most 8 chunks per wave
+    static const int env_e = [] {
+        const char* e = getenv("XSI_DEC_E");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 1 && v <= 8) ? v : 0;
+    }();
+    int E = 8;
+    const int cand[] = {8, 6, 5, 4, 3, 2, 1};
+    for (int e : cand) {
+        E = e;
+        const uint64_t wgs = (uint64_t)n_blocks * ((nch + 4u * e - 1u) / (4u * e));
+        if (wgs >= 512u) break;
+    }
+    if (env_e) E = env_e;
+    g.E = E;
+    g.splits = (nch + 4u * E - 1u) / (4u * E);
+    g.log2_cwp = next_pow2_log2(yp_stride);
+    if (g.stage) {
+        uint32_t B = (uint32_t)(RANK_RP * g.T) >> g.log2_cwp;
+        if (B > 16u) B = 16u;
+        if (B < 1u) B = 1u;
+        auto need = [&](uint32_t b) { return 2u * b * yp_stride * 8u + 2u * b * 8u + 64u; };
+        while (B > 1u && need(B) > 64u * 1024u) B >>= 1;
+        g.batch = B;
+        g.lds_bytes = need(B);
+        if ((uint32_t)(RANK_RP * g.T) < yp_stride) g.stage = false;  // one row does not fit a register batch
+    }
+    if (!g.stage) {
+        g.batch = 1;
+        g.lds_bytes = 0;
+    }
+    return g;
+}
+
+template <bool STAGE>
+static hipError_t launch_rank(hipStream_t s, const RankGeom& g, uint32_t n_blocks, RankArgs A) {
+#define XSI_RANK_CASE(EE)                                                                                     \
+    if (g.E == EE) {                                                                                          \
+        if (g.lds_bytes) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank<256, EE, STAGE>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes); \
+            if (e != hipSuccess) return e;                                                                    \
+        }                                                                                                     \
+        k_chain_decode_rank<256, EE, STAGE><<<dim3(n_blocks, g.splits), dim3(256), g.lds_bytes, s>>>(A);      \
+        return hipGetLastError();                                                                             \
+    }
+    XSI_RANK_CASE(1)
+    XSI_RANK_CASE(2)
+    XSI_RANK_CASE(3)
+    XSI_RANK_CASE(4)
+    XSI_RANK_CASE(5)
+    XSI_RANK_CASE(6)
+    XSI_RANK_CASE(7)
+    XSI_RANK_CASE(8)
+#undef XSI_RANK_CASE
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
                                uint32_t* scratch_a) {
     ChainArgs A{};
@@ -838,16 +1100,35 @@ hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n
 }
 
 hipError_t launch_chain_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
-                               uint32_t* out_rows, uint32_t out_stride_w, uint32_t* scratch_a) {
+                               uint32_t* out_rows, uint32_t out_stride_w, uint32_t* scratch_a, bool any_haploid) {
+    if (!n_blocks) return hipSuccess;
+    // element-major kernel: every block without fully haploid lines
+    RankArgs R{};
+    R.blocks = blocks;
+    R.wah_lines = L.wah_lines;
+    R.yp = L.yp;
+    R.yp_stride = L.yp_stride;
+    R.wah_z = L.wah_z;
+    R.out = out_rows;
+    R.out_stride_w = out_stride_w;
+    R.N = L.N;
+    const RankGeom g = rank_geometry(L.N, L.yp_stride, n_blocks);
+    R.batch = g.batch;
+    R.log2_cwp = g.log2_cwp;
+    hipError_t e = g.stage ? launch_rank<true>(s, g, n_blocks, R) : launch_rank<false>(s, g, n_blocks, R);
+    if (e != hipSuccess || !any_haploid) return e;
+    // position-major kernel: the blocks with fully haploid lines (it skips the others)
     ChainArgs A{};
     A.wah_lines = L.wah_lines;
     A.kind = L.kind;
-    A.src = reinterpret_cast<const uint32_t*>(L.yrows);
-    A.src_stride_w = L.y_stride64 * 2u;
+    A.src = reinterpret_cast<const uint32_t*>(L.yp);
+    A.src_stride_w = L.yp_stride * 2u;
+    A.src_elem_shift = 1;
     A.dst = out_rows;
     A.dst_stride_w = out_stride_w;
     A.N = L.N;
     A.out_row_base = 0;
+    A.only_haploid_blocks = 1;
     return launch_chain<true>(s, nullptr, blocks, n_blocks, A, scratch_a);
 }
 
@@ -1557,9 +1838,21 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
     uint32_t ones;
     (void)wave_wah_expand_row(src, D.wah_words - start, nbits, row, &ones);
     __syncthreads();
-    uint32_t* dst = reinterpret_cast<uint32_t*>(L.yrows + (size_t)j * L.y_stride64);
-    for (uint32_t i = lane; i < rw; i += 64u) dst[i] = row[i];
-    if (lane == 0) L.ones[l] = ones;
+    // {32 row bits, ones before them}: the decode chain's rank-select table for this line
+    uint2* dst = L.yp + (size_t)j * L.yp_stride;
+    uint32_t base = 0;
+    for (uint32_t i0 = 0; i0 < L.yp_stride; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const uint32_t v = i < rw ? row[i] : 0u;
+        const uint32_t c = (uint32_t)__popc(v);
+        const uint32_t inc = wave_scan_incl(c);
+        if (i < L.yp_stride) dst[i] = make_uint2(v, base + inc - c);
+        base += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) {
+        L.ones[l] = ones;
+        L.wah_z[j] = nbits - base;
+    }
 }
 
 hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,

@@ -91,8 +91,10 @@ struct DecLines {
     uint32_t* sparse_start;// [sparse rank] byte offset inside the block's sparse matrix
     uint32_t* wah_lines;   // [wah rank] binary line
     uint32_t* sparse_lines;
-    uint64_t* yrows;       // [wah rank] permuted rows
-    uint32_t y_stride64;
+    uint2* yp;             // [wah rank][yp_stride] permuted rows as {32 bits, ones before these bits} pairs
+    uint32_t yp_stride;    // pairs per row (>= ceil(N/32), even)
+    uint32_t* wah_z;       // [wah rank] zeros of the line (line bits - ones)
+    uint32_t y_stride64;   // ceil(N/64): 64-bit words of a plain bit row
     uint32_t* ones;        // per binary line: allele count (accessor "ones")
     uint32_t* wah_cumg;    // [wah rank] cumulative 15-bit groups before the line (mixed-ploidy blocks)
     uint64_t file_len;     // bytes of the file image (bounds every read)
@@ -113,7 +115,7 @@ hipError_t launch_sparse_walk(hipStream_t s, const uint8_t* file, const DecBlock
 hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
                              uint32_t max_wah, const uint32_t* d_totals);
 hipError_t launch_chain_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
-                               uint32_t* out_rows, uint32_t out_stride_w, uint32_t* scratch_a);
+                               uint32_t* out_rows, uint32_t out_stride_w, uint32_t* scratch_a, bool any_haploid);
 hipError_t launch_sparse_fill(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
                               uint32_t max_sparse, const uint32_t* d_totals, uint32_t* out_rows,
                               uint32_t out_stride_w, int apply_negation);
