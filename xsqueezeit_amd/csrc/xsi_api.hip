@@ -282,7 +282,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     HIP_TRY(launch_scan_blocks_wah(s, d_blocks, n_blocks, d_totals));
     HIP_TRY(launch_build_wah_list(s, d_blocks, n_blocks, L));
     stage_mark(ctx, XSI_ST_CHAIN_ENC);
-    HIP_TRY(launch_chain_encode(s, d_blocks, n_blocks, L, scratch_a));
+    HIP_TRY(launch_chain_encode(s, d_blocks, n_blocks, L, scratch_a, L.bin_nbits != nullptr));
     stage_mark(ctx, XSI_ST_WAH_SIZE);
     HIP_TRY(launch_wah_sizes(s, L, d_totals, n_bin));
     stage_mark(ctx, XSI_ST_LAYOUT);
@@ -406,7 +406,7 @@ int xsi_hip_debug_chain_encode(xsi_hip_ctx* ctx, const xsi_encode_params* p, con
     HIP_TRY(launch_classify(s, d_blocks, n_blocks, L));
     HIP_TRY(launch_scan_blocks_wah(s, d_blocks, n_blocks, d_totals));
     HIP_TRY(launch_build_wah_list(s, d_blocks, n_blocks, L));
-    HIP_TRY(launch_chain_encode(s, d_blocks, n_blocks, L, scratch_a));
+    HIP_TRY(launch_chain_encode(s, d_blocks, n_blocks, L, scratch_a, L.bin_nbits != nullptr));
     uint32_t tot[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(tot, d_totals, 4, hipMemcpyDeviceToHost, s));
     if (d_line_kind) {

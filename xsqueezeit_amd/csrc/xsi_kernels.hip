@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(1024) k_classify(EncBlock* __restrict__ blocks
     EncBlock& B = blocks[b];
     const uint32_t first = B.first_bin, n = B.n_bin;
     uint32_t wah_base = 0, sp_base = 0;
+    int any_hap = 0;
     uint32_t* fb = L.flagbits + ((size_t)b * FV_COUNT + FV_IS_WAH) * (MAX_BIN_PER_BLOCK / 32);
     for (uint32_t c0 = 0; c0 < n; c0 += blockDim.x) {
         const uint32_t i = c0 + threadIdx.x;
@@ -106,6 +107,7 @@ __global__ void __launch_bounds__(1024) k_classify(EncBlock* __restrict__ blocks
             }
             L.kind[l] = (uint8_t)k;
             L.line_block[l] = b;
+            if (k & KIND_HAPLOID) any_hap = 1;
         }
         const uint64_t W = __ballot(is_wah);
         if (lane_id() == 0 && c0 + (threadIdx.x & ~63u) < n) {
@@ -122,9 +124,11 @@ __global__ void __launch_bounds__(1024) k_classify(EncBlock* __restrict__ blocks
         wah_base += (uint32_t)(tot >> 40);
         sp_base += (uint32_t)(tot & 0xFFFFFFFFFFull);
     }
+    any_hap = __syncthreads_or(any_hap);
     if (threadIdx.x == 0) {
         B.n_wah = wah_base;
         B.sparse_bytes = sp_base;
+        B.has_haploid = any_hap ? 1u : 0u;  // chain kernel selection; block_layout recomputes it from the BCF flags
     }
 }
 
@@ -423,6 +427,7 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
         wah_first = dblocks[blockIdx.x].wah_first;
         n_wah = dblocks[blockIdx.x].n_wah;
     } else {
+        if (A.only_haploid_blocks && !eblocks[blockIdx.x].has_haploid) return;
         wah_first = eblocks[blockIdx.x].wah_first;
         n_wah = eblocks[blockIdx.x].n_wah;
     }
@@ -623,6 +628,7 @@ __global__ void __launch_bounds__(1024) k_chain_global(const EncBlock* __restric
         wah_first = dblocks[blockIdx.x].wah_first;
         n_wah = dblocks[blockIdx.x].n_wah;
     } else {
+        if (A.only_haploid_blocks && !eblocks[blockIdx.x].has_haploid) return;
         wah_first = eblocks[blockIdx.x].wah_first;
         n_wah = eblocks[blockIdx.x].n_wah;
     }
@@ -1086,7 +1092,8 @@ static hipError_t launch_rank(hipStream_t s, const RankGeom& g, uint32_t n_block
 }
 
 hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
-                               uint32_t* scratch_a) {
+                               uint32_t* scratch_a, bool any_haploid) {
+    (void)any_haploid;  // the position-major kernel handles haploid lines itself
     ChainArgs A{};
     A.wah_lines = L.wah_lines;
     A.kind = L.kind;

@@ -65,7 +65,7 @@ hipError_t launch_classify(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, c
 hipError_t launch_scan_blocks_wah(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, uint32_t* totals);
 hipError_t launch_build_wah_list(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L);
 hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
-                               uint32_t* scratch_a /*global-memory variant only*/);
+                               uint32_t* scratch_a /*global-memory variant only*/, bool any_haploid);
 hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_total_wah, uint32_t max_wah);
 hipError_t launch_block_layout(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
                                const EncSide& S, int32_t default_phased);
