@@ -56,7 +56,11 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     L = binding.lib()
-    ctx = binding.Context(local_rank, torch.cuda.current_stream().cuda_stream)
+    # ONE explicit stream shared by torch and the codec (torch's default stream has handle 0, which
+    # the C ABI reads as "create your own stream": two unordered streams would race)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = binding.Context(local_rank, stream.cuda_stream)
 
     N, S = args.haps, args.sites
     n_samples = N // 2

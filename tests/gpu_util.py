@@ -13,25 +13,34 @@ def torch_mod():
 
 
 _CTX = None
+_STREAM = None
 
 
 def ctx():
-    global _CTX
+    """One context for the whole test session, sharing ONE explicit stream with torch: torch's
+    default stream has handle 0, which the C ABI reads as "create your own stream", and two
+    unordered streams would race (torch fills / copies vs our kernels)."""
+    global _CTX, _STREAM
     if _CTX is None:
         torch = torch_mod()
         assert torch.cuda.is_available(), "GPU tests need a GPU"
         torch.cuda.init()
-        _CTX = binding.Context(0, torch.cuda.current_stream().cuda_stream)
+        _STREAM = torch.cuda.Stream()
+        torch.cuda.set_stream(_STREAM)
+        assert _STREAM.cuda_stream != 0
+        _CTX = binding.Context(0, _STREAM.cuda_stream)
     return _CTX
 
 
 def dev_u8(arr):
     torch = torch_mod()
+    ctx()
     return torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).cuda()
 
 
 def dev_empty(nbytes):
     torch = torch_mod()
+    ctx()
     return torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
 
 

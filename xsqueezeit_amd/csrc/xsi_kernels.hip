@@ -1030,25 +1030,40 @@ struct RankGeom {
 
 static RankGeom rank_geometry(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
     RankGeom g{};
-    g.T = 256;
     const uint32_t nch = (N + 63u) / 64u;
     g.stage = N <= 65536u;
-    // chunks per wave: enough workgroups to cover the chip about twice, at most 8 chunks per wave
+    // Every workgroup stages the whole rank-select row of each line, so splitting a block's
+    // haplotypes over S workgroups multiplies that L2 traffic by S.  Prefer the largest workgroup
+    // that still gives about one workgroup per CU, and at most 8 chunks per wave.
     static const int env_e = [] {
         const char* e = getenv("XSI_DEC_E");
         const int v = e ? atoi(e) : 0;
         return (v >= 1 && v <= 8) ? v : 0;
     }();
-    int E = 8;
-    const int cand[] = {8, 6, 5, 4, 3, 2, 1};
-    for (int e : cand) {
-        E = e;
-        const uint64_t wgs = (uint64_t)n_blocks * ((nch + 4u * e - 1u) / (4u * e));
-        if (wgs >= 512u) break;
+    static const int env_t = [] {
+        const char* e = getenv("XSI_DEC_T");
+        const int v = e ? atoi(e) : 0;
+        return (v == 256 || v == 512 || v == 1024) ? v : 0;
+    }();
+    // about one workgroup per CU (measured best at the bench size: T=512, E=5, 2 splits: 2.3 ms
+    // against 2.9 ms for 5 splits of T=256 and 3.4 ms for a single 1024-thread workgroup per block)
+    int T, E;
+    {
+        const uint32_t s_target = n_blocks >= 256u ? 1u : (256u + n_blocks / 2u) / (n_blocks ? n_blocks : 1u);
+        const uint32_t per_wg = (nch + s_target - 1u) / s_target;  // chunks one workgroup should cover
+        T = per_wg <= 8u ? 256 : (per_wg <= 64u ? 512 : 1024);
+        const uint32_t waves = (uint32_t)T / 64u;
+        uint32_t e = (per_wg + waves - 1u) / waves;
+        if (e < 1u) e = 1u;
+        if (e > 8u) e = 8u;
+        E = (int)e;
     }
+    if (env_t) T = env_t;
     if (env_e) E = env_e;
+    g.T = T;
     g.E = E;
-    g.splits = (nch + 4u * E - 1u) / (4u * E);
+    const uint32_t per_wg = (uint32_t)(T / 64) * (uint32_t)E;
+    g.splits = (nch + per_wg - 1u) / per_wg;
     g.log2_cwp = next_pow2_log2(yp_stride);
     if (g.stage) {
         uint32_t B = (uint32_t)(RANK_RP * g.T) >> g.log2_cwp;
@@ -1069,24 +1084,23 @@ static RankGeom rank_geometry(uint32_t N, uint32_t yp_stride, uint32_t n_blocks)
 
 template <bool STAGE>
 static hipError_t launch_rank(hipStream_t s, const RankGeom& g, uint32_t n_blocks, RankArgs A) {
-#define XSI_RANK_CASE(EE)                                                                                     \
-    if (g.E == EE) {                                                                                          \
+#define XSI_RANK_CASE(TT, EE)                                                                                 \
+    if (g.T == TT && g.E == EE) {                                                                             \
         if (g.lds_bytes) {                                                                                    \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank<256, EE, STAGE>), \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank<TT, EE, STAGE>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes); \
             if (e != hipSuccess) return e;                                                                    \
         }                                                                                                     \
-        k_chain_decode_rank<256, EE, STAGE><<<dim3(n_blocks, g.splits), dim3(256), g.lds_bytes, s>>>(A);      \
+        k_chain_decode_rank<TT, EE, STAGE><<<dim3(n_blocks, g.splits), dim3(TT), g.lds_bytes, s>>>(A);        \
         return hipGetLastError();                                                                             \
     }
-    XSI_RANK_CASE(1)
-    XSI_RANK_CASE(2)
-    XSI_RANK_CASE(3)
-    XSI_RANK_CASE(4)
-    XSI_RANK_CASE(5)
-    XSI_RANK_CASE(6)
-    XSI_RANK_CASE(7)
-    XSI_RANK_CASE(8)
+#define XSI_RANK_CASES(TT) \
+    XSI_RANK_CASE(TT, 1) XSI_RANK_CASE(TT, 2) XSI_RANK_CASE(TT, 3) XSI_RANK_CASE(TT, 4) \
+    XSI_RANK_CASE(TT, 5) XSI_RANK_CASE(TT, 6) XSI_RANK_CASE(TT, 7) XSI_RANK_CASE(TT, 8)
+    XSI_RANK_CASES(256)
+    XSI_RANK_CASES(512)
+    XSI_RANK_CASES(1024)
+#undef XSI_RANK_CASES
 #undef XSI_RANK_CASE
     return hipErrorInvalidValue;
 }
@@ -1149,7 +1163,11 @@ __global__ void __launch_bounds__(256) k_wah_sizes(EncLines L, const uint32_t* _
     const uint32_t l = L.wah_lines[j];
     uint32_t nbits = nbits_of(L, l);
     const uint32_t* row = reinterpret_cast<const uint32_t*>(L.yrows + (size_t)j * L.y_stride64);
-    const uint32_t n = wave_wah_encode_row<false>(row, nbits, nullptr);
+    uint32_t n;
+    if (L.wah_scratch)
+        n = wave_wah_encode_row<true>(row, nbits, L.wah_scratch + (size_t)j * L.wah_scratch_stride);
+    else
+        n = wave_wah_encode_row<false>(row, nbits, nullptr);
     if (lane_id() == 0) L.wah_len[j] = n;
 }
 
@@ -1169,7 +1187,14 @@ __global__ void __launch_bounds__(256) k_wah_write(const EncBlock* __restrict__ 
     const uint32_t nbits = nbits_of(L, l);
     const uint32_t* row = reinterpret_cast<const uint32_t*>(L.yrows + (size_t)j * L.y_stride64);
     uint16_t* dst = reinterpret_cast<uint16_t*>(out + B.out_off + 16u + B.off_wah) + L.wah_off[j];
-    (void)wave_wah_encode_row<true>(row, nbits, dst);
+    if (L.wah_scratch) {
+        // the sizing pass already produced the words: move them to their final place
+        const uint16_t* src = L.wah_scratch + (size_t)j * L.wah_scratch_stride;
+        const uint32_t n = L.wah_len[j];
+        for (uint32_t i = lane_id(); i < n; i += 64u) dst[i] = src[i];
+    } else {
+        (void)wave_wah_encode_row<true>(row, nbits, dst);
+    }
 }
 
 hipError_t launch_wah_write(hipStream_t s, const EncBlock* blocks, const EncLines& L, uint32_t max_wah,

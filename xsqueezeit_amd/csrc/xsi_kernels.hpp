@@ -33,6 +33,8 @@ struct EncLines {
     uint32_t* wah_off;          // word offset inside the block's WAH matrix (by batch-wide rank)
     uint64_t* yrows;            // permuted bit rows, one per WAH line (by batch-wide rank)
     uint32_t y_stride64;
+    uint16_t* wah_scratch;      // [rank][wah_scratch_stride] WAH16 words of each line (encoded once, copied to place)
+    uint32_t wah_scratch_stride;
     uint32_t* flagbits;         // [n_blocks][FV_COUNT][MAX_BIN_PER_BLOCK/32] packed flag vectors
     uint16_t* flagwah;          // [n_blocks][FV_COUNT][FLAG_WORDS_MAX] encoded flag vectors
 };
