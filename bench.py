@@ -148,6 +148,19 @@ def main():
         kern_ms = (enc_ms / max(enc_n, 1))
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in timing.items() if v[1]}
+        # HBM bytes of that kernel from the PMC passes kept under profiles/ (separate --pmc FETCH_SIZE /
+        # WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 note in
+        # MI355X_MICROARCH.md).  Only valid for the default workload; null otherwise.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath) and (N, S, args.block_len) == (5008, 1_000_000, 8192):
+            try:
+                tj = json.load(open(tpath))
+                key = [k for k in tj if k.startswith("xsi::k_chain_lds") and "false" in k]
+                if key:
+                    traffic = tj[key[0]]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         pipeline_gbs = (cells / 4.0 + 2.0 * xsi_bytes) / (dt / args.steps) / 1e9
         out = {
             "metric": "GT cells/sec (hap x site) encode+decode round-trip",
@@ -163,7 +176,8 @@ def main():
                        if distributed else "1 GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_chain_lds (PBWT chain, encode)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": kern_ms,
+                         "traffic": traffic, "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc passes)" if traffic else None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                          "chain_decode_ms": dec_ms / max(dec_n, 1),
                          "pipeline_achieved_GBps": pipeline_gbs, "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
                          "stage_ms": stages},
