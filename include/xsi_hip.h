@@ -157,6 +157,16 @@ int xsi_hip_decode_gt(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, u
                       uint64_t n_blocks, const uint32_t* h_n_allele, uint64_t n_lines, int32_t* d_gt_out,
                       uint64_t gt_stride, uint32_t* h_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles);
 
+/*
+ * Allele counts without expanding genotypes — the GPU form of AccessorInternals::fill_allele_counts
+ * (include/accessor_internals_new.hpp:407-438): d_ones[r] = ALT count of binary line r of the decoded
+ * blocks (WAH lines by popcount of their words, sparse lines from their count field), d_kind[r]
+ * (optional) = bit0 WAH line, bit1 negated sparse, bit2 fully haploid line.  No PBWT chain is run.
+ */
+int xsi_hip_decode_counts(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block,
+                          uint64_t n_blocks, uint32_t* d_ones, uint8_t* d_kind, uint64_t capacity,
+                          uint64_t* h_n_bin);
+
 /* Deterministic synthetic haplotype matrix: writes n_lines packed rows starting
  * at site index first_line.  Generator defined in DESIGN.md; mirrored in numpy for the tests. */
 int xsi_hip_synth_packed(xsi_hip_ctx* ctx, uint64_t seed, uint64_t first_line, uint64_t n_lines, uint32_t n_haps,
@@ -194,6 +204,10 @@ int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_
  * sets *ngt_arr = hap_samples (accessor.hpp:58-67). */
 int64_t xsi_accessor_get_genotypes(xsi_accessor* a, uint32_t n_alleles, uint64_t position, void** h_gt,
                                    int* ngt_arr);
+/* Accessor::fill_allele_counts(n_alleles, position) (accessor.hpp:52-54): counts only, no genotype
+ * expansion; like the reference, counts[0] = line values - sum of ALT counts (missing / end-of-vector
+ * are not subtracted, accessor_internals_new.hpp:437). */
+int xsi_accessor_fill_allele_counts(xsi_accessor* a, uint32_t n_alleles, uint64_t position);
 /* Accessor::get_allele_counts after a fill (accessor.hpp:56). */
 int xsi_accessor_allele_counts(xsi_accessor* a, uint64_t* h_counts, uint32_t n_alleles);
 uint64_t xsi_accessor_hap_samples(const xsi_accessor* a);

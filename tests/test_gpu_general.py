@@ -190,3 +190,52 @@ def test_writer_and_accessor_files(tmp_path, kw):
     assert np.array_equal(got0, lines[0][0])
     ctypes.CDLL(None).free(pp)
     L.xsi_accessor_close(a)
+
+
+def test_allele_counts_without_expansion(tmp_path):
+    """fill_allele_counts path (no genotype expansion, no PBWT chain): device API and accessor mirror
+    against the oracle's fill_allele_counts, including its quirk of not subtracting missing / EOV."""
+    import gpu_util as G
+    from oracle import oracle
+    torch = G.torch_mod()
+    L = binding.lib()
+    rng = np.random.default_rng(33)
+    n, n_lines, block_len = 150, 500, 128
+    lines = _random_lines(rng, n, n_lines, multi=True, missing=True, eov=True)
+    dp = oracle.default_phased_of(lines, n)
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=3, default_phased=dp)
+    n_bin = G.num_variants(lines)
+    d_file = G.dev_u8(np.frombuffer(ref, dtype=np.uint8))
+    d_ones = torch.zeros(n_bin, dtype=torch.int32, device="cuda")
+    d_kind = torch.zeros(n_bin, dtype=torch.uint8, device="cuda")
+    nb = ctypes.c_uint64(0)
+    n_blocks = (n_lines + block_len - 1) // block_len
+    binding.check(L.xsi_hip_decode_counts(G.ctx().handle, d_file.data_ptr(), len(ref), 0, n_blocks, d_ones.data_ptr(),
+                                          d_kind.data_ptr(), n_bin, ctypes.byref(nb)))
+    assert nb.value == n_bin
+    ones = d_ones.cpu().numpy()
+    rd = oracle.Reader(ref)
+    path = tmp_path / "f.xsi"
+    path.write_bytes(ref)
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
+    cnt = np.zeros(8, dtype=np.uint64)
+    block = off = g = 0
+    for i, (gt, na) in enumerate(lines):
+        if i and i % block_len == 0:
+            block += 1
+            off = 0
+        bm = (block << 15) | off
+        exp = rd.fill_allele_counts(na, bm)
+        assert np.array_equal(ones[g:g + na - 1], exp[1:na].astype(np.int32)), "line %d" % i
+        binding.check(L.xsi_accessor_fill_allele_counts(a, na, bm))
+        binding.check(L.xsi_accessor_allele_counts(a, cnt.ctypes.data, na))
+        assert np.array_equal(cnt[:na], exp), "accessor line %d" % i
+        off += na - 1
+        g += na - 1
+    # interleave with genotype fills on the same accessor (state switches between the two views)
+    buf = np.zeros(2 * n, dtype=np.int32)
+    r = L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, lines[3][1], 0 << 15 | sum(x[1] - 1 for x in lines[:3]))
+    assert r == 2 * n and np.array_equal(buf, lines[3][0])
+    binding.check(L.xsi_accessor_fill_allele_counts(a, lines[0][1], 0))
+    L.xsi_accessor_close(a)

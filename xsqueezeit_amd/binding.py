@@ -44,7 +44,7 @@ SYMBOLS = [
     "xsi_hip_abi_version", "xsi_hip_last_error", "xsi_hip_ctx_create", "xsi_hip_ctx_destroy",
     "xsi_hip_ctx_synchronize", "xsi_hip_ctx_workspace_bytes", "xsi_hip_ctx_set_timing",
     "xsi_hip_ctx_get_timing", "xsi_hip_stage_name", "xsi_hip_encode_bound", "xsi_hip_encode_packed",
-    "xsi_hip_encode_gt", "xsi_hip_encode_gt_bound", "xsi_hip_make_header", "xsi_hip_decode_packed", "xsi_hip_decode_gt",
+    "xsi_hip_encode_gt", "xsi_hip_encode_gt_bound", "xsi_hip_make_header", "xsi_hip_decode_packed", "xsi_hip_decode_gt", "xsi_hip_decode_counts", "xsi_accessor_fill_allele_counts",
     "xsi_hip_synth_packed", "xsi_hip_debug_chain_encode", "xsi_writer_open", "xsi_writer_append",
     "xsi_writer_finalize", "xsi_writer_close", "xsi_accessor_open", "xsi_accessor_fill_genotype_array",
     "xsi_accessor_get_genotypes", "xsi_accessor_allele_counts", "xsi_accessor_hap_samples",
@@ -97,6 +97,10 @@ def lib():
     L.xsi_hip_decode_packed.argtypes = [vp, vp, u64, u64, u64, vp, u32, u64, c.POINTER(u64), vp]
     L.xsi_hip_decode_gt.restype = c.c_int
     L.xsi_hip_decode_gt.argtypes = [vp, vp, u64, u64, u64, vp, u64, vp, u64, vp, vp, u32]
+    L.xsi_hip_decode_counts.restype = c.c_int
+    L.xsi_hip_decode_counts.argtypes = [vp, vp, u64, u64, u64, vp, vp, u64, c.POINTER(u64)]
+    L.xsi_accessor_fill_allele_counts.restype = c.c_int
+    L.xsi_accessor_fill_allele_counts.argtypes = [vp, u32, u64]
     L.xsi_hip_synth_packed.restype = c.c_int
     L.xsi_hip_synth_packed.argtypes = [vp, u64, u64, u64, u32, vp, u32]
     L.xsi_hip_debug_chain_encode.restype = c.c_int

@@ -450,6 +450,27 @@ int xsi_hip_decode_packed(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_le
     return XSI_OK;
 }
 
+int xsi_hip_decode_counts(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block,
+                           uint64_t n_blocks64, uint32_t* d_ones, uint8_t* d_kind, uint64_t capacity, uint64_t* h_n_bin) {
+    if (!ctx || !d_file || !d_ones) return set_error(XSI_ERR_ARG, "decode_counts: null argument");
+    if (file_len < 256) return set_error(XSI_ERR_FORMAT, "file image shorter than the 256-byte header");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DecodePlan P;
+    int rc = decode_prepare(ctx, d_file, file_len, first_block, n_blocks64, &P);
+    if (rc) return rc;
+    if (P.n_bin > capacity) return set_error(XSI_ERR_CAPACITY, "decode_counts: %u binary lines, capacity %llu", P.n_bin,
+                                             (unsigned long long)capacity);
+    rc = decode_counts_only(ctx, d_file, P);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_ones, P.L.ones, 4ull * P.n_bin, hipMemcpyDeviceToDevice, s));
+    if (d_kind) HIP_TRY(hipMemcpyAsync(d_kind, P.L.kind, P.n_bin, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    stage_collect(ctx);
+    if (h_n_bin) *h_n_bin = P.n_bin;
+    return XSI_OK;
+}
+
 int xsi_hip_synth_packed(xsi_hip_ctx* ctx, uint64_t seed, uint64_t first_line, uint64_t n_lines, uint32_t n_haps,
                          void* d_bits, uint32_t row_stride_bytes) {
     if (!ctx || !d_bits) return set_error(XSI_ERR_ARG, "synth_packed: null argument");
@@ -555,6 +576,19 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
     L.yp_stride = L.y_stride64 * 2u;
     WS(L.yp, "dec.yp", 8ull * L.yp_stride * (size_t)(P->n_wah ? P->n_wah : 1));
     WS(L.wah_z, "dec.wah_z", 4ull * (P->n_wah ? P->n_wah : 1) + 64);
+    return XSI_OK;
+}
+
+// Line boundaries + popcounts only: ones[] per binary line, no rows, no chain.
+int decode_counts_only(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P) {
+    hipStream_t s = ctx->stream;
+    const uint8_t* f = (const uint8_t*)d_file;
+    stage_mark(ctx, XSI_ST_DEC_BOUND);
+    HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, P.L));
+    HIP_TRY(launch_sparse_walk(s, f, P.d_blocks, P.n_blocks, P.L));
+    stage_mark(ctx, XSI_ST_DEC_EXPAND);
+    HIP_TRY(launch_line_counts(s, f, P.d_blocks, P.L, P.n_wah, P.n_sparse, P.d_totals));
+    stage_mark(ctx, -1);
     return XSI_OK;
 }
 

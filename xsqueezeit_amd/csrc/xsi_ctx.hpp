@@ -86,6 +86,7 @@ int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D,
                   uint32_t* d_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles);
 int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block, uint64_t n_blocks,
                    DecodePlan* P);
+int decode_counts_only(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P);
 int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t* out, uint32_t stride_w,
                   int apply_negation);
 int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide S, std::vector<EncBlock>& blocks_h,

@@ -183,7 +183,8 @@ __device__ __forceinline__ uint32_t wave_wah_encode_row(const uint32_t* __restri
 // Expand one WAH16 line into a zeroed packed row held in LDS (wah2_extract_template,
 // wah.hpp:177-223).  One wave.  `src` is 2-byte aligned; at most `max_words` words may be
 // read.  Returns the words consumed; *ones = set bits counted like the reference (fills count
-// whole groups).  The caller must barrier before reading `row`.
+// whole groups).  The caller must barrier before reading `row`.  row == nullptr: count only
+// (wah2_advance_pointer_count_ones, wah.hpp:125-150).
 __device__ __forceinline__ uint32_t wave_wah_expand_row(const uint16_t* __restrict__ src, uint32_t max_words,
                                                         uint32_t nbits, uint32_t* row /*LDS*/, uint32_t* ones) {
     const uint32_t lane = lane_id();
@@ -204,7 +205,7 @@ __device__ __forceinline__ uint32_t wave_wah_expand_row(const uint16_t* __restri
                 const uint32_t o = s * WAH_BITS;
                 const uint32_t v = word & 0x7FFFu;
                 cnt1 += (uint32_t)__popc(v);
-                if (v && o < row_bits) {
+                if (row && v && o < row_bits) {
                     atomicOr(&row[o >> 5], v << (o & 31u));
                     if ((o & 31u) > 17u && (o >> 5) + 1u < (row_bits >> 5)) atomicOr(&row[(o >> 5) + 1u], v >> (32u - (o & 31u)));
                 }
@@ -213,7 +214,7 @@ __device__ __forceinline__ uint32_t wave_wah_expand_row(const uint16_t* __restri
             }
         }
         // ones-fills: the whole wave paints each run
-        uint64_t F = __ballot(active && fill && (word & 0x4000u) && ng);
+        uint64_t F = row ? __ballot(active && fill && (word & 0x4000u) && ng) : 0ull;
         while (F) {
             const int f = __ffsll((long long)F) - 1;
             F &= F - 1ull;

@@ -233,6 +233,10 @@ struct xsi_accessor {
     DecodePlan P;
     DecodedPlanes D;
     bool biallelic = false;
+    // counts-only view of a block (fill_allele_counts never expands genotypes)
+    int64_t cnt_block = -1;
+    std::vector<uint32_t> cnt_ones;
+    std::vector<uint8_t> cnt_kind;
     // composed window of a bi-allelic block, or the single last composed line
     int32_t* d_rows = nullptr;
     int32_t* h_rows = nullptr;  // pinned
@@ -254,6 +258,7 @@ static int accessor_load_block(xsi_accessor* a, uint64_t block) {
     if (rc) return rc;
     a->biallelic = a->P.n_bin == a->P.n_bcf;
     a->cur_block = (int64_t)block;
+    a->cnt_block = -1;
     a->win_n = 0;
     return XSI_OK;
 }
@@ -431,6 +436,41 @@ int64_t xsi_accessor_get_genotypes(xsi_accessor* a, uint32_t n_alleles, uint64_t
     }
     *ngt_arr = (int)ngt;
     return xsi_accessor_fill_genotype_array(a, (int32_t*)*h_gt, ngt, n_alleles, position);
+}
+
+int xsi_accessor_fill_allele_counts(xsi_accessor* a, uint32_t n_alleles, uint64_t position) {
+    if (!a) return set_error(XSI_ERR_ARG, "fill_allele_counts: null accessor");
+    if (n_alleles < 2) return set_error(XSI_ERR_ARG, "fill_allele_counts: n_alleles < 2");
+    const uint64_t block = (position & 0xFFFFFFFFull) >> BM_BLOCK_BITS;
+    const uint32_t offset = (uint32_t)(position & ((1u << BM_BLOCK_BITS) - 1u));
+    if (a->cnt_block < 0 || (uint64_t)a->cnt_block != block) {
+        if (block >= a->n_blocks) return set_error(XSI_ERR_ARG, "block %llu beyond the file", (unsigned long long)block);
+        DecodePlan P;
+        int rc = decode_prepare(a->ctx, a->d_file, a->file.size(), block, 1, &P);
+        if (rc) return rc;
+        rc = decode_counts_only(a->ctx, a->d_file, P);
+        if (rc) return rc;
+        a->cnt_ones.resize(P.n_bin);
+        a->cnt_kind.resize(P.n_bin);
+        HIP_TRY(hipMemcpyAsync(a->cnt_ones.data(), P.L.ones, 4ull * P.n_bin, hipMemcpyDeviceToHost, a->ctx->stream));
+        HIP_TRY(hipMemcpyAsync(a->cnt_kind.data(), P.L.kind, P.n_bin, hipMemcpyDeviceToHost, a->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+        a->cnt_block = (int64_t)block;
+        a->cur_block = -1;  // the shared workspace now holds the counts-only state of this block
+        a->win_n = 0;
+    }
+    if ((size_t)offset + (n_alleles - 1) > a->cnt_ones.size())
+        return set_error(XSI_ERR_ARG, "position offset %u (+%u alleles) beyond the block", offset, n_alleles - 1);
+    const uint64_t N = a->num_samples ? a->num_samples * 2 : a->hap_samples;
+    const uint64_t nl = (a->cnt_kind[offset] & KIND_HAPLOID) ? N / 2 : N;
+    a->last_counts.assign(n_alleles, 0);
+    uint64_t total = 0;
+    for (uint32_t k = 1; k < n_alleles; ++k) {
+        a->last_counts[k] = a->cnt_ones[offset + k - 1];
+        total += a->last_counts[k];
+    }
+    a->last_counts[0] = nl - total;  // sic: missing / end-of-vector not subtracted (:437)
+    return XSI_OK;
 }
 
 int xsi_accessor_allele_counts(xsi_accessor* a, uint64_t* h_counts, uint32_t n_alleles) {

@@ -1898,6 +1898,55 @@ hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock*
     return hipGetLastError();
 }
 
+// allele counts without expansion (fill_allele_counts_advance, accessor_internals_new.hpp:407-438):
+// WAH lines by popcount over their words (wah2_advance_pointer_count_ones, wah.hpp:125-150),
+// sparse lines from their count field (sparse_advance_pointer, :639-653).
+__global__ void __launch_bounds__(256) k_wah_count(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
+                                                   DecLines L, const uint32_t* __restrict__ d_totals) {
+    const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (j >= d_totals[1] || d_totals[3]) return;
+    const uint32_t l = L.wah_lines[j];
+    const DecBlock& D = blocks[L.line_block[l]];
+    const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
+    const uint32_t start = L.wah_start[j];
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah) + start;
+    uint32_t ones;
+    (void)wave_wah_expand_row(src, D.wah_words - start, nbits, nullptr, &ones);
+    if (lane_id() == 0) L.ones[l] = ones;
+}
+
+__global__ void __launch_bounds__(256) k_sparse_count(const uint8_t* __restrict__ file,
+                                                      const DecBlock* __restrict__ blocks, DecLines L,
+                                                      const uint32_t* __restrict__ d_totals) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= d_totals[2] || d_totals[3]) return;
+    const uint32_t l = L.sparse_lines[k];
+    const DecBlock& D = blocks[L.line_block[l]];
+    const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
+    const uint64_t at = D.gt_off + D.off_sparse + L.sparse_start[k];
+    uint32_t num = 0;
+    if (at + L.aet <= L.file_len) num = rd_at(file + at, L.aet);
+    const uint32_t msb = (L.aet == 2u) ? 0x8000u : 0x80000000u;
+    const bool neg = (num & msb) != 0u;
+    num &= ~msb;
+    L.ones[l] = neg ? nbits - num : num;
+    if (neg) L.kind[l] |= KIND_NEGATED;
+}
+
+hipError_t launch_line_counts(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
+                              uint32_t max_wah, uint32_t max_sparse, const uint32_t* d_totals) {
+    if (max_wah) {
+        k_wah_count<<<dim3((max_wah + 3u) / 4u), dim3(256), 0, s>>>(file, blocks, L, d_totals);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (max_sparse) {
+        k_sparse_count<<<dim3((max_sparse + 255u) / 256u), dim3(256), 0, s>>>(file, blocks, L, d_totals);
+        return hipGetLastError();
+    }
+    return hipSuccess;
+}
+
 // sparse lines -> bit rows (sparse_extract + the fill loops of fill_genotype_array_advance,
 // accessor_internals_new.hpp:208-219, 619-637).  apply_negation: write the ALT bit row of a
 // negated bi-allelic line (complement of the listed REF positions); otherwise the raw listed

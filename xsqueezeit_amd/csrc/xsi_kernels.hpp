@@ -122,6 +122,9 @@ hipError_t launch_sparse_fill(hipStream_t s, const uint8_t* file, const DecBlock
                               uint32_t max_sparse, const uint32_t* d_totals, uint32_t* out_rows,
                               uint32_t out_stride_w, int apply_negation);
 
+hipError_t launch_line_counts(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
+                              uint32_t max_wah, uint32_t max_sparse, const uint32_t* d_totals);
+
 // ---- synthetic data ----
 hipError_t launch_synth_packed(hipStream_t s, uint64_t seed, uint64_t first_line, uint64_t n_lines, uint32_t n_haps,
                                uint32_t* bits, uint32_t stride_w);
