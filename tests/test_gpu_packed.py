@@ -166,3 +166,95 @@ def test_capacity_error_is_reported():
     rc = binding.lib().xsi_hip_encode_packed(G.ctx().handle, ctypes.byref(p), d_bits.data_ptr(), 300, stride,
                                              d_out.data_ptr(), 1024, d_off.data_ptr(), ctypes.byref(res))
     assert rc == binding.XSI_ERR_CAPACITY
+
+
+@pytest.mark.parametrize("n_haps,n_lines,block_len,thr", [
+    (65534, 20, 8, 65),     # largest count with u16 A_T in header AND blocks (32767 samples)
+    (65536, 12, 8, 65),     # 32768 samples: first size of the A_T mismatch window (encode-only)
+    (131072, 10, 8, 131),   # 65536 samples: first size with u32 A_T everywhere
+    (64, 200, 50, 0),       # exactly one wave chunk
+    (66, 200, 50, 0),       # one sample past a chunk boundary
+    (4096, 300, 128, 4),    # exact multiple of the chain capacity (no padding members)
+])
+def test_size_boundaries(n_haps, n_lines, block_len, thr):
+    import gpu_util as G
+    bits, packed, stride = _mk(n_haps, n_lines, 1000 + n_haps)
+    p = G.params(n_haps // 2, block_len, thr)
+    names = ["S%d" % i for i in range(n_haps // 2)]
+    ref = G.oracle_file_from_bits(bits, p, names)
+    region, offsets, res = G.encode_packed(packed, n_haps, p)
+    got = G.assemble_file(region, offsets, p, n_lines, n_lines, names)
+    assert got == ref
+    if 32768 <= n_haps // 2 <= 65535:
+        return
+    out, counts = G.decode_packed(got, n_haps, stride)
+    assert np.array_equal(out, packed)
+
+
+def test_all_sparse_and_all_wah_blocks():
+    """Blocks whose lines are all sparse (no PBWT work at all, chain kernels exit early) and
+    blocks whose lines are all WAH; plus a ragged last block of a single line."""
+    import gpu_util as G
+    n_haps = 5008
+    rng = np.random.default_rng(9)
+    rows = []
+    for i in range(64):   # block 0: monomorphic / singletons only -> all sparse
+        r = np.zeros(n_haps, np.uint8)
+        if i % 3:
+            r[rng.integers(0, n_haps, size=i % 4)] = 1
+        rows.append(r)
+    for i in range(64):   # block 1: common variants -> all WAH
+        rows.append((rng.random(n_haps) < 0.3 + 0.005 * i).astype(np.uint8))
+    for i in range(64):   # block 2: all-ALT and near-all-ALT lines (negated sparse)
+        r = np.ones(n_haps, np.uint8)
+        r[rng.integers(0, n_haps, size=i % 5)] = 0
+        rows.append(r)
+    rows.append((rng.random(n_haps) < 0.5).astype(np.uint8))  # block 3: one line
+    bits = np.stack(rows)
+    stride = synth.row_stride_bytes(n_haps)
+    packed = synth.pack_rows(bits, stride)
+    p = G.params(n_haps // 2, 64, 5)
+    names = ["S%d" % i for i in range(n_haps // 2)]
+    ref = G.oracle_file_from_bits(bits, p, names)
+    region, offsets, res = G.encode_packed(packed, n_haps, p)
+    assert res.n_blocks == 4
+    got = G.assemble_file(region, offsets, p, len(rows), len(rows), names)
+    assert got == ref
+    out, counts = G.decode_packed(got, n_haps, stride)
+    assert np.array_equal(out, packed)
+    assert np.array_equal(counts, bits.sum(1).astype(np.int32))
+
+
+def test_argument_errors():
+    import gpu_util as G
+    torch = G.torch_mod()
+    L = binding.lib()
+    bits, packed, stride = _mk(200, 10, 1)
+    d_bits = G.dev_u8(packed)
+    d_out = G.dev_empty(1 << 16)
+    d_off = torch.zeros(4, dtype=torch.int64, device="cuda")
+    res = binding.EncodeResult()
+    p = G.params(100, 8, 0)
+    h = G.ctx().handle
+    # zero lines, bad stride, block_len beyond the BM offset range
+    assert L.xsi_hip_encode_packed(h, ctypes.byref(p), d_bits.data_ptr(), 0, stride, d_out.data_ptr(), 1 << 16,
+                                   d_off.data_ptr(), ctypes.byref(res)) == binding.XSI_ERR_ARG
+    assert L.xsi_hip_encode_packed(h, ctypes.byref(p), d_bits.data_ptr(), 10, 12, d_out.data_ptr(), 1 << 16,
+                                   d_off.data_ptr(), ctypes.byref(res)) == binding.XSI_ERR_ARG
+    pbad = G.params(100, 40000, 0)
+    assert L.xsi_hip_encode_packed(h, ctypes.byref(pbad), d_bits.data_ptr(), 10, stride, d_out.data_ptr(), 1 << 16,
+                                   d_off.data_ptr(), ctypes.byref(res)) == binding.XSI_ERR_ARG
+    # decode: garbage image, truncated image, block range beyond the file
+    junk = G.dev_u8(np.zeros(4096, np.uint8))
+    rows = ctypes.c_uint64(0)
+    assert L.xsi_hip_decode_packed(h, junk.data_ptr(), 4096, 0, 1, d_out.data_ptr(), stride, 10, ctypes.byref(rows),
+                                   None) == binding.XSI_ERR_FORMAT
+    assert L.xsi_hip_decode_packed(h, junk.data_ptr(), 100, 0, 1, d_out.data_ptr(), stride, 10, ctypes.byref(rows),
+                                   None) == binding.XSI_ERR_FORMAT
+    ref = G.oracle_file_from_bits(bits, p)
+    d_file = G.dev_u8(np.frombuffer(ref, np.uint8))
+    assert L.xsi_hip_decode_packed(h, d_file.data_ptr(), len(ref), 1, 5, d_out.data_ptr(), stride, 100,
+                                   ctypes.byref(rows), None) == binding.XSI_ERR_ARG
+    # row capacity too small
+    assert L.xsi_hip_decode_packed(h, d_file.data_ptr(), len(ref), 0, 2, d_out.data_ptr(), stride, 3,
+                                   ctypes.byref(rows), None) == binding.XSI_ERR_CAPACITY

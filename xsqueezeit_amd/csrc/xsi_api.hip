@@ -133,11 +133,9 @@ uint64_t xsi_hip_encode_bound(const xsi_encode_params* p, uint64_t n_bcf_lines, 
     uint64_t per_line = G * 2;
     const uint64_t sp = (2ull + p->mac_threshold) * aet;
     if (sp > per_line) per_line = sp;
-    // side channels per BCF line (general path): missing + EOV lists and a phase WAH line
-    const uint64_t side = 2 * (1 + N) * aet + G * 2;
     // per block: outer dict 16, GT dict 8 + 18*8, five flag vectors, pad
     const uint64_t per_block = 16 + 8 + 18 * 8 + 5ull * FLAG_WORDS_MAX * 2 + 4;
-    return n_blocks * per_block + n_binary_lines * per_line + (n_binary_lines ? 0 : 0) + 0 * side;
+    return n_blocks * per_block + n_binary_lines * per_line;
 }
 
 int xsi_hip_make_header(const xsi_header_fields* f, uint8_t h[256]) {
