@@ -260,8 +260,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // Stable partition of `a` by the per-lane key bits; zc = zeros of my wave.  Shared by the fast
 // and the haploid paths.  `nvalid_total` = N for the haploid path (pads excluded), na otherwise.
-template <int T, int E, bool PADS_ARE_ONES>
-__device__ __forceinline__ void chain_scatter(uint16_t* a, uint32_t* wcnt, const uint32_t (&av)[E],
+template <int T, int E, bool PADS_ARE_ONES, typename AT>
+__device__ __forceinline__ void chain_scatter(AT* a, uint32_t* wcnt, const uint32_t (&av)[E],
                                               const KeyBits<E>& keys, uint32_t zc, uint32_t w, uint32_t lane,
                                               uint32_t N, uint32_t na) {
     constexpr int W = T / 64;
@@ -288,7 +288,7 @@ __device__ __forceinline__ void chain_scatter(uint16_t* a, uint32_t* wcnt, const
             const uint32_t zpre = mbcnt64(zm);
             const uint32_t opre = PADS_ARE_ONES ? lane - zpre : mbcnt64(om);
             const uint32_t dest = bit ? ob + opre : zb + zpre;
-            if (PADS_ARE_ONES || lane < nv) a[dest] = (uint16_t)av[e];
+            if (PADS_ARE_ONES || lane < nv) a[dest] = (AT)av[e];
             const uint32_t nz = (uint32_t)__popcll(zm);
             zb += nz;
             ob += (PADS_ARE_ONES ? 64u : nv) - nz;
@@ -303,12 +303,12 @@ __device__ __forceinline__ void chain_scatter(uint16_t* a, uint32_t* wcnt, const
 // of a[i] is the bit of sample a[i]/2.  Rare, kept out of line so it costs the fast path nothing.
 // LDS arrays are passed as byte offsets into the dynamic LDS segment: handing LDS pointers to an
 // out-of-line function makes hipcc (ROCm 7.2) cast them to flat and trip over its own null check.
-template <int T, int E, bool DECODE>
+template <int T, int E, bool DECODE, typename AT>
 __device__ __attribute__((noinline)) void chain_step_haploid(uint32_t a_off, uint32_t c_off, uint32_t xrow_off,
                                                              uint32_t wcnt_off, uint32_t N, uint32_t na, uint32_t cw,
                                                              uint32_t* orow, uint32_t orow_words) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t* a = reinterpret_cast<uint16_t*>(smem + a_off);
+    AT* a = reinterpret_cast<AT*>(smem + a_off);
     const uint32_t* c = reinterpret_cast<const uint32_t*>(smem + c_off);
     uint32_t* xrow = reinterpret_cast<uint32_t*>(smem + xrow_off);
     uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem + wcnt_off);
@@ -399,10 +399,13 @@ __device__ __attribute__((noinline)) void chain_step_haploid(uint32_t a_off, uin
         }
         orow[i] = v;
     }
-    chain_scatter<T, E, false>(a, wcnt, av, keys, zc, w, lane, N, na);
+    chain_scatter<T, E, false, AT>(a, wcnt, av, keys, zc, w, lane, N, na);
 }
 
-template <int T, int E, bool DECODE>
+// AT = element type of `a` in LDS: uint32_t while the array fits (N <= 32768: full-rate 32-bit
+// LDS writes in the scatter), uint16_t beyond (adjacent lanes then share a dword, measured ~2x the
+// scatter cost, but 65536 members still fit one CU's LDS).
+template <int T, int E, bool DECODE, typename AT>
 __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eblocks,
                                                  const DecBlock* __restrict__ dblocks, ChainArgs A) {
     constexpr int W = T / 64;
@@ -411,8 +414,8 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
     static_assert(E <= 64 && W <= 16, "per-lane bitfields are 64 bits wide; counts scanned in one DPP row");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t N = A.N;
-    uint16_t* a = reinterpret_cast<uint16_t*>(smem);
-    uint32_t* col = reinterpret_cast<uint32_t*>(smem + (size_t)NA * 2u);
+    AT* a = reinterpret_cast<AT*>(smem);
+    uint32_t* col = reinterpret_cast<uint32_t*>(smem + (size_t)NA * sizeof(AT));
     uint32_t* xrow = col + 2u * A.batch * CW;  // CW words (decode scatter target / haploid scratch)
     uint32_t* wcnt = xrow + CW;                // 2*W words
     uint32_t* linfo = wcnt + 2 * W;            // 3 x 16: binary line | haploid<<31, two batches ahead
@@ -433,7 +436,7 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
     }
     if (n_wah == 0) return;
 
-    for (uint32_t i = tid; i < NA; i += T) a[i] = (uint16_t)i;
+    for (uint32_t i = tid; i < NA; i += T) a[i] = (AT)i;
     for (uint32_t i = tid; i < CW; i += T) xrow[i] = 0;
 
     const uint32_t B = A.batch;
@@ -495,7 +498,7 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
     store_cols(0);
     __syncthreads();
 
-    uint16_t* aw = a + w * (E * 64u) + lane;  // my element of chunk e is aw[e*64]
+    AT* aw = a + w * (E * 64u) + lane;  // my element of chunk e is aw[e*64]
     for (uint32_t bt = 0; bt < n_batches; ++bt) {
         const bool more = bt + 1u < n_batches;
         load_info(bt + 2u);
@@ -509,7 +512,7 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
             if (info >> 31) {
                 uint32_t* orow = DECODE ? A.dst + (size_t)(line - A.out_row_base) * A.dst_stride_w
                                         : A.dst + (size_t)rank * A.dst_stride_w;
-                chain_step_haploid<T, E, DECODE>(0u, (uint32_t)((const unsigned char*)c - smem),
+                chain_step_haploid<T, E, DECODE, AT>(0u, (uint32_t)((const unsigned char*)c - smem),
                                                  (uint32_t)((unsigned char*)xrow - smem),
                                                  (uint32_t)((unsigned char*)wcnt - smem), N, NA, CW, orow,
                                                  A.dst_stride_w);
@@ -579,8 +582,9 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
             // ---- pass 2: stable scatter.  Destinations are formed directly as LDS byte addresses.
             uint32_t sc = row16_scan_incl(lane < (uint32_t)W ? wcnt[lane] : 0u);
             const uint32_t tz = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
-            uint32_t zb2 = (w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u) * 2u;
-            uint32_t ob2 = (tz + w * (E * 64u)) * 2u - zb2;  // byte address of my wave's first one
+            constexpr uint32_t AS = sizeof(AT), ASH = sizeof(AT) == 4 ? 2u : 1u;
+            uint32_t zb2 = (w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u) * AS;
+            uint32_t ob2 = (tz + w * (E * 64u)) * AS - zb2;  // byte address of my wave's first one
             unsigned char* abytes = reinterpret_cast<unsigned char*>(a);
             static_for<0, E>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
@@ -590,12 +594,12 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
                 else
                     om = __ballot(keys.template get<e>() != 0u);
                 const uint32_t zpre = mbcnt64(~om);
-                const uint32_t d0 = zb2 + (zpre << 1);
-                const uint32_t d1 = ob2 + ((lane - zpre) << 1);
+                const uint32_t d0 = zb2 + (zpre << ASH);
+                const uint32_t d1 = ob2 + ((lane - zpre) << ASH);
                 const uint32_t addr = ((om >> lane) & 1ull) ? d1 : d0;
-                *reinterpret_cast<uint16_t*>(abytes + addr) = (uint16_t)av[e];
-                const uint32_t no2 = (uint32_t)__popcll(om) * 2u;
-                zb2 += 128u - no2;
+                *reinterpret_cast<AT*>(abytes + addr) = (AT)av[e];
+                const uint32_t no2 = (uint32_t)__popcll(om) * AS;
+                zb2 += 64u * AS - no2;
                 ob2 += no2;
             });
             __syncthreads();
@@ -794,7 +798,8 @@ ChainGeom chain_geometry(uint32_t N, bool decode) {
     if (B > 16u) B = 16u;
     if (B < 1u) B = 1u;
     const uint32_t lds_max = 160u * 1024u;
-    auto need = [&](uint32_t b) { return NA * 2u + (2u * b * cw + cw + 2u * 16u + 48u) * 4u; };
+    const uint32_t asz = NA <= 32768u ? 4u : 2u;  // element size of `a` (see k_chain_lds)
+    auto need = [&](uint32_t b) { return NA * asz + (2u * b * cw + cw + 2u * 16u + 48u) * 4u; };
     while (B > 1u && need(B) > lds_max) B >>= 1;
     g.threads = T;
     g.chunks = E;
@@ -821,10 +826,11 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
     }
 #define XSI_CHAIN_CASE(TT, EE)                                                                              \
     if (g.threads == TT && g.chunks == EE) {                                                                \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_lds<TT, EE, DECODE>),     \
+        using AT = std::conditional_t<((TT) * (EE) <= 32768), uint32_t, uint16_t>;                          \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_lds<TT, EE, DECODE, AT>), \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);   \
         if (e != hipSuccess) return e;                                                                      \
-        k_chain_lds<TT, EE, DECODE><<<dim3(n_blocks), dim3(TT), g.lds_bytes, s>>>(eb, db, A);               \
+        k_chain_lds<TT, EE, DECODE, AT><<<dim3(n_blocks), dim3(TT), g.lds_bytes, s>>>(eb, db, A);           \
         return hipGetLastError();                                                                           \
     }
     XSI_CHAIN_CASE(256, 1)
