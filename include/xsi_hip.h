@@ -73,7 +73,8 @@ typedef struct xsi_encode_params {
     uint32_t mac_threshold;      /* (size_t)(n_samples*ploidy*MAF), gt_compressor_new.hpp:98-99 */
     int32_t default_phased;      /* 0/1, xcf.cpp:811-836 */
     uint32_t wah_encode_missing; /* 0 = WS_SPARSE (default), 1 = WS_WAH (--wah-encode-missing) */
-    uint32_t reserved;
+    uint32_t zstd_level;         /* file writer only: 0 = no zstd layer, else --zstd with this --zl level
+                                    (reference default 7, include/xsqueezeit.hpp); block calls ignore it */
 } xsi_encode_params;
 
 /* Result of an encode call (host struct, filled after the stream is synchronised). */
@@ -83,7 +84,7 @@ typedef struct xsi_encode_result {
     uint64_t n_binary_lines;
     uint64_t n_wah_lines;
     uint32_t max_ploidy;    /* max line ploidy seen (for finalize_file(max_ploidy)) */
-    uint32_t reserved;
+    uint32_t last_block_bytes; /* bytes of the last block before its pad to 4 (what the zstd layer compresses) */
 } xsi_encode_result;
 
 /* Upper bound of the blocks region for a job, for sizing d_out. */

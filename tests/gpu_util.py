@@ -45,7 +45,7 @@ def dev_empty(nbytes):
 
 
 def params(n_samples, block_len=8192, mac_thr=0, default_phased=1, wah_encode_missing=0):
-    return binding.EncodeParams(n_samples, block_len, mac_thr, default_phased, wah_encode_missing, 0)
+    return binding.EncodeParams(n_samples, block_len, mac_thr, default_phased, wah_encode_missing, 0)  # zstd_level=0
 
 
 def encode_packed(packed, n_haps, p):

@@ -239,3 +239,68 @@ def test_allele_counts_without_expansion(tmp_path):
     assert r == 2 * n and np.array_equal(buf, lines[3][0])
     binding.check(L.xsi_accessor_fill_allele_counts(a, lines[0][1], 0))
     L.xsi_accessor_close(a)
+
+
+def test_zstd_layer_roundtrip(tmp_path):
+    """--zstd files (BlockWithZstdCompressor, interfaces.hpp:288-315): u64 sizes + one zstd frame per
+    block.  The inflated blocks equal the plain file's blocks byte for byte, and the accessor reads
+    the compressed file back.  (Frame bytes themselves depend on the libzstd version, as they do for
+    the reference, so they are not pinned.)"""
+    import struct
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    try:
+        Z = ctypes.CDLL("libzstd.so.1")
+    except OSError:
+        pytest.skip("no libzstd.so.1 on this box")
+    Z.ZSTD_decompress.restype = ctypes.c_size_t
+    Z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    rng = np.random.default_rng(77)
+    n, n_lines, block_len = 100, 600, 256
+    lines = _random_lines(rng, n, n_lines, multi=True, missing=True)
+    dp = oracle.default_phased_of(lines, n)
+    names = ["s%d" % i for i in range(n)]
+    plain = oracle.encode_file(lines, n, block_len=block_len, mac_thr=2, default_phased=dp, sample_names=names)
+    path = str(tmp_path / "z.xsi").encode()
+    p = G.params(n, block_len, 2, dp)
+    p.zstd_level = 7
+    w = ctypes.c_void_p()
+    arr = (ctypes.c_char_p * n)(*[s.encode() for s in names])
+    binding.check(L.xsi_writer_open(ctypes.byref(w), G.ctx().handle, path, ctypes.byref(p), arr))
+    for gt, na in lines:
+        gt = np.ascontiguousarray(gt, dtype=np.int32)
+        binding.check(L.xsi_writer_append(w, gt.ctypes.data, gt.size, na))
+    binding.check(L.xsi_writer_finalize(w, 0))
+    L.xsi_writer_close(w)
+    z = open(path, "rb").read()
+    assert z[17] & 4, "zstd bit of the header"
+    assert len(z) < len(plain)
+    # inflate every block and compare with the plain file's block
+    zio, zso = struct.unpack_from("<QQ", z, 72)
+    pio, pso = struct.unpack_from("<QQ", plain, 72)
+    zoffs = np.frombuffer(z, "<u8", (zso - zio) // 8, zio)
+    poffs = list(np.frombuffer(plain, "<u8", (pso - pio) // 8, pio)) + [pio]
+    assert len(zoffs) == len(poffs) - 1
+    for b, off in enumerate(zoffs):
+        csize, usize = struct.unpack_from("<QQ", z, int(off))
+        out = ctypes.create_string_buffer(usize)
+        src = z[int(off) + 16:int(off) + 16 + csize]
+        r = Z.ZSTD_decompress(out, usize, src, csize)
+        assert r == usize
+        assert out.raw == plain[int(poffs[b]):int(poffs[b]) + usize], "block %d" % b
+        assert int(poffs[b + 1]) - int(poffs[b]) - usize < 8
+    # read the compressed file back
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, path))
+    buf = np.zeros(2 * n, dtype=np.int32)
+    block = off = 0
+    for i, (gt, na) in enumerate(lines):
+        if i and i % block_len == 0:
+            block += 1
+            off = 0
+        r = L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, na, (block << 15) | off)
+        assert r == len(gt) and np.array_equal(buf[:r], gt), "line %d" % i
+        off += na - 1
+    binding.check(L.xsi_accessor_fill_allele_counts(a, lines[0][1], 0))
+    L.xsi_accessor_close(a)

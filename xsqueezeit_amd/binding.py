@@ -23,13 +23,13 @@ class XsiError(RuntimeError):
 class EncodeParams(ctypes.Structure):
     _fields_ = [("n_samples", ctypes.c_uint32), ("block_len", ctypes.c_uint32), ("mac_threshold", ctypes.c_uint32),
                 ("default_phased", ctypes.c_int32), ("wah_encode_missing", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32)]
+                ("zstd_level", ctypes.c_uint32)]
 
 
 class EncodeResult(ctypes.Structure):
     _fields_ = [("n_blocks", ctypes.c_uint64), ("blocks_bytes", ctypes.c_uint64),
                 ("n_binary_lines", ctypes.c_uint64), ("n_wah_lines", ctypes.c_uint64),
-                ("max_ploidy", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("max_ploidy", ctypes.c_uint32), ("last_block_bytes", ctypes.c_uint32)]
 
 
 class HeaderFields(ctypes.Structure):

@@ -299,7 +299,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
         if (rc) return rc;
     }
     stage_mark(ctx, -1);
-    uint64_t res[4];
+    uint64_t res[5];
     HIP_TRY(hipMemcpyAsync(res, d_result, sizeof(res), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     stage_collect(ctx);
@@ -311,7 +311,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
         h_result->n_binary_lines = n_bin;
         h_result->n_wah_lines = res[2];
         h_result->max_ploidy = 2;
-        h_result->reserved = 0;
+        h_result->last_block_bytes = (uint32_t)res[4];
     }
     return XSI_OK;
 }

@@ -31,6 +31,37 @@ using namespace xsi;
     } while (0)
 
 // ------------------------------------------------------------------------------------------
+// optional zstd layer (BlockWithZstdCompressor, interfaces.hpp:288-315; set_block_ptr,
+// accessor_internals_new.hpp:857-886).  Host-side, like the reference.  libzstd is bound at run
+// time (no zstd headers in the build image); without it --zstd files are refused.
+// ------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+namespace {
+struct ZstdApi {
+    size_t (*compress)(void*, size_t, const void*, size_t, int) = nullptr;
+    size_t (*decompress)(void*, size_t, const void*, size_t) = nullptr;
+    unsigned (*is_error)(size_t) = nullptr;
+    const char* (*error_name)(size_t) = nullptr;
+    bool ok = false;
+};
+const ZstdApi& zstd_api() {
+    static ZstdApi z = [] {
+        ZstdApi a;
+        void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libzstd.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+        a.compress = reinterpret_cast<decltype(a.compress)>(dlsym(h, "ZSTD_compress"));
+        a.decompress = reinterpret_cast<decltype(a.decompress)>(dlsym(h, "ZSTD_decompress"));
+        a.is_error = reinterpret_cast<decltype(a.is_error)>(dlsym(h, "ZSTD_isError"));
+        a.error_name = reinterpret_cast<decltype(a.error_name)>(dlsym(h, "ZSTD_getErrorName"));
+        a.ok = a.compress && a.decompress && a.is_error;
+        return a;
+    }();
+    return z;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
 // writer
 // ------------------------------------------------------------------------------------------
 struct xsi_writer {
@@ -84,8 +115,25 @@ static int writer_flush_block(xsi_writer* w) {
     w->h_out.resize(res.blocks_bytes);
     HIP_TRY(hipMemcpy(w->h_out.data(), w->d_out, res.blocks_bytes, hipMemcpyDeviceToHost));
     w->indices.push_back(w->file_pos);  // xsi_factory.hpp:533
-    if (fwrite(w->h_out.data(), 1, w->h_out.size(), w->f) != w->h_out.size()) return set_error(XSI_ERR_IO, "short write");
-    w->file_pos += w->h_out.size();
+    if (w->p.zstd_level) {
+        // compress_and_write, interfaces.hpp:291-314: u64 compressed size, u64 original size, frame; pad to 4
+        const ZstdApi& z = zstd_api();
+        const uint64_t usize = res.last_block_bytes;  // the block as streamed, before its pad
+        std::vector<uint8_t> frame((size_t)usize * 2 + 64);
+        const size_t csize = z.compress(frame.data(), frame.size(), w->h_out.data(), (size_t)usize, (int)w->p.zstd_level);
+        if (z.is_error(csize)) return set_error(XSI_ERR_IO, "Failed to compress block: %s", z.error_name ? z.error_name(csize) : "zstd");
+        const uint64_t c64 = csize;
+        if (fwrite(&c64, 8, 1, w->f) != 1 || fwrite(&usize, 8, 1, w->f) != 1 || fwrite(frame.data(), 1, csize, w->f) != csize)
+            return set_error(XSI_ERR_IO, "short write");
+        w->file_pos += 16 + csize;
+        while (w->file_pos % 4) {
+            fputc(0, w->f);
+            w->file_pos++;
+        }
+    } else {
+        if (fwrite(w->h_out.data(), 1, w->h_out.size(), w->f) != w->h_out.size()) return set_error(XSI_ERR_IO, "short write");
+        w->file_pos += w->h_out.size();
+    }
     w->lines_in_block = w->lines_on_device = 0;
     w->ngt.clear();
     w->n_allele.clear();
@@ -112,6 +160,7 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
     if (!out || !ctx || !path || !p) return set_error(XSI_ERR_ARG, "writer_open: null argument");
     if (!p->n_samples || !p->block_len || p->block_len > MAX_BIN_PER_BLOCK)
         return set_error(XSI_ERR_ARG, "writer_open: bad n_samples / block_len");
+    if (p->zstd_level && !zstd_api().ok) return set_error(XSI_ERR_UNSUPPORTED, "--zstd requested but libzstd.so.1 could not be loaded");
     HIP_TRY(hipSetDevice(ctx->device));
     xsi_writer* w = new xsi_writer();
     w->ctx = ctx;
@@ -188,7 +237,7 @@ int xsi_writer_finalize(xsi_writer* w, uint32_t max_ploidy) {
     hf.block_len = w->p.block_len;
     hf.mac_threshold = w->p.mac_threshold;
     hf.default_phased = w->p.default_phased;
-    hf.zstd = 0;
+    hf.zstd = w->p.zstd_level ? 1 : 0;
     hf.num_variants = w->variant_counter;
     hf.xcf_entries = w->entry_counter;
     hf.indices_offset = w->file_pos;
@@ -233,6 +282,11 @@ struct xsi_accessor {
     DecodePlan P;
     DecodedPlanes D;
     bool biallelic = false;
+    // zstd files: every block is inflated on the host into a one-block image (header + block + index)
+    bool zstd = false;
+    std::vector<uint8_t> mini;
+    uint8_t* d_mini = nullptr;
+    size_t d_mini_cap = 0;
     // counts-only view of a block (fill_allele_counts never expands genotypes)
     int64_t cnt_block = -1;
     std::vector<uint32_t> cnt_ones;
@@ -249,12 +303,67 @@ struct xsi_accessor {
     std::vector<uint64_t> last_counts;
 };
 
-static int accessor_load_block(xsi_accessor* a, uint64_t block) {
+// Device image + block number to hand the decoder for file block `block` (set_block_ptr,
+// accessor_internals_new.hpp:845-893).  Plain files: the whole file already sits in HBM.  zstd files:
+// inflate the block on the host (ZSTD_decompress) and upload a one-block image.
+static int accessor_block_image(xsi_accessor* a, uint64_t block, const uint8_t** d_img, uint64_t* len, uint64_t* blk) {
     if (block >= a->n_blocks) return set_error(XSI_ERR_ARG, "block %llu beyond the %llu blocks of the file",
                                                (unsigned long long)block, (unsigned long long)a->n_blocks);
-    int rc = decode_prepare(a->ctx, a->d_file, a->file.size(), block, 1, &a->P);
+    if (!a->zstd) {
+        *d_img = a->d_file;
+        *len = a->file.size();
+        *blk = block;
+        return XSI_OK;
+    }
+    const uint8_t* h = a->file.data();
+    auto get = [&](size_t off, int bytes) {
+        uint64_t v = 0;
+        for (int i = 0; i < bytes; ++i) v |= (uint64_t)h[off + i] << (8 * i);
+        return v;
+    };
+    const uint64_t io = get(72, 8);
+    const uint64_t off = a->version >= 5 ? get(io + block * 8, 8) : get(io + block * 4, 4);
+    const int sz = a->version >= 5 ? 8 : 4;
+    if (off + 2 * sz > a->file.size()) return set_error(XSI_ERR_FORMAT, "block offset outside the file");
+    const uint64_t csize = get(off, sz), usize = get(off + sz, sz);
+    if (off + 2 * sz + csize > a->file.size() || usize > (1ull << 34)) return set_error(XSI_ERR_FORMAT, "corrupt zstd block header");
+    const ZstdApi& z = zstd_api();
+    if (!z.ok) return set_error(XSI_ERR_UNSUPPORTED, "zstd-compressed file but libzstd.so.1 could not be loaded");
+    size_t body = (size_t)usize;
+    while ((256 + body) % 8) body++;
+    a->mini.assign(256 + body + 8, 0);
+    memcpy(a->mini.data(), h, 256);
+    a->mini[17] &= (uint8_t)~4u;  // the image handed to the GPU is not compressed
+    const size_t r = z.decompress(a->mini.data() + 256, (size_t)usize, h + off + 2 * sz, (size_t)csize);
+    if (z.is_error(r) || r != usize) return set_error(XSI_ERR_FORMAT, "Failed to decompress block");
+    auto put = [&](size_t o, uint64_t v, int bytes) {
+        for (int i = 0; i < bytes; ++i) a->mini[o + i] = (uint8_t)(v >> (8 * i));
+    };
+    put(8, 5, 4);  // the one-block image always carries a u64 index
+    put(72, 256 + body, 8);
+    put(80, 256 + body + 8, 8);
+    put(256 + body, 256, 8);
+    if (a->mini.size() > a->d_mini_cap) {
+        if (a->d_mini) (void)hipFree(a->d_mini);
+        a->d_mini = nullptr;
+        a->d_mini_cap = a->mini.size() + a->mini.size() / 4;
+        HIP_TRY(hipMalloc((void**)&a->d_mini, a->d_mini_cap));
+    }
+    HIP_TRY(hipMemcpy(a->d_mini, a->mini.data(), a->mini.size(), hipMemcpyHostToDevice));
+    *d_img = a->d_mini;
+    *len = a->mini.size();
+    *blk = 0;
+    return XSI_OK;
+}
+
+static int accessor_load_block(xsi_accessor* a, uint64_t block) {
+    const uint8_t* img;
+    uint64_t len, blk;
+    int rc = accessor_block_image(a, block, &img, &len, &blk);
     if (rc) return rc;
-    rc = decode_all_planes(a->ctx, a->d_file, a->P, &a->D);
+    rc = decode_prepare(a->ctx, img, len, blk, 1, &a->P);
+    if (rc) return rc;
+    rc = decode_all_planes(a->ctx, img, a->P, &a->D);
     if (rc) return rc;
     a->biallelic = a->P.n_bin == a->P.n_bcf;
     a->cur_block = (int64_t)block;
@@ -342,9 +451,10 @@ int xsi_accessor_open(xsi_accessor** out, xsi_hip_ctx* ctx, const char* path) {
         delete a;
         return set_error(XSI_ERR_FORMAT, "PLOIDY ERROR");
     }
-    if (h[17] & 4u) {
+    a->zstd = (h[17] & 4u) != 0;
+    if (a->zstd && !zstd_api().ok) {
         delete a;
-        return set_error(XSI_ERR_UNSUPPORTED, "zstd-compressed .xsi files are not supported yet");
+        return set_error(XSI_ERR_UNSUPPORTED, "zstd-compressed file but libzstd.so.1 could not be loaded");
     }
     const uint64_t io = get(72, 8), so = get(80, 8);
     if (io > (uint64_t)sz || so > (uint64_t)sz || so < io) {
@@ -368,8 +478,11 @@ int xsi_accessor_open(xsi_accessor** out, xsi_hip_ctx* ctx, const char* path) {
         delete a;
         return rc;
     }
-    hipError_t e = hipMalloc((void**)&a->d_file, (size_t)sz);
-    if (e == hipSuccess) e = hipMemcpy(a->d_file, h, (size_t)sz, hipMemcpyHostToDevice);
+    hipError_t e = hipSuccess;
+    if (!a->zstd) {
+        e = hipMalloc((void**)&a->d_file, (size_t)sz);
+        if (e == hipSuccess) e = hipMemcpy(a->d_file, h, (size_t)sz, hipMemcpyHostToDevice);
+    }
     const uint64_t N = a->num_samples ? a->num_samples * 2 : a->hap_samples;
     // window of composed rows: <= 64 MiB of int32
     uint64_t win = N ? (64ull << 20) / (N * 4) : 1;
@@ -444,11 +557,14 @@ int xsi_accessor_fill_allele_counts(xsi_accessor* a, uint32_t n_alleles, uint64_
     const uint64_t block = (position & 0xFFFFFFFFull) >> BM_BLOCK_BITS;
     const uint32_t offset = (uint32_t)(position & ((1u << BM_BLOCK_BITS) - 1u));
     if (a->cnt_block < 0 || (uint64_t)a->cnt_block != block) {
-        if (block >= a->n_blocks) return set_error(XSI_ERR_ARG, "block %llu beyond the file", (unsigned long long)block);
         DecodePlan P;
-        int rc = decode_prepare(a->ctx, a->d_file, a->file.size(), block, 1, &P);
+        const uint8_t* img;
+        uint64_t len, blk;
+        int rc = accessor_block_image(a, block, &img, &len, &blk);
         if (rc) return rc;
-        rc = decode_counts_only(a->ctx, a->d_file, P);
+        rc = decode_prepare(a->ctx, img, len, blk, 1, &P);
+        if (rc) return rc;
+        rc = decode_counts_only(a->ctx, img, P);
         if (rc) return rc;
         a->cnt_ones.resize(P.n_bin);
         a->cnt_kind.resize(P.n_bin);
@@ -490,6 +606,7 @@ void xsi_accessor_close(xsi_accessor* a) {
     if (!a) return;
     if (a->ctx) (void)hipStreamSynchronize(a->ctx->stream);
     if (a->d_file) (void)hipFree(a->d_file);
+    if (a->d_mini) (void)hipFree(a->d_mini);
     if (a->d_rows) (void)hipFree(a->d_rows);
     if (a->h_rows) (void)hipHostFree(a->h_rows);
     if (a->d_counts) (void)hipFree(a->d_counts);

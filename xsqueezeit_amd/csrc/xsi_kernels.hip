@@ -1428,6 +1428,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks_out(EncBlock* __restrict__
         d_result[1] = n_blocks;
         d_result[2] = wah;
         d_result[3] = base > capacity ? 1u : 0u;
+        d_result[4] = n_blocks ? 16u + blocks[n_blocks - 1u].gt_bytes : 0u;
     }
 }
 
