@@ -24,6 +24,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md "Chip-level
 
 
 def main():
+    # Libraries (RCCL prints a version banner) write to stdout; the contract is ONE JSON line there.
+    # Park the real stdout and point fd 1 at stderr until the line is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -35,6 +40,8 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-sample-sites", type=int, default=98304, help="sites of the CPU-oracle baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-rank code path (process group + RCCL gather) even with one rank (testing)")
     args = ap.parse_args()
 
     import torch
@@ -45,7 +52,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     if distributed:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -232,7 +239,8 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
     if distributed:
         tdist.destroy_process_group()
