@@ -76,28 +76,30 @@ def test_general_encode_bit_exact_and_decode(n_samples, n_lines, block_len, maf,
         assert np.array_equal(counts[i][:nal[i]], oref[i][1]), "allele counts line %d" % i
 
 
-def test_haploid_and_mixed_lines():
-    """Fully haploid lines interleaved with diploid ones (mixed-ploidy chrX-like input)."""
+@pytest.mark.parametrize("n,n_lines,block_len", [(60, 240, 64), (1600, 160, 64), (2504, 96, 32), (70000, 24, 8)])
+def test_haploid_and_mixed_lines(n, n_lines, block_len):
+    """Fully haploid lines interleaved with diploid ones (mixed-ploidy chrX-like input), through the
+    256-thread, the 1024-thread and the global-memory chain kernels."""
     import gpu_util as G
     from oracle import oracle
-    rng = np.random.default_rng(11)
-    n = 60
+    rng = np.random.default_rng(11 + n)
     lines = []
-    for i in range(240):
+    for i in range(n_lines):
         if i % 5 == 3:
             al = (rng.random(n) < 0.3).astype(np.int32)
             lines.append((((al + 1) << 1).astype(np.int32), 2))
         else:
             lines.extend(_random_lines(rng, n, 1, eov=(i % 7 == 0)))
     dp = oracle.default_phased_of(lines, n)
-    p = G.params(n, 64, 0, dp)
-    ref = oracle.encode_file(lines, n, block_len=64, mac_thr=0, default_phased=dp)
+    thr = n // 500
+    p = G.params(n, block_len, thr, dp)
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=thr, default_phased=dp)
     region, offsets, res = G.encode_gt(lines, n, p)
     got = G.assemble_file(region, offsets, p, len(lines), G.num_variants(lines), ["S%d" % i for i in range(n)], 2)
     assert got == ref
     nal = [na for _, na in lines]
     rows, _ = G.decode_gt(got, nal)
-    oref = oracle.decode_file(ref, nal, block_len=64)
+    oref = oracle.decode_file(ref, nal, block_len=block_len)
     for i in range(len(lines)):
         assert np.array_equal(rows[i], oref[i][0]), "line %d" % i
 
