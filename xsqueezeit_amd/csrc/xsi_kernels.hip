@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
                     }
                     if (!MASKS_IN_SGPR) keys.template set<e>(bit);
                 }
-                if (MASKS_IN_SGPR) ms[e] = m;
+                if constexpr (MASKS_IN_SGPR) ms[e] = m;
                 ones += (uint32_t)__popcll(m);
             });
             if (!DECODE) {
@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
             static_for<0, E>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
                 uint64_t om;
-                if (MASKS_IN_SGPR)
+                if constexpr (MASKS_IN_SGPR)
                     om = ms[e];
                 else
                     om = __ballot(keys.template get<e>() != 0u);
@@ -754,6 +754,189 @@ __global__ void __launch_bounds__(1024) k_chain_global(const EncBlock* __restric
     }
 }
 
+// Streaming variant of the encode chain for N > 65536 (blocks without fully haploid lines).
+// Still one workgroup per block with `a` ping-ponged in HBM/L2, but `a` is read ONCE per line:
+//   * wave w owns the positions of segment w (segments are 2^seg_shift positions);
+//   * the per-segment zero counts a line needs before it can scatter are accumulated one line
+//     ahead: while line t moves member v to position d of a_t, the wave also looks up v's bit on
+//     line t+1 and adds its zero to the counter of d's segment (both bit rows sit in LDS);
+//   * U chunks of 64 positions are loaded before the first is used, so a wave keeps U global
+//     loads in flight instead of one.
+// Per line: one pass over `a` (4 B read + 4 B written per member), two barriers.
+constexpr int STREAM_U = 8;
+constexpr int STREAM_ROW_REGS = 20;  // row words per thread: N <= 1024*20*32
+
+__global__ void __launch_bounds__(1024) k_chain_stream(const EncBlock* __restrict__ eblocks, ChainArgs A,
+                                                       uint32_t* __restrict__ scratch_a, uint32_t SS) {
+    constexpr uint32_t T = 1024, W = 16, U = STREAM_U;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t N = A.N, cw = A.cw;
+    uint32_t* rows = reinterpret_cast<uint32_t*>(smem);  // [2][cw]
+    uint32_t* zc = rows + 2u * cw;                       // [3][W] zero counts per segment, rotating
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    if (eblocks[blockIdx.x].has_haploid) return;  // k_chain_global handles those blocks
+    const uint32_t wah_first = eblocks[blockIdx.x].wah_first;
+    const uint32_t n_wah = eblocks[blockIdx.x].n_wah;
+    if (n_wah == 0) return;
+    const size_t na = ((size_t)N + 63u) & ~(size_t)63u;
+    uint32_t* a0 = scratch_a + (size_t)blockIdx.x * 2u * na;
+    uint32_t* a1 = a0 + na;
+    const uint32_t src_words = (N + 31u) >> 5;
+    const uint32_t tail_mask = (N & 31u) ? ((1u << (N & 31u)) - 1u) : ~0u;
+    auto load_word = [&](const uint32_t* srow, uint32_t i) -> uint32_t {
+        const uint32_t v = srow[i < src_words ? i : 0u];
+        return i >= src_words ? 0u : (i == src_words - 1u ? (v & tail_mask) : v);
+    };
+    for (uint32_t i = tid; i < N; i += T) a0[i] = i;
+    {
+        const uint32_t* r0 = A.src + (size_t)A.wah_lines[wah_first] * A.src_stride_w;
+        for (uint32_t i = tid; i < cw; i += T) rows[i] = load_word(r0, i);
+        if (n_wah > 1) {
+            const uint32_t* r1 = A.src + (size_t)A.wah_lines[wah_first + 1u] * A.src_stride_w;
+            for (uint32_t i = tid; i < cw; i += T) rows[cw + i] = load_word(r1, i);
+        }
+    }
+    if (tid < 3u * W) zc[tid] = 0;
+    // wave w owns positions [w*SS, (w+1)*SS) (SS is a multiple of 64)
+    const uint32_t p_lo = w * SS < N ? w * SS : N;
+    const uint32_t p_hi = (w + 1u) * SS < N ? (w + 1u) * SS : N;
+    const uint32_t n_full = (p_hi - p_lo) / (64u * U);  // groups of U full chunks
+    __threadfence_block();
+    __syncthreads();
+    {
+        // a_0 is the identity: zeros of the first line per segment straight from its row
+        uint32_t ones = 0;
+        const uint32_t w_hi = p_hi > p_lo ? (p_hi + 31u) >> 5 : 0u;  // empty segment: nothing to count
+        for (uint32_t i = (p_lo >> 5) + lane; i < w_hi; i += 64u) ones += (uint32_t)__popc(rows[i]);
+        ones = wave_sum(ones);
+        if (lane == 0) zc[w] = (p_hi - p_lo) - ones;
+    }
+    for (uint32_t j = 0; j < n_wah; ++j) {
+        const uint32_t rank = wah_first + j;
+        const unsigned char* rcur = reinterpret_cast<const unsigned char*>(rows + (j & 1u) * cw);
+        // last line: no look-ahead needed; point it at the current row so the code stays branch-free
+        const unsigned char* rnxt =
+            reinterpret_cast<const unsigned char*>(rows + ((j + 1u < n_wah ? j + 1u : j) & 1u) * cw);
+        const bool has_next2 = j + 2u < n_wah;
+        uint32_t* zcur = zc + (j % 3u) * W;
+        uint32_t* znxt = zc + ((j + 1u) % 3u) * W;
+        uint32_t* zclr = zc + ((j + 2u) % 3u) * W;
+        __syncthreads();  // rows, zcur and a_in complete
+        // row of line j+2 -> registers now, -> LDS after this line (its buffer is still in use)
+        uint32_t pre[STREAM_ROW_REGS];
+        if (has_next2) {
+            const uint32_t* r2 = A.src + (size_t)A.wah_lines[rank + 2u] * A.src_stride_w;
+#pragma unroll
+            for (int k = 0; k < STREAM_ROW_REGS; ++k) pre[k] = load_word(r2, (uint32_t)k * T + tid);
+        }
+        if (tid < W) zclr[tid] = 0;
+        uint32_t zb = 0, tz = 0;
+        {
+            const uint32_t c = lane < W ? zcur[lane] : 0u;
+            const uint32_t sc = row16_scan_incl(c);
+            tz = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
+            zb = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
+        }
+        uint32_t ob = tz + (p_lo - zb);  // destination of my segment's first one
+        const uint32_t* ain = (j & 1u) ? a1 : a0;
+        uint32_t* aout = (j & 1u) ? a0 : a1;
+        uint2* yr = reinterpret_cast<uint2*>(A.dst + (size_t)rank * A.dst_stride_w);
+        // look-ahead accumulators: zeros of line j+1 among the members I move, per destination segment
+        uint32_t zseg = zb / SS, zacc = 0, zbound = (zseg + 1u) * SS;
+        uint32_t oseg = ob / SS, oacc = 0, obound = (oseg + 1u) * SS;
+
+        // one chunk of 64 positions starting at cb whose members are vv; returns the chunk's y bits
+        auto step = [&](auto full_tag, uint32_t cb, uint32_t vv) -> uint64_t {
+            constexpr bool FULL = decltype(full_tag)::value;
+            const bool valid = FULL || (cb + lane < p_hi);  // valid lanes are a prefix of the wave
+            const uint32_t woff = (vv >> 3) & ~3u;          // byte offset of the word holding bit vv
+            uint32_t bit = __builtin_amdgcn_ubfe(*reinterpret_cast<const uint32_t*>(rcur + woff), vv, 1u);
+            uint32_t nbit = __builtin_amdgcn_ubfe(*reinterpret_cast<const uint32_t*>(rnxt + woff), vv, 1u);
+            if (!FULL && !valid) {
+                bit = 0;
+                nbit = 1;
+            }
+            const uint64_t vm = FULL ? ~0ull : __ballot(valid);
+            const uint64_t om = __ballot(bit != 0u), zm = ~om & vm;
+            const uint64_t nz = __ballot(nbit == 0u);  // members whose bit on the next line is 0
+            const uint32_t zpre = mbcnt64(zm);
+            const uint32_t dest = bit ? ob + (lane - zpre) : zb + zpre;
+            if (FULL || valid) aout[dest] = vv;
+            const uint32_t nzc = (uint32_t)__popcll(zm), noc = (uint32_t)__popcll(om);
+            if (zb + nzc > zbound) {  // the zeros of this chunk cross into the next segment (rare)
+                const uint64_t hi = __ballot(valid && !bit && dest >= zbound);
+                zacc += (uint32_t)__popcll(nz & zm & ~hi);
+                if (lane == 0 && zacc) atomicAdd(&znxt[zseg], zacc);
+                ++zseg;
+                zbound += SS;
+                zacc = (uint32_t)__popcll(nz & hi);
+            } else {
+                zacc += (uint32_t)__popcll(nz & zm);
+            }
+            if (ob + noc > obound) {
+                const uint64_t hi = __ballot(valid && bit && dest >= obound);
+                oacc += (uint32_t)__popcll(nz & om & ~hi);
+                if (lane == 0 && oacc) atomicAdd(&znxt[oseg], oacc);
+                ++oseg;
+                obound += SS;
+                oacc = (uint32_t)__popcll(nz & hi);
+            } else {
+                oacc += (uint32_t)__popcll(nz & om);
+            }
+            zb += nzc;
+            ob += noc;
+            return om;
+        };
+
+        uint32_t base = p_lo;
+        uint32_t vn[U];
+        if (n_full) {
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) vn[u] = ain[base + u * 64u + lane];
+        }
+        for (uint32_t g = 0; g < n_full; ++g, base += 64u * U) {
+            uint32_t v[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) v[u] = vn[u];
+            if (g + 1u < n_full) {
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) vn[u] = ain[base + (U + u) * 64u + lane];
+            }
+            uint32_t mine_lo = 0, mine_hi = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint64_t om = step(std::true_type{}, base + u * 64u, v[u]);
+                if (lane == u) {
+                    mine_lo = (uint32_t)om;
+                    mine_hi = (uint32_t)(om >> 32);
+                }
+            }
+            if (lane < U) yr[(base >> 6) + lane] = make_uint2(mine_lo, mine_hi);
+        }
+        for (; base < p_hi; base += 64u) {
+            const uint32_t idx = base + lane;
+            const uint32_t vv = idx < p_hi ? ain[idx] : 0u;
+            const uint64_t om = step(std::false_type{}, base, vv);
+            if (lane == 0) yr[base >> 6] = make_uint2((uint32_t)om, (uint32_t)(om >> 32));
+        }
+        if (lane == 0) {
+            if (zacc) atomicAdd(&znxt[zseg], zacc);
+            if (oacc) atomicAdd(&znxt[oseg], oacc);
+        }
+        __threadfence_block();
+        __syncthreads();  // everyone is done with rcur
+        if (has_next2) {
+            uint32_t* rdst = rows + (j & 1u) * cw;
+#pragma unroll
+            for (int k = 0; k < STREAM_ROW_REGS; ++k) {
+                const uint32_t i = (uint32_t)k * T + tid;
+                if (i < cw) rdst[i] = pre[k];
+            }
+        }
+    }
+}
+
 static uint32_t next_pow2_log2(uint32_t v) {
     uint32_t l = 0;
     while ((1u << l) < v) ++l;
@@ -818,6 +1001,21 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
     A.batch = g.batch;
     if (!g.in_lds) {
         if (!scratch_a) return hipErrorInvalidValue;
+        // encode: A.only_haploid_blocks arrives as "some block has fully haploid lines"
+        const bool any_haploid = A.only_haploid_blocks != 0;
+        if (!DECODE) A.only_haploid_blocks = 0;
+        if (!DECODE && A.cw <= 1024u * STREAM_ROW_REGS && !getenv("XSI_NO_STREAM_CHAIN")) {
+            // streaming kernel for the blocks without fully haploid lines, the two-pass kernel for the rest
+            const uint32_t seg = (((A.N + 15u) / 16u) + 63u) & ~63u;  // positions per wave
+            const uint32_t lds = (2u * A.cw + 3u * 16u) * 4u;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_stream),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            k_chain_stream<<<dim3(n_blocks), dim3(1024), lds, s>>>(eb, A, scratch_a, seg);
+            e = hipGetLastError();
+            if (e != hipSuccess || !any_haploid) return e;
+            A.only_haploid_blocks = 1;
+        }
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_global<DECODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
         if (e != hipSuccess) return e;
@@ -1028,6 +1226,112 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
     }
 }
 
+// Long rows (65536 < N <= 1024*RANK_BIG_RP*32): one {bits, prefix} row at a time in LDS (up to
+// 160 KB), the next row prefetched into registers while the current one is used.  A gather from
+// LDS serves 64 lanes in a few cycles; the same gather from L2 is one request per lane (~1 lane
+// per clock per CU), which is what bounded the unstaged path.  Each workgroup covers 16*E chunks
+// of haplotypes; grid = (splits, blocks) so the splits of one block are dispatched together and
+// share the row through L2.
+constexpr int RANK_BIG_RP = 20;
+
+template <int E>
+__global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
+    constexpr int T = 1024, W = 16, G = 8;  // G: gathers in flight per wave
+    static_assert(E % G == 0, "E must be a multiple of the gather group");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DecBlock& D = A.blocks[blockIdx.y];
+    if (D.error || D.n_wah == 0 || D.off_line_haploid != VAL_UNDEFINED) return;
+    const uint32_t N = A.N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t cg0 = (blockIdx.x * W + w) * E;  // first chunk of my wave
+    const uint32_t wah_first = D.wah_first, n_wah = D.n_wah;
+    const uint32_t CWP = A.yp_stride;
+    uint2* row = reinterpret_cast<uint2*>(smem);
+
+    uint32_t r[E];
+    static_for<0, E>([&](auto ecn) {
+        constexpr int e = decltype(ecn)::value;
+        r[e] = (cg0 + (uint32_t)e) * 64u + lane;
+        if (r[e] >= N) r[e] = 0;
+    });
+    uint32_t vm_lo = 0, vm_hi = 0;
+    {
+        const uint64_t base = (uint64_t)(cg0 + lane) * 64u;
+        if (lane < (uint32_t)E && base < N) {
+            const uint32_t nv = (N - base >= 64u) ? 64u : (uint32_t)(N - base);
+            const uint64_t vm = nv == 64u ? ~0ull : ((1ull << nv) - 1ull);
+            vm_lo = (uint32_t)vm;
+            vm_hi = (uint32_t)(vm >> 32);
+        }
+    }
+    const bool store_lane = lane < (uint32_t)E && (uint64_t)(cg0 + lane) * 64u < N;
+    const uint32_t row_words = ((N + 63u) / 64u) * 2u;
+    const bool pad_writer = blockIdx.x == 0 && A.out_stride_w > row_words;
+
+    uint2 R[RANK_BIG_RP];
+    auto load_row = [&](uint32_t j) {
+        const uint2* src = A.yp + (size_t)(wah_first + j) * CWP;
+#pragma unroll
+        for (int q = 0; q < RANK_BIG_RP; ++q) {
+            const uint32_t idx = (uint32_t)q * T + tid;
+            R[q] = idx < CWP ? src[idx] : make_uint2(0, 0);
+        }
+    };
+    auto store_row = [&]() {
+#pragma unroll
+        for (int q = 0; q < RANK_BIG_RP; ++q) {
+            const uint32_t idx = (uint32_t)q * T + tid;
+            if (idx < CWP) row[idx] = R[q];
+        }
+    };
+    load_row(0);
+    store_row();
+    uint32_t line = A.wah_lines[wah_first], Z = A.wah_z[wah_first];
+    __syncthreads();
+    for (uint32_t j = 0; j < n_wah; ++j) {
+        const bool more = j + 1u < n_wah;
+        uint32_t line_n = 0, Z_n = 0;
+        if (more) {
+            load_row(j + 1u);
+            line_n = A.wah_lines[wah_first + j + 1u];
+            Z_n = A.wah_z[wah_first + j + 1u];
+        }
+        uint32_t mine_lo = 0, mine_hi = 0;
+        static_for<0, E / G>([&](auto gcn) {
+            constexpr int g0 = decltype(gcn)::value * G;
+            uint2 pr[G];
+            static_for<0, G>([&](auto ecn) {
+                constexpr int e = decltype(ecn)::value;
+                pr[e] = row[r[g0 + e] >> 5];
+            });
+            static_for<0, G>([&](auto ecn) {
+                constexpr int e = decltype(ecn)::value;
+                const uint32_t rr = r[g0 + e];
+                const uint32_t bit = __builtin_amdgcn_ubfe(pr[e].x, rr, 1u);
+                const uint32_t ob = pr[e].y + (uint32_t)__popc(pr[e].x & ((1u << (rr & 31u)) - 1u));
+                r[g0 + e] = bit ? Z + ob : rr - ob;
+                const uint64_t m = __ballot(bit != 0u);
+                if (lane == (uint32_t)(g0 + e)) {
+                    mine_lo = (uint32_t)m;
+                    mine_hi = (uint32_t)(m >> 32);
+                }
+            });
+        });
+        if (store_lane) {
+            uint2* orow = reinterpret_cast<uint2*>(A.out + (size_t)line * A.out_stride_w);
+            orow[cg0 + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
+        }
+        if (pad_writer)
+            for (uint32_t i = row_words + tid; i < A.out_stride_w; i += T) A.out[(size_t)line * A.out_stride_w + i] = 0;
+        __syncthreads();  // everyone is done with the row
+        if (more) store_row();
+        line = line_n;
+        Z = Z_n;
+        __syncthreads();
+    }
+}
+
 struct RankGeom {
     int T, E;
     uint32_t splits, batch, lds_bytes, log2_cwp;
@@ -1113,8 +1417,10 @@ static hipError_t launch_rank(hipStream_t s, const RankGeom& g, uint32_t n_block
 
 hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
                                uint32_t* scratch_a, bool any_haploid) {
-    (void)any_haploid;  // the position-major kernel handles haploid lines itself
     ChainArgs A{};
+    // LDS kernel: handles haploid lines itself.  N > 65536: the streaming kernel takes the blocks
+    // without haploid lines, k_chain_global the others (only_haploid_blocks makes it skip the rest).
+    A.only_haploid_blocks = (any_haploid && !chain_geometry(L.N, false).in_lds) ? 1u : 0u;
     A.wah_lines = L.wah_lines;
     A.kind = L.kind;
     A.src = L.planes;
@@ -1124,6 +1430,34 @@ hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n
     A.N = L.N;
     A.out_row_base = 0;
     return launch_chain<false>(s, blocks, nullptr, n_blocks, A, scratch_a);
+}
+
+// Long-row decode: E by how many workgroups it takes to fill the chip.
+static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) {
+    const uint32_t nch = (A.N + 63u) / 64u;
+    const uint32_t lds = A.yp_stride * 8u;
+    auto splits_of = [&](uint32_t e) { return (nch + 16u * e - 1u) / (16u * e); };
+    static const int env_e = [] {
+        const char* e = getenv("XSI_DEC_BIG_E");
+        return e ? atoi(e) : 0;
+    }();
+    uint32_t E = 8;
+    if ((uint64_t)n_blocks * splits_of(32) >= 256u) E = 32;
+    else if ((uint64_t)n_blocks * splits_of(16) >= 256u) E = 16;
+    if (env_e == 8 || env_e == 16 || env_e == 32) E = (uint32_t)env_e;
+#define XSI_BIG_CASE(EE)                                                                                     \
+    if (E == EE) {                                                                                           \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank_big<EE>),      \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+        if (e != hipSuccess) return e;                                                                       \
+        k_chain_decode_rank_big<EE><<<dim3(splits_of(EE), n_blocks), dim3(1024), lds, s>>>(A);               \
+        return hipGetLastError();                                                                            \
+    }
+    XSI_BIG_CASE(8)
+    XSI_BIG_CASE(16)
+    XSI_BIG_CASE(32)
+#undef XSI_BIG_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_chain_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
@@ -1142,7 +1476,11 @@ hipError_t launch_chain_decode(hipStream_t s, const DecBlock* blocks, uint32_t n
     const RankGeom g = rank_geometry(L.N, L.yp_stride, n_blocks);
     R.batch = g.batch;
     R.log2_cwp = g.log2_cwp;
-    hipError_t e = g.stage ? launch_rank<true>(s, g, n_blocks, R) : launch_rank<false>(s, g, n_blocks, R);
+    hipError_t e;
+    if (!g.stage && L.yp_stride <= 1024u * RANK_BIG_RP && L.yp_stride * 8u <= 160u * 1024u && !getenv("XSI_NO_BIG_RANK"))
+        e = launch_rank_big(s, n_blocks, R);
+    else
+        e = g.stage ? launch_rank<true>(s, g, n_blocks, R) : launch_rank<false>(s, g, n_blocks, R);
     if (e != hipSuccess || !any_haploid) return e;
     // position-major kernel: the blocks with fully haploid lines (it skips the others)
     ChainArgs A{};
