@@ -6,12 +6,23 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 namespace xsi {
 
 constexpr uint32_t WAH_BITS = 15;
 constexpr uint32_t WAH_MAXC = 0x3FFF;  // 16383 groups per fill word (wah.hpp:383)
+
+// compile-time loop
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 

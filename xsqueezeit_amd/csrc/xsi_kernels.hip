@@ -249,15 +249,6 @@ struct KeyBits {
     }
 };
 
-// compile-time loop
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
 // Stable partition of `a` by the per-lane key bits; zc = zeros of my wave.  Shared by the fast
 // and the haploid paths.  `nvalid_total` = N for the haploid path (pads excluded), na otherwise.
 template <int T, int E, bool PADS_ARE_ONES, typename AT>
@@ -949,7 +940,12 @@ static const int k_chain_E[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 
 ChainGeom chain_geometry(uint32_t N, bool decode) {
     (void)decode;
     ChainGeom g{};
-    g.in_lds = N <= 65536u;
+    // XSI_STREAM_MIN_N: use the streaming kernel (prefix array in HBM/L2) from this N on (tuning aid)
+    static const uint32_t stream_min = [] {
+        const char* e = getenv("XSI_STREAM_MIN_N");
+        return e ? (uint32_t)atoi(e) : 65537u;
+    }();
+    g.in_lds = N <= 65536u && N < stream_min;
     if (!g.in_lds) {
         const uint32_t cw = (((N + 31u) >> 5) + 1u) & ~1u;
         g.threads = 1024;
@@ -1053,368 +1049,6 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
     return hipErrorInvalidValue;
 }
 
-// ------------------------------------------------------------------------------------------
-// PBWT chain, decode side, element-major ("rank tracking").
-//
-// The position-major kernel above moves the prefix array `a` around and needs two workgroup
-// barriers per line.  Decode does not need `a` at all.  Let r_k(h) be the position of haplotype
-// h in a_k (the inverse permutation, r_0(h) = h).  Then, with y_k the stored permuted row,
-//     x_k(h)     = y_k[r_k(h)]                                   (accessor_internals_new.hpp:228-230)
-//     r_{k+1}(h) = x_k(h) ? Z_k + ones_k(r_k(h)) : r_k(h) - ones_k(r_k(h))      (gt_block.hpp:124-136)
-// where ones_k(r) = number of set bits of y_k before position r and Z_k = zeros of y_k: the stable
-// partition moves a zero at position r to (zeros before r) and a one to Z + (ones before r).
-// Every haplotype's rank evolves on its own from read-only data (y_k plus a per-32-bit prefix
-// popcount, both produced by k_wah_expand), so there is NO communication between threads: no
-// barrier per line, no scatter, no atomics, and the haplotypes of one block can be split over
-// several workgroups to fill all 256 CUs even when there are fewer blocks than CUs.
-// 64 consecutive haplotypes live in one wave chunk, so their decoded bits are one ballot = one
-// 64-bit word of the natural-order output row.
-// Blocks that contain fully haploid lines keep the position-major kernel (a haploid line orders
-// y by the even members of `a`, which needs the permutation itself).
-// ------------------------------------------------------------------------------------------
-struct RankArgs {
-    const DecBlock* blocks;
-    const uint32_t* wah_lines;  // [rank] binary line
-    const uint2* yp;            // [rank][yp_stride] {bits, ones before}
-    uint32_t yp_stride;
-    const uint32_t* wah_z;      // [rank] zeros of the line
-    uint32_t* out;              // output rows by binary line
-    uint32_t out_stride_w;
-    uint32_t N;
-    uint32_t batch;             // lines staged per LDS batch
-    uint32_t log2_cwp;
-};
-
-constexpr int RANK_RP = 6;  // {bits, prefix} pairs a thread carries while a batch is in flight
-
-template <int T, int E, bool STAGE>
-__global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
-    constexpr int W = T / 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const DecBlock& D = A.blocks[blockIdx.x];
-    if (D.error || D.n_wah == 0 || D.off_line_haploid != VAL_UNDEFINED) return;
-    const uint32_t N = A.N;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t cg0 = (blockIdx.y * W + w) * E;  // first chunk of my wave
-    const uint32_t wah_first = D.wah_first, n_wah = D.n_wah;
-    const uint32_t CWP = A.yp_stride;
-
-    uint32_t r[E];
-    static_for<0, E>([&](auto ecn) {
-        constexpr int e = decltype(ecn)::value;
-        r[e] = (cg0 + (uint32_t)e) * 64u + lane;
-        if (r[e] >= N) r[e] = 0;  // haplotypes beyond N idle on position 0; their output is masked
-    });
-    // lane e (< E) stores chunk cg0+e's word; valid-bit mask of that chunk for the row tail
-    uint32_t vm_lo = 0, vm_hi = 0;
-    {
-        const uint64_t base = (uint64_t)(cg0 + lane) * 64u;
-        if (lane < (uint32_t)E && base < N) {
-            const uint32_t nv = (N - base >= 64u) ? 64u : (uint32_t)(N - base);
-            const uint64_t vm = nv == 64u ? ~0ull : ((1ull << nv) - 1ull);
-            vm_lo = (uint32_t)vm;
-            vm_hi = (uint32_t)(vm >> 32);
-        }
-    }
-    const bool store_lane = lane < (uint32_t)E && (uint64_t)(cg0 + lane) * 64u < N;
-    // rows are padded (e.g. to 128 bytes): the words past the last chunk must read as zero
-    const uint32_t row_words = ((N + 63u) / 64u) * 2u;
-    const bool pad_writer = blockIdx.y == 0 && A.out_stride_w > row_words;
-
-    if (!STAGE) {
-        // rows too long for LDS (N > 65536): rank-select straight from L2
-        for (uint32_t j = 0; j < n_wah; ++j) {
-            const uint32_t rank = wah_first + j;
-            const uint2* row = A.yp + (size_t)rank * CWP;
-            const uint32_t Z = A.wah_z[rank];
-            const uint32_t line = A.wah_lines[rank];
-            uint32_t mine_lo = 0, mine_hi = 0;
-            static_for<0, E>([&](auto ecn) {
-                constexpr int e = decltype(ecn)::value;
-                const uint2 pr = row[r[e] >> 5];
-                const uint32_t bit = __builtin_amdgcn_ubfe(pr.x, r[e], 1u);
-                const uint32_t ob = pr.y + (uint32_t)__popc(pr.x & ((1u << (r[e] & 31u)) - 1u));
-                r[e] = bit ? Z + ob : r[e] - ob;
-                const uint64_t m = __ballot(bit != 0u);
-                if (lane == (uint32_t)e) {
-                    mine_lo = (uint32_t)m;
-                    mine_hi = (uint32_t)(m >> 32);
-                }
-            });
-            if (store_lane) {
-                uint2* orow = reinterpret_cast<uint2*>(A.out + (size_t)line * A.out_stride_w);
-                orow[cg0 + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
-            }
-            if (pad_writer)
-                for (uint32_t i = row_words + tid; i < A.out_stride_w; i += T) A.out[(size_t)line * A.out_stride_w + i] = 0;
-        }
-        return;
-    }
-
-    uint2* stage = reinterpret_cast<uint2*>(smem);                       // 2 x B x CWP pairs
-    const uint32_t B = A.batch;
-    uint32_t* meta = reinterpret_cast<uint32_t*>(stage + 2u * B * CWP);  // 2 x B x {line, Z}
-    const uint32_t cwp_mask = (1u << A.log2_cwp) - 1u;
-    const uint32_t n_batches = (n_wah + B - 1u) / B;
-    uint2 R[RANK_RP];
-    uint2 Rm = make_uint2(0, 0);
-    auto load_batch = [&](uint32_t bt) {
-        if (tid < B && bt * B + tid < n_wah) {
-            const uint32_t rank = wah_first + bt * B + tid;
-            Rm = make_uint2(A.wah_lines[rank], A.wah_z[rank]);
-        }
-#pragma unroll
-        for (int q = 0; q < RANK_RP; ++q) {
-            const uint32_t idx = (uint32_t)q * T + tid;
-            const uint32_t jj = idx >> A.log2_cwp, wi = idx & cwp_mask;
-            const uint32_t j = bt * B + jj;
-            uint2 v = make_uint2(0, 0);
-            if (jj < B && j < n_wah && wi < CWP) v = A.yp[(size_t)(wah_first + j) * CWP + wi];
-            R[q] = v;
-        }
-    };
-    auto store_batch = [&](uint32_t buf) {
-        if (tid < B) {
-            meta[(buf * B + tid) * 2u] = Rm.x;
-            meta[(buf * B + tid) * 2u + 1u] = Rm.y;
-        }
-#pragma unroll
-        for (int q = 0; q < RANK_RP; ++q) {
-            const uint32_t idx = (uint32_t)q * T + tid;
-            const uint32_t jj = idx >> A.log2_cwp, wi = idx & cwp_mask;
-            if (jj < B && wi < CWP) stage[(buf * B + jj) * CWP + wi] = R[q];
-        }
-    };
-    load_batch(0);
-    store_batch(0);
-    __syncthreads();
-    for (uint32_t bt = 0; bt < n_batches; ++bt) {
-        const bool more = bt + 1u < n_batches;
-        if (more) load_batch(bt + 1u);
-        const uint32_t jn = (n_wah - bt * B) < B ? (n_wah - bt * B) : B;
-        for (uint32_t jj = 0; jj < jn; ++jj) {
-            const uint2* row = stage + ((bt & 1u) * B + jj) * CWP;
-            const uint32_t line = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[((bt & 1u) * B + jj) * 2u]);
-            const uint32_t Z = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[((bt & 1u) * B + jj) * 2u + 1u]);
-            uint2 pr[E];
-            static_for<0, E>([&](auto ecn) {
-                constexpr int e = decltype(ecn)::value;
-                pr[e] = row[r[e] >> 5];
-            });
-            uint32_t mine_lo = 0, mine_hi = 0;
-            static_for<0, E>([&](auto ecn) {
-                constexpr int e = decltype(ecn)::value;
-                const uint32_t bit = __builtin_amdgcn_ubfe(pr[e].x, r[e], 1u);
-                const uint32_t ob = pr[e].y + (uint32_t)__popc(pr[e].x & ((1u << (r[e] & 31u)) - 1u));
-                r[e] = bit ? Z + ob : r[e] - ob;
-                const uint64_t m = __ballot(bit != 0u);
-                if (lane == (uint32_t)e) {
-                    mine_lo = (uint32_t)m;
-                    mine_hi = (uint32_t)(m >> 32);
-                }
-            });
-            if (store_lane) {
-                uint2* orow = reinterpret_cast<uint2*>(A.out + (size_t)line * A.out_stride_w);
-                orow[cg0 + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
-            }
-            if (pad_writer)
-                for (uint32_t i = row_words + tid; i < A.out_stride_w; i += T) A.out[(size_t)line * A.out_stride_w + i] = 0;
-        }
-        if (more) store_batch((bt + 1u) & 1u);
-        __syncthreads();
-    }
-}
-
-// Long rows (65536 < N <= 1024*RANK_BIG_RP*32): one {bits, prefix} row at a time in LDS (up to
-// 160 KB), the next row prefetched into registers while the current one is used.  A gather from
-// LDS serves 64 lanes in a few cycles; the same gather from L2 is one request per lane (~1 lane
-// per clock per CU), which is what bounded the unstaged path.  Each workgroup covers 16*E chunks
-// of haplotypes; grid = (splits, blocks) so the splits of one block are dispatched together and
-// share the row through L2.
-constexpr int RANK_BIG_RP = 20;
-
-template <int E>
-__global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
-    constexpr int T = 1024, W = 16, G = 8;  // G: gathers in flight per wave
-    static_assert(E % G == 0, "E must be a multiple of the gather group");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const DecBlock& D = A.blocks[blockIdx.y];
-    if (D.error || D.n_wah == 0 || D.off_line_haploid != VAL_UNDEFINED) return;
-    const uint32_t N = A.N;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t cg0 = (blockIdx.x * W + w) * E;  // first chunk of my wave
-    const uint32_t wah_first = D.wah_first, n_wah = D.n_wah;
-    const uint32_t CWP = A.yp_stride;
-    uint2* row = reinterpret_cast<uint2*>(smem);
-
-    uint32_t r[E];
-    static_for<0, E>([&](auto ecn) {
-        constexpr int e = decltype(ecn)::value;
-        r[e] = (cg0 + (uint32_t)e) * 64u + lane;
-        if (r[e] >= N) r[e] = 0;
-    });
-    uint32_t vm_lo = 0, vm_hi = 0;
-    {
-        const uint64_t base = (uint64_t)(cg0 + lane) * 64u;
-        if (lane < (uint32_t)E && base < N) {
-            const uint32_t nv = (N - base >= 64u) ? 64u : (uint32_t)(N - base);
-            const uint64_t vm = nv == 64u ? ~0ull : ((1ull << nv) - 1ull);
-            vm_lo = (uint32_t)vm;
-            vm_hi = (uint32_t)(vm >> 32);
-        }
-    }
-    const bool store_lane = lane < (uint32_t)E && (uint64_t)(cg0 + lane) * 64u < N;
-    const uint32_t row_words = ((N + 63u) / 64u) * 2u;
-    const bool pad_writer = blockIdx.x == 0 && A.out_stride_w > row_words;
-
-    uint2 R[RANK_BIG_RP];
-    auto load_row = [&](uint32_t j) {
-        const uint2* src = A.yp + (size_t)(wah_first + j) * CWP;
-#pragma unroll
-        for (int q = 0; q < RANK_BIG_RP; ++q) {
-            const uint32_t idx = (uint32_t)q * T + tid;
-            R[q] = idx < CWP ? src[idx] : make_uint2(0, 0);
-        }
-    };
-    auto store_row = [&]() {
-#pragma unroll
-        for (int q = 0; q < RANK_BIG_RP; ++q) {
-            const uint32_t idx = (uint32_t)q * T + tid;
-            if (idx < CWP) row[idx] = R[q];
-        }
-    };
-    load_row(0);
-    store_row();
-    uint32_t line = A.wah_lines[wah_first], Z = A.wah_z[wah_first];
-    __syncthreads();
-    for (uint32_t j = 0; j < n_wah; ++j) {
-        const bool more = j + 1u < n_wah;
-        uint32_t line_n = 0, Z_n = 0;
-        if (more) {
-            load_row(j + 1u);
-            line_n = A.wah_lines[wah_first + j + 1u];
-            Z_n = A.wah_z[wah_first + j + 1u];
-        }
-        uint32_t mine_lo = 0, mine_hi = 0;
-        static_for<0, E / G>([&](auto gcn) {
-            constexpr int g0 = decltype(gcn)::value * G;
-            uint2 pr[G];
-            static_for<0, G>([&](auto ecn) {
-                constexpr int e = decltype(ecn)::value;
-                pr[e] = row[r[g0 + e] >> 5];
-            });
-            static_for<0, G>([&](auto ecn) {
-                constexpr int e = decltype(ecn)::value;
-                const uint32_t rr = r[g0 + e];
-                const uint32_t bit = __builtin_amdgcn_ubfe(pr[e].x, rr, 1u);
-                const uint32_t ob = pr[e].y + (uint32_t)__popc(pr[e].x & ((1u << (rr & 31u)) - 1u));
-                r[g0 + e] = bit ? Z + ob : rr - ob;
-                const uint64_t m = __ballot(bit != 0u);
-                if (lane == (uint32_t)(g0 + e)) {
-                    mine_lo = (uint32_t)m;
-                    mine_hi = (uint32_t)(m >> 32);
-                }
-            });
-        });
-        if (store_lane) {
-            uint2* orow = reinterpret_cast<uint2*>(A.out + (size_t)line * A.out_stride_w);
-            orow[cg0 + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
-        }
-        if (pad_writer)
-            for (uint32_t i = row_words + tid; i < A.out_stride_w; i += T) A.out[(size_t)line * A.out_stride_w + i] = 0;
-        __syncthreads();  // everyone is done with the row
-        if (more) store_row();
-        line = line_n;
-        Z = Z_n;
-        __syncthreads();
-    }
-}
-
-struct RankGeom {
-    int T, E;
-    uint32_t splits, batch, lds_bytes, log2_cwp;
-    bool stage;
-};
-
-static RankGeom rank_geometry(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
-    RankGeom g{};
-    const uint32_t nch = (N + 63u) / 64u;
-    g.stage = N <= 65536u;
-    // Every workgroup stages the whole rank-select row of each line, so splitting a block's
-    // haplotypes over S workgroups multiplies that L2 traffic by S.  Prefer the largest workgroup
-    // that still gives about one workgroup per CU, and at most 8 chunks per wave.
-    static const int env_e = [] {
-        const char* e = getenv("XSI_DEC_E");
-        const int v = e ? atoi(e) : 0;
-        return (v >= 1 && v <= 8) ? v : 0;
-    }();
-    static const int env_t = [] {
-        const char* e = getenv("XSI_DEC_T");
-        const int v = e ? atoi(e) : 0;
-        return (v == 256 || v == 512 || v == 1024) ? v : 0;
-    }();
-    // about one workgroup per CU (measured best at the bench size: T=512, E=5, 2 splits: 2.3 ms
-    // against 2.9 ms for 5 splits of T=256 and 3.4 ms for a single 1024-thread workgroup per block)
-    int T, E;
-    {
-        const uint32_t s_target = n_blocks >= 256u ? 1u : (256u + n_blocks / 2u) / (n_blocks ? n_blocks : 1u);
-        const uint32_t per_wg = (nch + s_target - 1u) / s_target;  // chunks one workgroup should cover
-        T = per_wg <= 8u ? 256 : (per_wg <= 64u ? 512 : 1024);
-        const uint32_t waves = (uint32_t)T / 64u;
-        uint32_t e = (per_wg + waves - 1u) / waves;
-        if (e < 1u) e = 1u;
-        if (e > 8u) e = 8u;
-        E = (int)e;
-    }
-    if (env_t) T = env_t;
-    if (env_e) E = env_e;
-    g.T = T;
-    g.E = E;
-    const uint32_t per_wg = (uint32_t)(T / 64) * (uint32_t)E;
-    g.splits = (nch + per_wg - 1u) / per_wg;
-    g.log2_cwp = next_pow2_log2(yp_stride);
-    if (g.stage) {
-        uint32_t B = (uint32_t)(RANK_RP * g.T) >> g.log2_cwp;
-        if (B > 16u) B = 16u;
-        if (B < 1u) B = 1u;
-        auto need = [&](uint32_t b) { return 2u * b * yp_stride * 8u + 2u * b * 8u + 64u; };
-        while (B > 1u && need(B) > 64u * 1024u) B >>= 1;
-        g.batch = B;
-        g.lds_bytes = need(B);
-        if ((uint32_t)(RANK_RP * g.T) < yp_stride) g.stage = false;  // one row does not fit a register batch
-    }
-    if (!g.stage) {
-        g.batch = 1;
-        g.lds_bytes = 0;
-    }
-    return g;
-}
-
-template <bool STAGE>
-static hipError_t launch_rank(hipStream_t s, const RankGeom& g, uint32_t n_blocks, RankArgs A) {
-#define XSI_RANK_CASE(TT, EE)                                                                                 \
-    if (g.T == TT && g.E == EE) {                                                                             \
-        if (g.lds_bytes) {                                                                                    \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank<TT, EE, STAGE>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes); \
-            if (e != hipSuccess) return e;                                                                    \
-        }                                                                                                     \
-        k_chain_decode_rank<TT, EE, STAGE><<<dim3(n_blocks, g.splits), dim3(TT), g.lds_bytes, s>>>(A);        \
-        return hipGetLastError();                                                                             \
-    }
-#define XSI_RANK_CASES(TT) \
-    XSI_RANK_CASE(TT, 1) XSI_RANK_CASE(TT, 2) XSI_RANK_CASE(TT, 3) XSI_RANK_CASE(TT, 4) \
-    XSI_RANK_CASE(TT, 5) XSI_RANK_CASE(TT, 6) XSI_RANK_CASE(TT, 7) XSI_RANK_CASE(TT, 8)
-    XSI_RANK_CASES(256)
-    XSI_RANK_CASES(512)
-    XSI_RANK_CASES(1024)
-#undef XSI_RANK_CASES
-#undef XSI_RANK_CASE
-    return hipErrorInvalidValue;
-}
-
 hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
                                uint32_t* scratch_a, bool any_haploid) {
     ChainArgs A{};
@@ -1432,55 +1066,11 @@ hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n
     return launch_chain<false>(s, blocks, nullptr, n_blocks, A, scratch_a);
 }
 
-// Long-row decode: E by how many workgroups it takes to fill the chip.
-static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) {
-    const uint32_t nch = (A.N + 63u) / 64u;
-    const uint32_t lds = A.yp_stride * 8u;
-    auto splits_of = [&](uint32_t e) { return (nch + 16u * e - 1u) / (16u * e); };
-    static const int env_e = [] {
-        const char* e = getenv("XSI_DEC_BIG_E");
-        return e ? atoi(e) : 0;
-    }();
-    uint32_t E = 8;
-    if ((uint64_t)n_blocks * splits_of(32) >= 256u) E = 32;
-    else if ((uint64_t)n_blocks * splits_of(16) >= 256u) E = 16;
-    if (env_e == 8 || env_e == 16 || env_e == 32) E = (uint32_t)env_e;
-#define XSI_BIG_CASE(EE)                                                                                     \
-    if (E == EE) {                                                                                           \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank_big<EE>),      \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
-        if (e != hipSuccess) return e;                                                                       \
-        k_chain_decode_rank_big<EE><<<dim3(splits_of(EE), n_blocks), dim3(1024), lds, s>>>(A);               \
-        return hipGetLastError();                                                                            \
-    }
-    XSI_BIG_CASE(8)
-    XSI_BIG_CASE(16)
-    XSI_BIG_CASE(32)
-#undef XSI_BIG_CASE
-    return hipErrorInvalidValue;
-}
-
 hipError_t launch_chain_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                                uint32_t* out_rows, uint32_t out_stride_w, uint32_t* scratch_a, bool any_haploid) {
     if (!n_blocks) return hipSuccess;
-    // element-major kernel: every block without fully haploid lines
-    RankArgs R{};
-    R.blocks = blocks;
-    R.wah_lines = L.wah_lines;
-    R.yp = L.yp;
-    R.yp_stride = L.yp_stride;
-    R.wah_z = L.wah_z;
-    R.out = out_rows;
-    R.out_stride_w = out_stride_w;
-    R.N = L.N;
-    const RankGeom g = rank_geometry(L.N, L.yp_stride, n_blocks);
-    R.batch = g.batch;
-    R.log2_cwp = g.log2_cwp;
-    hipError_t e;
-    if (!g.stage && L.yp_stride <= 1024u * RANK_BIG_RP && L.yp_stride * 8u <= 160u * 1024u && !getenv("XSI_NO_BIG_RANK"))
-        e = launch_rank_big(s, n_blocks, R);
-    else
-        e = g.stage ? launch_rank<true>(s, g, n_blocks, R) : launch_rank<false>(s, g, n_blocks, R);
+    // element-major kernels (xsi_rank.hip): every block without fully haploid lines
+    hipError_t e = launch_rank_decode(s, blocks, n_blocks, L, out_rows, out_stride_w);
     if (e != hipSuccess || !any_haploid) return e;
     // position-major kernel: the blocks with fully haploid lines (it skips the others)
     ChainArgs A{};

@@ -116,6 +116,9 @@ hipError_t launch_sparse_walk(hipStream_t s, const uint8_t* file, const DecBlock
                               const DecLines& L);
 hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
                              uint32_t max_wah, const uint32_t* d_totals);
+// element-major decode chain (xsi_rank.hip): all blocks without fully haploid lines
+hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
+                              uint32_t* out_rows, uint32_t out_stride_w);
 hipError_t launch_chain_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                                uint32_t* out_rows, uint32_t out_stride_w, uint32_t* scratch_a, bool any_haploid);
 hipError_t launch_sparse_fill(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
