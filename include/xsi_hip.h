@@ -205,6 +205,13 @@ int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_
  * sets *ngt_arr = hap_samples (accessor.hpp:58-67). */
 int64_t xsi_accessor_get_genotypes(xsi_accessor* a, uint32_t n_alleles, uint64_t position, void** h_gt,
                                    int* ngt_arr);
+/* Decoded blocks stay resident in HBM (LRU) so that backward and random seeks do not replay a block
+ * prefix the way accessor_internals_new.hpp:154-196 does.  Budget in bytes (default: half of the free
+ * HBM at open, at most 64 GiB; XSI_ACCESSOR_CACHE_MB overrides); 0 keeps only the current block. */
+int xsi_accessor_set_cache_bytes(xsi_accessor* a, uint64_t bytes);
+/* Any of the outputs may be NULL. */
+int xsi_accessor_cache_stats(const xsi_accessor* a, uint64_t* blocks, uint64_t* bytes, uint64_t* hits,
+                             uint64_t* misses);
 /* Accessor::fill_allele_counts(n_alleles, position) (accessor.hpp:52-54): counts only, no genotype
  * expansion; like the reference, counts[0] = line values - sum of ALT counts (missing / end-of-vector
  * are not subtracted, accessor_internals_new.hpp:437). */

@@ -306,3 +306,72 @@ def test_zstd_layer_roundtrip(tmp_path):
         off += na - 1
     binding.check(L.xsi_accessor_fill_allele_counts(a, lines[0][1], 0))
     L.xsi_accessor_close(a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("budget", [None, "two_blocks", 0])
+def test_accessor_random_access_block_cache(tmp_path, budget):
+    """Config-5 style use: uniformly random BM positions over many blocks (mixed ploidy, multi-allelic,
+    EOV) through fill_genotype_array, interleaved with fill_allele_counts.  Decoded blocks stay
+    resident in HBM; results must not depend on the cache budget (default / two blocks with
+    evictions / none = decode in the shared workspace)."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    rng = np.random.default_rng(5150)
+    n, n_lines, block_len = 90, 1300, 100
+    lines = _random_lines(rng, n, n_lines, multi=True, missing=True, eov=True, phase=True)
+    dp = oracle.default_phased_of(lines, n)
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=2, default_phased=dp)
+    path = tmp_path / "ra.xsi"
+    path.write_bytes(ref)
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
+    u64 = ctypes.c_uint64
+    if budget == "two_blocks":
+        # decode one block, read its footprint, allow two of them
+        buf0 = np.zeros(2 * n, dtype=np.int32)
+        assert L.xsi_accessor_fill_genotype_array(a, buf0.ctypes.data, buf0.size, lines[0][1], 0) > 0
+        nb, by = u64(0), u64(0)
+        binding.check(L.xsi_accessor_cache_stats(a, ctypes.byref(nb), ctypes.byref(by), None, None))
+        assert nb.value == 1 and by.value > 0
+        binding.check(L.xsi_accessor_set_cache_bytes(a, 2 * by.value + 1024))
+    elif budget == 0:
+        binding.check(L.xsi_accessor_set_cache_bytes(a, 0))
+    bms = []
+    block = off = 0
+    for i, (_, na) in enumerate(lines):
+        if i and i % block_len == 0:
+            block += 1
+            off = 0
+        bms.append((block << 15) | off)
+        off += na - 1
+    # one reader per block on the oracle side: it replays forward only, so visit in sorted order there
+    order = [int(x) for x in rng.integers(0, n_lines, 400)]
+    rd = oracle.Reader(ref)
+    expect = {}
+    for i in sorted(set(order)):
+        expect[i] = rd.fill_genotype_array(lines[i][1], bms[i])
+    buf = np.zeros(2 * n, dtype=np.int32)
+    cnt = np.zeros(8, dtype=np.uint64)
+    for k, i in enumerate(order):
+        na = lines[i][1]
+        egt, ecnt = expect[i]
+        r = L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, na, bms[i])
+        assert r == len(egt), "line %d: %s" % (i, binding.lib().xsi_hip_last_error())
+        assert np.array_equal(buf[:r], egt), "line %d (query %d)" % (i, k)
+        binding.check(L.xsi_accessor_allele_counts(a, cnt.ctypes.data, na))
+        assert np.array_equal(cnt[:na], ecnt)
+        if k % 7 == 0:  # counts-only view of another block in between
+            j = order[(k * 13 + 5) % len(order)]
+            binding.check(L.xsi_accessor_fill_allele_counts(a, lines[j][1], bms[j]))
+    nb, by, hits, misses = u64(0), u64(0), u64(0), u64(0)
+    binding.check(L.xsi_accessor_cache_stats(a, ctypes.byref(nb), ctypes.byref(by), ctypes.byref(hits), ctypes.byref(misses)))
+    n_blocks = (n_lines + block_len - 1) // block_len
+    if budget is None:
+        assert nb.value == n_blocks and misses.value == n_blocks  # every block decoded exactly once
+    elif budget == "two_blocks":
+        assert nb.value <= 2 and misses.value > n_blocks
+    else:
+        assert nb.value == 0
+    L.xsi_accessor_close(a)

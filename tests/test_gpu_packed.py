@@ -44,6 +44,9 @@ def test_synth_matches_numpy():
     (16390, 80, 64, 16),
     (64976, 24, 16, 64),
     (70002, 12, 8, 70),
+    (65600, 120, 60, 65),     # streaming chain: short last segment, long look-ahead history
+    (131074, 200, 100, 131),
+    (200000, 64, 64, 200),
 ])
 def test_chain_matches_numpy(n_haps, n_lines, block_len, thr):
     import gpu_util as G
@@ -83,6 +86,8 @@ def test_chain_matches_numpy(n_haps, n_lines, block_len, thr):
     (70002, 12, 8, 70),      # 35001 samples: header A_T=4, block A_T=2 -> encode-only
     (131074, 12, 8, 131),    # 65537 samples: u32 A_T everywhere, global-memory chain
     (200000, 10, 8, 200),
+    (140000, 260, 128, 140),  # streaming encode chain + LDS-staged long-row decode chain, long blocks
+    (530000, 24, 12, 530),    # > 16384 rank-select pairs per row: deepest prefetch variant
 ])
 def test_encode_bit_exact_and_roundtrip(n_haps, n_lines, block_len, thr):
     import gpu_util as G

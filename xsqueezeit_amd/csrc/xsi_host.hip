@@ -277,11 +277,27 @@ struct xsi_accessor {
     uint32_t version = 0, aet = 0, ploidy = 0;
     uint64_t hap_samples = 0, num_samples = 0, n_blocks = 0;
     std::vector<std::string> names;
-    // current block
+    // current block: a view (P, D) of either a cache entry or, when the cache cannot take it, the
+    // context workspace
     int64_t cur_block = -1;
+    bool cur_in_workspace = false;
     DecodePlan P;
     DecodedPlanes D;
     bool biallelic = false;
+    // decoded blocks kept in HBM (LRU): the reference replays a block's prefix on every backward or
+    // random seek (accessor_internals_new.hpp:154-196); here a block is decoded once and stays
+    // resident, so a revisit costs one compose kernel
+    struct CachedBlock {
+        uint64_t block = 0, last_use = 0;
+        size_t bytes = 0;
+        uint8_t* mem = nullptr;
+        DecodePlan P;
+        DecodedPlanes D;
+        bool biallelic = false;
+    };
+    std::vector<CachedBlock> cache;
+    size_t cache_bytes = 0, cache_budget = 0;
+    uint64_t tick = 0, cache_hits = 0, cache_misses = 0;
     // zstd files: every block is inflated on the host into a one-block image (header + block + index)
     bool zstd = false;
     std::vector<uint8_t> mini;
@@ -356,16 +372,104 @@ static int accessor_block_image(xsi_accessor* a, uint64_t block, const uint8_t**
     return XSI_OK;
 }
 
+static void accessor_evict(xsi_accessor* a, size_t idx) {
+    (void)hipFree(a->cache[idx].mem);
+    a->cache_bytes -= a->cache[idx].bytes;
+    a->cache.erase(a->cache.begin() + (long)idx);
+}
+
+// Copy the decoded state of the block that sits in the context workspace into a private
+// allocation and repoint (P, D) at it.  Returns false when the budget / HBM cannot take it.
+static bool accessor_cache_store(xsi_accessor* a, uint64_t block) {
+    const size_t n_bin = a->P.n_bin ? a->P.n_bin : 1;
+    const size_t plane_b = 4ull * a->D.stride_w * n_bin;
+    auto al = [](size_t v) { return (v + 255u) & ~(size_t)255u; };
+    const bool side = a->D.has_side;
+    const size_t need = al(plane_b) * (side ? 4u : 1u) + al(n_bin) * (side ? 2u : 1u) + al(4 * n_bin + 64) * 4u +
+                        al(sizeof(DecBlock));
+    if (need > a->cache_budget) return false;
+    while (a->cache_bytes + need > a->cache_budget && !a->cache.empty()) {
+        size_t lru = 0;
+        for (size_t i = 1; i < a->cache.size(); ++i)
+            if (a->cache[i].last_use < a->cache[lru].last_use) lru = i;
+        accessor_evict(a, lru);
+    }
+    uint8_t* mem = nullptr;
+    while (hipMalloc((void**)&mem, need) != hipSuccess) {
+        (void)hipGetLastError();
+        if (a->cache.empty()) return false;
+        size_t lru = 0;
+        for (size_t i = 1; i < a->cache.size(); ++i)
+            if (a->cache[i].last_use < a->cache[lru].last_use) lru = i;
+        accessor_evict(a, lru);
+    }
+    hipStream_t s = a->ctx->stream;
+    size_t off = 0;
+    bool ok = true;
+    auto take = [&](const void* src, size_t bytes) -> void* {
+        void* dst = mem + off;
+        if (src && bytes && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) ok = false;
+        off += al(bytes);
+        return dst;
+    };
+    xsi_accessor::CachedBlock e;
+    e.P = a->P;
+    e.D = a->D;
+    e.D.planes = (uint32_t*)take(a->D.planes, plane_b);
+    e.P.L.kind = (uint8_t*)take(a->P.L.kind, n_bin);
+    e.P.L.ones = (uint32_t*)take(a->P.L.ones, 4 * n_bin);
+    e.P.L.line_block = (uint32_t*)take(a->P.L.line_block, 4 * n_bin);
+    e.D.n_miss = (uint32_t*)take(a->D.n_miss, 4 * n_bin + 64);
+    e.D.n_eov = (uint32_t*)take(a->D.n_eov, 4 * n_bin + 64);
+    e.P.d_blocks = (DecBlock*)take(a->P.d_blocks, sizeof(DecBlock));
+    if (side) {
+        e.D.side = (uint8_t*)take(a->D.side, n_bin);
+        e.D.miss_planes = (uint32_t*)take(a->D.miss_planes, plane_b);
+        e.D.eov_planes = (uint32_t*)take(a->D.eov_planes, plane_b);
+        e.D.phase_planes = (uint32_t*)take(a->D.phase_planes, plane_b);
+    }
+    if (!ok || hipStreamSynchronize(s) != hipSuccess || off > need) {
+        (void)hipGetLastError();
+        (void)hipFree(mem);
+        return false;
+    }
+    e.block = block;
+    e.last_use = ++a->tick;
+    e.bytes = need;
+    e.mem = mem;
+    e.biallelic = a->biallelic;
+    a->cache_bytes += need;
+    a->P = e.P;
+    a->D = e.D;
+    a->cache.push_back(std::move(e));
+    return true;
+}
+
 static int accessor_load_block(xsi_accessor* a, uint64_t block) {
+    for (auto& e : a->cache)
+        if (e.block == block) {
+            e.last_use = ++a->tick;
+            a->P = e.P;
+            a->D = e.D;
+            a->biallelic = e.biallelic;
+            a->cur_block = (int64_t)block;
+            a->cur_in_workspace = false;
+            a->win_n = 0;
+            ++a->cache_hits;
+            return XSI_OK;
+        }
+    ++a->cache_misses;
     const uint8_t* img;
     uint64_t len, blk;
     int rc = accessor_block_image(a, block, &img, &len, &blk);
     if (rc) return rc;
+    a->cur_block = -1;
     rc = decode_prepare(a->ctx, img, len, blk, 1, &a->P);
     if (rc) return rc;
     rc = decode_all_planes(a->ctx, img, a->P, &a->D);
     if (rc) return rc;
     a->biallelic = a->P.n_bin == a->P.n_bcf;
+    a->cur_in_workspace = !accessor_cache_store(a, block);
     a->cur_block = (int64_t)block;
     a->cnt_block = -1;
     a->win_n = 0;
@@ -497,7 +601,37 @@ int xsi_accessor_open(xsi_accessor** out, xsi_hip_ctx* ctx, const char* path) {
         xsi_accessor_close(a);
         return set_error(XSI_ERR_HIP, "accessor buffers: %s", hipGetErrorString(e));
     }
+    {
+        // decoded-block cache: half of the free HBM, at most 64 GiB, unless XSI_ACCESSOR_CACHE_MB says otherwise
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        a->cache_budget = free_b / 2;
+        if (a->cache_budget > (64ull << 30)) a->cache_budget = 64ull << 30;
+        if (const char* e = getenv("XSI_ACCESSOR_CACHE_MB")) a->cache_budget = (size_t)strtoull(e, nullptr, 10) << 20;
+    }
     *out = a;
+    return XSI_OK;
+}
+
+int xsi_accessor_set_cache_bytes(xsi_accessor* a, uint64_t bytes) {
+    if (!a) return set_error(XSI_ERR_ARG, "set_cache_bytes: null accessor");
+    a->cache_budget = (size_t)bytes;
+    while (a->cache_bytes > a->cache_budget && !a->cache.empty()) {
+        size_t lru = 0;
+        for (size_t i = 1; i < a->cache.size(); ++i)
+            if (a->cache[i].last_use < a->cache[lru].last_use) lru = i;
+        if (a->cur_block >= 0 && !a->cur_in_workspace && a->cache[lru].block == (uint64_t)a->cur_block) a->cur_block = -1;
+        accessor_evict(a, lru);
+    }
+    return XSI_OK;
+}
+
+int xsi_accessor_cache_stats(const xsi_accessor* a, uint64_t* blocks, uint64_t* bytes, uint64_t* hits, uint64_t* misses) {
+    if (!a) return set_error(XSI_ERR_ARG, "cache_stats: null accessor");
+    if (blocks) *blocks = a->cache.size();
+    if (bytes) *bytes = a->cache_bytes;
+    if (hits) *hits = a->cache_hits;
+    if (misses) *misses = a->cache_misses;
     return XSI_OK;
 }
 
@@ -572,8 +706,10 @@ int xsi_accessor_fill_allele_counts(xsi_accessor* a, uint32_t n_alleles, uint64_
         HIP_TRY(hipMemcpyAsync(a->cnt_kind.data(), P.L.kind, P.n_bin, hipMemcpyDeviceToHost, a->ctx->stream));
         HIP_TRY(hipStreamSynchronize(a->ctx->stream));
         a->cnt_block = (int64_t)block;
-        a->cur_block = -1;  // the shared workspace now holds the counts-only state of this block
-        a->win_n = 0;
+        if (a->cur_in_workspace) {
+            a->cur_block = -1;  // the shared workspace now holds the counts-only state of this block
+            a->win_n = 0;
+        }
     }
     if ((size_t)offset + (n_alleles - 1) > a->cnt_ones.size())
         return set_error(XSI_ERR_ARG, "position offset %u (+%u alleles) beyond the block", offset, n_alleles - 1);
@@ -605,6 +741,7 @@ const char* xsi_accessor_sample_name(const xsi_accessor* a, uint64_t i) {
 void xsi_accessor_close(xsi_accessor* a) {
     if (!a) return;
     if (a->ctx) (void)hipStreamSynchronize(a->ctx->stream);
+    for (auto& e : a->cache) (void)hipFree(e.mem);
     if (a->d_file) (void)hipFree(a->d_file);
     if (a->d_mini) (void)hipFree(a->d_mini);
     if (a->d_rows) (void)hipFree(a->d_rows);

@@ -938,14 +938,15 @@ static uint32_t next_pow2_log2(uint32_t v) {
 static const int k_chain_E[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64};
 
 ChainGeom chain_geometry(uint32_t N, bool decode) {
-    (void)decode;
     ChainGeom g{};
-    // XSI_STREAM_MIN_N: use the streaming kernel (prefix array in HBM/L2) from this N on (tuning aid)
+    // Encode: from ~48k haplotypes on the streaming kernel (prefix array in HBM/L2, one pass per line)
+    // beats the LDS kernel with its 48+ chunks per wave (measured: 90 ms against 110 ms per 8192-line
+    // block at 64976 haplotypes, 61 against 54 ms at 40000).  XSI_STREAM_MIN_N overrides (tuning aid).
     static const uint32_t stream_min = [] {
         const char* e = getenv("XSI_STREAM_MIN_N");
-        return e ? (uint32_t)atoi(e) : 65537u;
+        return e ? (uint32_t)atoi(e) : 49152u;
     }();
-    g.in_lds = N <= 65536u && N < stream_min;
+    g.in_lds = N <= 65536u && (decode || N < stream_min);
     if (!g.in_lds) {
         const uint32_t cw = (((N + 31u) >> 5) + 1u) & ~1u;
         g.threads = 1024;
