@@ -462,7 +462,8 @@ __global__ void __launch_bounds__(256) k_compose_gt(ComposeArgs C) {
     const uint32_t* ep = C.S.eov_planes ? C.S.eov_planes + (size_t)start * C.S.stride_w : nullptr;
     const uint32_t* pp = C.S.phase_planes ? C.S.phase_planes + (size_t)start * C.S.stride_w : nullptr;
     int32_t* orow = C.out + (size_t)li * C.out_stride;
-    for (uint32_t i = threadIdx.x; i < Nl; i += blockDim.x) {
+    // grid.y workgroups share one line (few lines of many haplotypes: random access)
+    for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < Nl; i += blockDim.x * gridDim.y) {
         const int32_t ph = (int32_t)(i & 1u) & DP;
         const uint32_t wi = i >> 5, bi = i & 31u;
         int32_t gt;
@@ -501,7 +502,7 @@ __global__ void __launch_bounds__(256) k_compose_gt(ComposeArgs C) {
         if ((f & 4u) && pp && ((pp[wi] >> bi) & 1u) && gt != GT_VECTOR_END) gt ^= (int32_t)(i & 1u);
         orow[i] = gt;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
         C.line_ngt[li] = Nl;
         if (C.allele_counts) {
             uint64_t total = 0;
@@ -601,7 +602,10 @@ int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D,
     C.allele_counts = d_allele_counts;
     C.max_alleles = max_alleles;
     stage_mark(ctx, XSI_ST_GT_COMPOSE);
-    k_compose_gt<<<dim3(n_out), dim3(256), 0, ctx->stream>>>(C);
+    uint32_t splits = (P.L.N + 2047u) / 2048u;  // >= 8 values per thread
+    if (splits > 2048u / n_out) splits = 2048u / n_out;
+    if (splits < 1u) splits = 1u;
+    k_compose_gt<<<dim3(n_out, splits), dim3(256), 0, ctx->stream>>>(C);
     HIP_TRY(hipGetLastError());
     return XSI_OK;
 }

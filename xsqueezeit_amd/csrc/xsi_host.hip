@@ -310,11 +310,10 @@ struct xsi_accessor {
     // composed window of a bi-allelic block, or the single last composed line
     int32_t* d_rows = nullptr;
     int32_t* h_rows = nullptr;  // pinned
-    uint64_t* d_counts = nullptr;
     uint64_t* h_counts = nullptr;  // pinned [win][2] or [1][max]
-    uint32_t* d_meta = nullptr;    // first_bin / n_allele / line_ngt
     uint32_t* h_meta = nullptr;    // pinned
-    uint32_t win_rows = 0, win_first = 0, win_n = 0;
+    uint32_t win_rows = 0, win_first = 0, win_n = 0, win_target = 1;
+    int64_t win_block = -1;
     uint32_t counts_cap = 0;
     std::vector<uint64_t> last_counts;
 };
@@ -482,11 +481,9 @@ static int accessor_compose(xsi_accessor* a, uint32_t first, uint32_t n, uint32_
     const uint32_t N = a->P.L.N;
     const uint32_t max_al = n_alleles;
     if ((uint64_t)n * max_al > a->counts_cap) {
-        if (a->d_counts) (void)hipFree(a->d_counts);
         if (a->h_counts) (void)hipHostFree(a->h_counts);
-        a->d_counts = a->h_counts = nullptr;
+        a->h_counts = nullptr;
         a->counts_cap = (uint32_t)((uint64_t)n * max_al + 64);
-        HIP_TRY(hipMalloc((void**)&a->d_counts, 8ull * a->counts_cap));
         HIP_TRY(hipHostMalloc((void**)&a->h_counts, 8ull * a->counts_cap, hipHostMallocDefault));
     }
     uint32_t* fb = a->h_meta;
@@ -495,14 +492,17 @@ static int accessor_compose(xsi_accessor* a, uint32_t first, uint32_t n, uint32_
         fb[i] = first + i * (n_alleles - 1);
         na[i] = n_alleles;
     }
-    HIP_TRY(hipMemcpyAsync(a->d_meta, a->h_meta, 8ull * a->win_rows, hipMemcpyHostToDevice, s));
-    int rc = compose_lines(a->ctx, a->P, a->D, a->d_meta, a->d_meta + a->win_rows, n, a->d_rows, N,
-                           a->d_meta + 2ull * a->win_rows, a->d_counts, max_al);
+    // line metadata, per-line value counts and allele counts live in pinned host memory that the
+    // kernel reads / writes directly (a few hundred bytes over PCIe): the only copy per call is the rows
+    int rc = compose_lines(a->ctx, a->P, a->D, a->h_meta, a->h_meta + a->win_rows, n, a->d_rows, N,
+                           a->h_meta + 2ull * a->win_rows, a->h_counts, max_al);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(a->h_rows, a->d_rows, (size_t)n * N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(a->h_counts, a->d_counts, 8ull * n * max_al, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(a->h_meta + 2ull * a->win_rows, a->d_meta + 2ull * a->win_rows, 4ull * n, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // latency path of a random-access query: poll instead of sleeping on the completion interrupt
+    hipError_t q;
+    while ((q = hipStreamQuery(s)) == hipErrorNotReady) {
+    }
+    HIP_TRY(q);
     return XSI_OK;
 }
 
@@ -595,7 +595,6 @@ int xsi_accessor_open(xsi_accessor** out, xsi_hip_ctx* ctx, const char* path) {
     a->win_rows = (uint32_t)win;
     if (e == hipSuccess) e = hipMalloc((void**)&a->d_rows, (size_t)win * N * 4);
     if (e == hipSuccess) e = hipHostMalloc((void**)&a->h_rows, (size_t)win * N * 4, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc((void**)&a->d_meta, 12ull * win);
     if (e == hipSuccess) e = hipHostMalloc((void**)&a->h_meta, 12ull * win, hipHostMallocDefault);
     if (e != hipSuccess) {
         xsi_accessor_close(a);
@@ -653,8 +652,14 @@ int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_
     uint32_t row = 0;
     if (a->biallelic && n_alleles == 2) {
         if (!(a->win_n && offset >= a->win_first && offset < a->win_first + a->win_n)) {
+            // window length follows the access pattern: a request that continues the previous window
+            // doubles it (sequential scan -> few large compose + copy steps), a jump resets it to one
+            // line (random access -> no composing / copying of lines nobody asked for)
+            const bool sequential = a->win_n && a->win_block == (int64_t)block && offset == a->win_first + a->win_n;
+            a->win_target = sequential ? (a->win_target * 2u > a->win_rows ? a->win_rows : a->win_target * 2u) : 1u;
+            a->win_block = (int64_t)block;
             uint32_t n = a->P.n_bin - offset;
-            if (n > a->win_rows) n = a->win_rows;
+            if (n > a->win_target) n = a->win_target;
             int rc = accessor_compose(a, offset, n, 2);
             if (rc) return rc;
             a->win_first = offset;
@@ -746,9 +751,7 @@ void xsi_accessor_close(xsi_accessor* a) {
     if (a->d_mini) (void)hipFree(a->d_mini);
     if (a->d_rows) (void)hipFree(a->d_rows);
     if (a->h_rows) (void)hipHostFree(a->h_rows);
-    if (a->d_counts) (void)hipFree(a->d_counts);
     if (a->h_counts) (void)hipHostFree(a->h_counts);
-    if (a->d_meta) (void)hipFree(a->d_meta);
     if (a->h_meta) (void)hipHostFree(a->h_meta);
     if (a->ctx) xsi_hip_ctx_destroy(a->ctx);
     delete a;
