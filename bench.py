@@ -176,13 +176,16 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "synthetic %d hap x %d biallelic sites per GPU, MAC threshold %d, %d-line blocks "
-                                   "(BASELINE.json configs[1]), encode to .xsi + decode to packed bits, inputs in HBM"
-                                   % (N, S, thr, args.block_len),
+                                   "(%s), encode to .xsi + decode to packed bits, inputs in HBM"
+                                   % (N, S, thr, args.block_len,
+                                      "BASELINE.json configs[1]" if (N, S) == (5008, 1000000) else
+                                      "BASELINE.json configs[2] shape" if (N, S) == (64976, 2000000) else
+                                      "not a BASELINE.json config: parity / scaling case"),
                        "haps": N, "sites_per_gpu": S, "block_len": args.block_len, "mac_threshold": thr,
                        "seed": args.seed, "xsi_bytes_per_gpu": xsi_bytes, "bytes_per_cell": c,
                        "parallelism": "blocks sharded over %d GPU(s); RCCL gather of block streams" % world
                        if distributed else "1 GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_chain_lds (PBWT chain, encode)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": ("k_chain_lds" if N < 49152 else "k_chain_stream") + " (PBWT chain, encode)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc passes)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,

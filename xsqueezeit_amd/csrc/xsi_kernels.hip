@@ -210,7 +210,11 @@ struct ChainArgs {
     uint32_t batch;              // columns per prefetch batch
     uint32_t out_row_base;       // decode: first output row of the batch (binary line numbering offset)
     uint32_t only_haploid_blocks;// decode: skip blocks the element-major kernel already handled
+    uint32_t segments;           // encode, LDS kernel: workgroups per block (line segments), >= 1
+    uint32_t seg_q16[5];         // cumulative segment boundaries as fractions of n_wah (Q16), [0] = 0
 };
+
+constexpr uint32_t PRE_ID_CAP = 8192;  // line ids of a segment's prefix held in LDS
 
 constexpr int CHAIN_RMAX = 4;
 
@@ -393,6 +397,129 @@ __device__ __attribute__((noinline)) void chain_step_haploid(uint32_t a_off, uin
     chain_scatter<T, E, false, AT>(a, wcnt, av, keys, zc, w, lane, N, na);
 }
 
+// 64-lane inclusive prefix sum: 16-lane rows with row_shr, then row_bcast:15 / row_bcast:31
+// (gfx9 DPP) carry the row totals forward.
+__device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t v) {
+    v = row16_scan_incl(v);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// Segment pre-pass.  With fewer blocks than CUs a block's chain is cut into line segments, one
+// workgroup each.  A segment that starts at WAH line s0 needs a_{s0}; that order is the stable sort
+// of the haplotypes by their bits on lines [0, s0) (last line most significant), i.e. an LSD radix
+// sort with the lines as digits.  No permuted row has to be produced for those lines (the previous
+// segment's workgroup does that), so 4 lines are taken per pass: one pass = read `a`, read a 4-bit
+// key per member, 16-bin stable counting sort, scatter; 2 barriers per 4 lines instead of 8.
+//   keys    : nib[] holds one nibble per haplotype (bit k = line 4p+k), built from the 4 bit rows
+//             (prefetched one pass ahead); padding members get 0xF and stay last, as in the chain;
+//   in-wave : peer mask of a lane = lanes of its chunk with the same key (4 ballots), rank = mbcnt;
+//             hist[key][wave] doubles as the running count of earlier chunks;
+//   x-wave  : every wave scans the 16 x W counters (bin-major) itself, lanes fetch their bin base
+//             with one ds_bpermute.
+// The result equals the chain's `a` after s0 lines exactly (both are stable).
+template <int T, int E, typename AT>
+__device__ __forceinline__ void chain_prepass(AT* a, uint32_t* pre_ids, uint32_t* nib, uint32_t* hist,
+                                              const ChainArgs& A, uint32_t wah_first, uint32_t s0, uint32_t tid,
+                                              uint32_t lane, uint32_t w) {
+    constexpr int W = T / 64;
+    constexpr uint32_t NA = (uint32_t)T * E, NW = NA / 8u;  // nibble words: 8 haplotypes each
+    static_assert(NW <= (uint32_t)T, "one nibble word per thread");
+    static_assert(W == 16 || W == 4, "scan layouts below");
+    const uint32_t N = A.N;
+    const uint32_t src_words = (N + 31u) >> 5;
+    for (uint32_t i = tid; i < s0; i += T) pre_ids[i] = A.wah_lines[wah_first + i];
+    for (uint32_t i = tid; i < 2u * 16u * W; i += T) hist[i] = 0;
+    __syncthreads();
+    const uint32_t rw = tid >> 2, rb = (tid & 3u) * 8u;  // my row word / byte within it
+    const bool builder = tid < NW;
+    uint32_t pad_or = 0;  // bits at or beyond N read as 1
+    if (rw * 32u + 32u > N) pad_or = (rw * 32u >= N) ? 0xFFFFFFFFu : (0xFFFFFFFFu << (N - rw * 32u));
+    uint32_t R4[4];
+    auto load_rows = [&](uint32_t p) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t line = pre_ids[4u * p + (uint32_t)k];
+            R4[k] = (builder && rw < src_words) ? A.src[(size_t)line * A.src_stride_w + rw] : 0u;
+        }
+    };
+    auto build_nib = [&]() {
+        if (builder) {
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t x = ((R4[k] | pad_or) >> rb) & 0xFFu;  // 8 haplotypes of line 4p+k
+                x = (x | (x << 12)) & 0x000F000Fu;
+                x = (x | (x << 6)) & 0x03030303u;
+                x = (x | (x << 3)) & 0x11111111u;               // bit i -> bit 4i
+                out |= x << k;
+            }
+            nib[tid] = out;
+        }
+    };
+    load_rows(0);
+    build_nib();
+    __syncthreads();
+    const uint32_t n_pass = s0 >> 2;
+    AT* aw = a + w * (E * 64u) + lane;
+    for (uint32_t p = 0; p < n_pass; ++p) {
+        uint32_t* h_cur = hist + (p & 1u) * 16u * W;
+        uint32_t* h_nxt = hist + ((p + 1u) & 1u) * 16u * W;
+        const bool more = p + 1u < n_pass;
+        if (more) load_rows(p + 1u);
+        uint32_t av[E], key[E], rk[E];
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            av[e] = (uint32_t)aw[e * 64];
+        });
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            const uint32_t v = av[e];
+            key[e] = (nib[v >> 3] >> ((v & 7u) * 4u)) & 15u;
+        });
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            uint32_t pm_lo = 0xFFFFFFFFu, pm_hi = 0xFFFFFFFFu;  // lanes of this chunk with my key
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t nb = (uint32_t)__builtin_amdgcn_sbfe((int)key[e], k, 1);  // 0 or ~0
+                const uint64_t Bk = __ballot(nb != 0u);
+                pm_lo &= ~((uint32_t)Bk ^ nb);
+                pm_hi &= ~((uint32_t)(Bk >> 32) ^ nb);
+            }
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi(pm_hi, __builtin_amdgcn_mbcnt_lo(pm_lo, 0u));
+            const uint32_t cnt = (uint32_t)__popc(pm_lo) + (uint32_t)__popc(pm_hi);
+            uint32_t* hp = h_cur + key[e] * W + w;
+            const uint32_t old = *hp;  // same-key members in my wave's earlier chunks
+            if (before == 0u) *hp = old + cnt;
+            rk[e] = old + before;
+        });
+        __syncthreads();  // counters complete; every wave has read `a` and nib
+        // exclusive prefix over the 16 x W counters in bin-major order (every wave for itself)
+        uint32_t exv;
+        if constexpr (W == 16) {
+            const uint4 c = reinterpret_cast<const uint4*>(h_cur)[lane];  // counters 4*lane .. 4*lane+3
+            const uint32_t tot = c.x + c.y + c.z + c.w;
+            const uint32_t ex0 = wave_scan_incl_dpp(tot) - tot;
+            const uint32_t comp = w & 3u;  // counter (key, w) sits in lane key*4 + w/4, component w%4
+            exv = ex0 + (comp > 0u ? c.x : 0u) + (comp > 1u ? c.y : 0u) + (comp > 2u ? c.z : 0u);
+        } else {
+            const uint32_t c = h_cur[lane];
+            exv = wave_scan_incl_dpp(c) - c;
+        }
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            const uint32_t src_lane = (W == 16) ? key[e] * 4u + (w >> 2) : key[e] * 4u + w;
+            const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)exv);
+            a[base + rk[e]] = (AT)av[e];
+        });
+        if (lane < 16u) h_nxt[lane * W + w] = 0;
+        if (more) build_nib();
+        __syncthreads();  // scatter done, next keys in place
+    }
+}
+
 // AT = element type of `a` in LDS: uint32_t while the array fits (N <= 32768: full-rate 32-bit
 // LDS writes in the scatter), uint16_t beyond (adjacent lanes then share a dword, measured ~2x the
 // scatter cost, but 65536 members still fit one CU's LDS).
@@ -414,21 +541,48 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
     // the wave index is uniform: telling the compiler so turns per-wave arithmetic into SALU
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 
+    constexpr bool CAN_SPLIT = !DECODE && E <= 8;  // segment pre-pass: one nibble word per thread
     uint32_t wah_first, n_wah;
+    uint32_t seg_start = 0;
     if (DECODE) {
         if (dblocks[blockIdx.x].error) return;
         if (A.only_haploid_blocks && dblocks[blockIdx.x].off_line_haploid == VAL_UNDEFINED) return;
         wah_first = dblocks[blockIdx.x].wah_first;
         n_wah = dblocks[blockIdx.x].n_wah;
     } else {
-        if (A.only_haploid_blocks && !eblocks[blockIdx.x].has_haploid) return;
-        wah_first = eblocks[blockIdx.x].wah_first;
-        n_wah = eblocks[blockIdx.x].n_wah;
+        const uint32_t S = CAN_SPLIT ? A.segments : 1u;
+        const uint32_t blk = blockIdx.x / S, seg = blockIdx.x - blk * S;
+        if (A.only_haploid_blocks && !eblocks[blk].has_haploid) return;
+        wah_first = eblocks[blk].wah_first;
+        n_wah = eblocks[blk].n_wah;
+        if (S > 1u) {
+            // blocks with fully haploid lines, very short or very long chains stay in one piece
+            if (eblocks[blk].has_haploid || n_wah < 64u || n_wah > PRE_ID_CAP) {
+                if (seg) return;
+            } else {
+                seg_start = (uint32_t)(((uint64_t)n_wah * A.seg_q16[seg]) >> 16) & ~3u;
+                const uint32_t seg_end =
+                    seg + 1u == S ? n_wah : ((uint32_t)(((uint64_t)n_wah * A.seg_q16[seg + 1u]) >> 16) & ~3u);
+                if (seg_start >= seg_end) return;
+                n_wah = seg_end;  // shifted below, once the pre-pass has used the prefix
+            }
+        }
     }
     if (n_wah == 0) return;
 
     for (uint32_t i = tid; i < NA; i += T) a[i] = (AT)i;
     for (uint32_t i = tid; i < CW; i += T) xrow[i] = 0;
+    if constexpr (CAN_SPLIT) {
+        if (seg_start) {
+            uint32_t* pre_ids = linfo + 48;
+            uint32_t* nib = pre_ids + PRE_ID_CAP;
+            uint32_t* hist = nib + NA / 8u;
+            __syncthreads();
+            chain_prepass<T, E, AT>(a, pre_ids, nib, hist, A, wah_first, seg_start, tid, lane, w);
+            wah_first += seg_start;
+            n_wah -= seg_start;
+        }
+    }
 
     const uint32_t B = A.batch;
     const uint32_t cwp_mask = (1u << A.log2_cwp) - 1u;
@@ -1019,13 +1173,55 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
         k_chain_global<DECODE><<<dim3(n_blocks), dim3(1024), g.lds_bytes, s>>>(eb, db, A, scratch_a);
         return hipGetLastError();
     }
+    // Encode with fewer blocks than CUs: cut every block's chain into line segments (chain_prepass).
+    // A later segment first pays rho x (lines before it) for the radix pre-pass, so segments shrink:
+    // len_s = len_0 - rho * start_s, all segments finishing together.
+    uint32_t segs = 1;
+    uint32_t lds_bytes = g.lds_bytes;
+    A.segments = 1;
+    if (!DECODE && g.chunks <= 8 && !A.only_haploid_blocks) {
+        static const int env_s = [] {
+            const char* e = getenv("XSI_CHAIN_SEGMENTS");
+            return e ? atoi(e) : 0;
+        }();
+        static const double rho = [] {
+            const char* e = getenv("XSI_CHAIN_RHO");
+            return e ? atof(e) : 0.5;
+        }();
+        uint32_t S = 256u / n_blocks;
+        if (S > 4u) S = 4u;
+        if (env_s >= 1 && env_s <= 4) S = (uint32_t)env_s;
+        if (S > 1u) {
+            double lo = 0.0, hi = 1.0, bound[5] = {0, 0, 0, 0, 0};
+            for (int it = 0; it < 50; ++it) {
+                const double l0 = 0.5 * (lo + hi);
+                double start = 0.0;
+                for (uint32_t k = 0; k < S; ++k) {
+                    double len = l0 - rho * start;
+                    if (len < 0.0) len = 0.0;
+                    start += len;
+                    bound[k + 1] = start;
+                }
+                if (start < 1.0) lo = l0; else hi = l0;
+            }
+            for (uint32_t k = 0; k <= 4; ++k) {
+                double b = k < S ? bound[k] : 1.0;
+                if (b > 1.0) b = 1.0;
+                A.seg_q16[k] = (uint32_t)(b * 65536.0);
+            }
+            A.seg_q16[0] = 0;
+            segs = S;
+            A.segments = S;
+            lds_bytes += (PRE_ID_CAP + (uint32_t)(g.threads * g.chunks) / 8u + 2u * 16u * 16u) * 4u;
+        }
+    }
 #define XSI_CHAIN_CASE(TT, EE)                                                                              \
     if (g.threads == TT && g.chunks == EE) {                                                                \
         using AT = std::conditional_t<((TT) * (EE) <= 32768), uint32_t, uint16_t>;                          \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_lds<TT, EE, DECODE, AT>), \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
         if (e != hipSuccess) return e;                                                                      \
-        k_chain_lds<TT, EE, DECODE, AT><<<dim3(n_blocks), dim3(TT), g.lds_bytes, s>>>(eb, db, A);           \
+        k_chain_lds<TT, EE, DECODE, AT><<<dim3(n_blocks * segs), dim3(TT), lds_bytes, s>>>(eb, db, A);       \
         return hipGetLastError();                                                                           \
     }
     XSI_CHAIN_CASE(256, 1)

@@ -426,7 +426,12 @@ hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_
     const RankGeom g = rank_geometry(L.N, L.yp_stride, n_blocks);
     R.batch = g.batch;
     R.log2_cwp = g.log2_cwp;
-    if (!g.stage && L.yp_stride <= 1024u * 20u && L.yp_stride * 8u <= 160u * 1024u && !getenv("XSI_NO_BIG_RANK"))
+    static const uint32_t big_min = [] {
+        const char* e = getenv("XSI_BIG_RANK_MIN_N");
+        return e ? (uint32_t)atoi(e) : 49152u;  // measured: 11.3 ms against 14.2 ms at 64 976 hap x 64 blocks, slower at 40 000
+    }();
+    if ((!g.stage || L.N >= big_min) && L.yp_stride <= 1024u * 20u && L.yp_stride * 8u <= 160u * 1024u &&
+        !getenv("XSI_NO_BIG_RANK"))
         return launch_rank_big(s, n_blocks, R);
     return g.stage ? launch_rank<true>(s, g, n_blocks, R) : launch_rank<false>(s, g, n_blocks, R);
 }
