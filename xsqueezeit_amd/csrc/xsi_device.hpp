@@ -41,6 +41,24 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
     }
     return v;
 }
+// 16-lane inclusive prefix sum with DPP row shifts (v_add_u32_dpp row_shr:1/2/4/8, bound_ctrl:0).
+__device__ __forceinline__ uint32_t row16_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    return v;
+}
+
+// 64-lane inclusive prefix sum: 16-lane rows with row_shr, then row_bcast:15 / row_bcast:31
+// (gfx9 DPP) carry the row totals forward.
+__device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t v) {
+    v = row16_scan_incl(v);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 __device__ __forceinline__ uint64_t wave_scan_incl64(uint64_t v) {
     const uint32_t lane = lane_id();
 #pragma unroll
@@ -111,8 +129,8 @@ __device__ __forceinline__ void wah_encode_chunk(uint32_t val, bool valid, bool 
                                                  WahCarry& c, uint16_t* __restrict__ dst) {
     const uint32_t lane = lane_id();
     const uint32_t t = (val == 0u) ? 0u : ((val == 0x7FFFu) ? 1u : 2u);
-    uint32_t prev_t = __shfl_up(t, 1, 64);
-    if (lane == 0) prev_t = c.type;
+    // type of the previous lane: DPP wave_shr:1, lane 0 takes the carry
+    const uint32_t prev_t = (uint32_t)__builtin_amdgcn_update_dpp((int)c.type, (int)t, 0x138, 0xF, 0xF, false);
     const bool head = valid && (t == 2u || t != prev_t);
     const uint64_t H = __ballot(head);
     const uint64_t V = __ballot(valid);
@@ -135,22 +153,19 @@ __device__ __forceinline__ void wah_encode_chunk(uint32_t val, bool valid, bool 
         const uint32_t nt = (next_val == 0u) ? 0u : ((next_val == 0x7FFFu) ? 1u : 2u);
         is_end = last_chunk || nt == 2u || nt != t;
     }
-    uint32_t emit = 0;
-    if (valid) {
-        if (t == 2u)
-            emit = 1;
-        else if (is_end)
-            emit = (len + WAH_MAXC - 1u) / WAH_MAXC;
-    }
+    // a run longer than 16383 groups (needs > 245 745 bits) emits several fill words: rare, and
+    // the only case that needs a division and a full scan
+    uint32_t emit = (valid && (t == 2u || is_end)) ? 1u : 0u;
     uint32_t pos, total;
-    if (!__any(emit > 1u)) {
+    if (!__any(emit && t < 2u && len > WAH_MAXC)) {
         const uint64_t E = __ballot(emit == 1u);
         pos = mbcnt64(E);
         total = (uint32_t)__popcll(E);
     } else {
-        const uint32_t inc = wave_scan_incl(emit);
+        if (emit && t < 2u) emit = (len + WAH_MAXC - 1u) / WAH_MAXC;
+        const uint32_t inc = wave_scan_incl_dpp(emit);
         pos = inc - emit;
-        total = __shfl(inc, 63, 64);
+        total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     }
     if (WRITE && emit) {
         uint16_t* o = dst + c.out + pos;
@@ -164,8 +179,8 @@ __device__ __forceinline__ void wah_encode_chunk(uint32_t val, bool valid, bool 
     }
     // carry = state after the last valid lane
     const uint32_t last = nvalid ? nvalid - 1u : 0u;
-    const uint32_t lt = __shfl(t, last, 64);
-    const uint32_t ll = __shfl(len, last, 64);
+    const uint32_t lt = (uint32_t)__builtin_amdgcn_readlane((int)t, (int)last);
+    const uint32_t ll = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)last);
     if (nvalid) {
         c.type = lt;
         c.len = (lt < 2u) ? ll : 0u;
@@ -173,20 +188,25 @@ __device__ __forceinline__ void wah_encode_chunk(uint32_t val, bool valid, bool 
     c.out += total;
 }
 
-// Encode a whole packed bit row with one wave.  Returns the number of WAH16 words.
+// Encode a whole packed bit row with one wave.  Returns the number of WAH16 words.  The groups of
+// the next two chunks are loaded before the current chunk is encoded, so the serial run-merging
+// logic never waits on memory.
 template <bool WRITE>
 __device__ __forceinline__ uint32_t wave_wah_encode_row(const uint32_t* __restrict__ row, uint32_t nbits,
                                                         uint16_t* __restrict__ dst) {
     const uint32_t lane = lane_id();
     const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
     WahCarry c{3u, 0u, 0u};
+    uint32_t cur = lane < G ? load_group15(row, lane, nbits) : 0u;
+    uint32_t n1 = lane + 64u < G ? load_group15(row, lane + 64u, nbits) : 0u;
     for (uint32_t g0 = 0; g0 < G; g0 += 64u) {
-        const uint32_t g = g0 + lane;
-        const bool valid = g < G;
-        const uint32_t val = valid ? load_group15(row, g, nbits) : 0u;
+        const uint32_t g2 = g0 + 128u + lane;
+        const uint32_t n2 = g2 < G ? load_group15(row, g2, nbits) : 0u;
         const bool last = g0 + 64u >= G;
-        const uint32_t next_val = last ? 0u : load_group15(row, g0 + 64u, nbits);
-        wah_encode_chunk<WRITE>(val, valid, last, next_val, c, dst);
+        const uint32_t next_val = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1);  // group g0+64 (0 past the end)
+        wah_encode_chunk<WRITE>(cur, g0 + lane < G, last, next_val, c, dst);
+        cur = n1;
+        n1 = n2;
     }
     return c.out;
 }
@@ -196,19 +216,25 @@ __device__ __forceinline__ uint32_t wave_wah_encode_row(const uint32_t* __restri
 // read.  Returns the words consumed; *ones = set bits counted like the reference (fills count
 // whole groups).  The caller must barrier before reading `row`.  row == nullptr: count only
 // (wah2_advance_pointer_count_ones, wah.hpp:125-150).
+// `pre0` = src[lane] (0 where lane >= max_words), loaded by the caller ahead of time; the words of
+// the next iteration are fetched before the current ones are used (an iteration that does not end
+// the line consumes exactly 64 words, so the prefetch is never wasted).
 __device__ __forceinline__ uint32_t wave_wah_expand_row(const uint16_t* __restrict__ src, uint32_t max_words,
-                                                        uint32_t nbits, uint32_t* row /*LDS*/, uint32_t* ones) {
+                                                        uint32_t nbits, uint32_t* row /*LDS*/, uint32_t* ones,
+                                                        uint32_t pre0) {
     const uint32_t lane = lane_id();
     const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
     const uint32_t row_bits = ((nbits + 31u) >> 5) << 5;
     uint32_t gbase = 0, wbase = 0, cnt1 = 0;
+    uint32_t cur = pre0;
     while (gbase < G && wbase < max_words) {
         const uint32_t wi = wbase + lane;
         const bool have = wi < max_words;
-        const uint32_t word = have ? (uint32_t)src[wi] : 0u;
+        const uint32_t nxt = wi + 64u < max_words ? (uint32_t)src[wi + 64u] : 0u;
+        const uint32_t word = have ? cur : 0u;
         const bool fill = (word & 0x8000u) != 0u;
         const uint32_t ng = have ? (fill ? (word & WAH_MAXC) : 1u) : 0u;
-        const uint32_t inc = wave_scan_incl(ng);
+        const uint32_t inc = wave_scan_incl_dpp(ng);
         const uint32_t s = gbase + inc - ng;  // first group covered by this word
         const bool active = have && s < G;
         if (active) {
@@ -229,7 +255,8 @@ __device__ __forceinline__ uint32_t wave_wah_expand_row(const uint16_t* __restri
         while (F) {
             const int f = __ffsll((long long)F) - 1;
             F &= F - 1ull;
-            const uint32_t fs = __shfl(s, f, 64), fn = __shfl(ng, f, 64);
+            const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)s, f);
+            const uint32_t fn = (uint32_t)__builtin_amdgcn_readlane((int)ng, f);
             uint32_t b0 = fs * WAH_BITS, b1 = b0 + fn * WAH_BITS;
             if (b1 > row_bits) b1 = row_bits;
             if (b0 >= b1) continue;
@@ -244,13 +271,21 @@ __device__ __forceinline__ uint32_t wave_wah_expand_row(const uint16_t* __restri
         const uint64_t A = __ballot(active);
         const uint32_t used = (uint32_t)__popcll(A);
         // groups covered by the consumed words
-        const uint32_t covered = __shfl(inc, used ? used - 1u : 0u, 64);
+        const uint32_t covered = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(used ? used - 1u : 0u));
         gbase += used ? covered : 0u;
         wbase += used;
         if (used < 64u) break;
+        cur = nxt;
     }
     *ones = wave_sum(cnt1);
     return wbase;
+}
+
+// Same, fetching the first words itself.
+__device__ __forceinline__ uint32_t wave_wah_expand_row(const uint16_t* __restrict__ src, uint32_t max_words,
+                                                        uint32_t nbits, uint32_t* row /*LDS*/, uint32_t* ones) {
+    const uint32_t lane = lane_id();
+    return wave_wah_expand_row(src, max_words, nbits, row, ones, lane < max_words ? (uint32_t)src[lane] : 0u);
 }
 
 }  // namespace xsi

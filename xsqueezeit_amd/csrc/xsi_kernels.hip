@@ -218,15 +218,6 @@ constexpr uint32_t PRE_ID_CAP = 8192;  // line ids of a segment's prefix held in
 
 constexpr int CHAIN_RMAX = 4;
 
-// 16-lane inclusive prefix sum with DPP row shifts (v_add_u32_dpp row_shr:1/2/4/8, bound_ctrl:0).
-__device__ __forceinline__ uint32_t row16_scan_incl(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
-    return v;
-}
-
 // v_writelane_b32 with a constant lane select: put a wave-uniform value into one lane of a VGPR
 // (no clang builtin exists).  The lane select is an inline constant, so the VALU-writes-SGPR ->
 // lane-select hazard does not arise; the SGPR data operand is interlocked like any VALU source.
@@ -395,15 +386,6 @@ __device__ __attribute__((noinline)) void chain_step_haploid(uint32_t a_off, uin
         orow[i] = v;
     }
     chain_scatter<T, E, false, AT>(a, wcnt, av, keys, zc, w, lane, N, na);
-}
-
-// 64-lane inclusive prefix sum: 16-lane rows with row_shr, then row_bcast:15 / row_bcast:31
-// (gfx9 DPP) carry the row totals forward.
-__device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t v) {
-    v = row16_scan_incl(v);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
-    return v;
 }
 
 // Segment pre-pass.  With fewer blocks than CUs a block's chain is cut into line segments, one
@@ -1186,7 +1168,7 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
         }();
         static const double rho = [] {
             const char* e = getenv("XSI_CHAIN_RHO");
-            return e ? atof(e) : 0.5;
+            return e ? atof(e) : 0.47;  // measured best at the bench size (0.25 ... 0.6 swept)
         }();
         uint32_t S = 256u / n_blocks;
         if (S > 4u) S = 4u;
@@ -1288,23 +1270,33 @@ hipError_t launch_chain_decode(hipStream_t s, const DecBlock* blocks, uint32_t n
 // WAH16 sizing and writing of the permuted rows (wah_encode2_with_size, wah.hpp:506-578).
 // One wave per WAH line; the sizing pass and the writing pass run the same encoder.
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t WAH_LINES_PER_WAVE = 4;  // amortises the dependent metadata loads of a line
+
 __global__ void __launch_bounds__(256) k_wah_sizes(EncLines L, const uint32_t* __restrict__ d_total_wah) {
-    const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (j >= d_total_wah[0]) return;
-    const uint32_t l = L.wah_lines[j];
-    uint32_t nbits = nbits_of(L, l);
-    const uint32_t* row = reinterpret_cast<const uint32_t*>(L.yrows + (size_t)j * L.y_stride64);
-    uint32_t n;
-    if (L.wah_scratch)
-        n = wave_wah_encode_row<true>(row, nbits, L.wah_scratch + (size_t)j * L.wah_scratch_stride);
-    else
-        n = wave_wah_encode_row<false>(row, nbits, nullptr);
-    if (lane_id() == 0) L.wah_len[j] = n;
+    const uint32_t lane = lane_id();
+    const uint32_t j0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * WAH_LINES_PER_WAVE;
+    const uint32_t total = d_total_wah[0];
+    if (j0 >= total) return;
+    // lane k fetches the metadata of line j0 + k; the lines are then encoded one after the other
+    uint32_t m_nbits = 0;
+    if (lane < WAH_LINES_PER_WAVE && j0 + lane < total) m_nbits = nbits_of(L, L.wah_lines[j0 + lane]);
+    for (uint32_t k = 0; k < WAH_LINES_PER_WAVE && j0 + k < total; ++k) {
+        const uint32_t j = j0 + k;
+        const uint32_t nbits = (uint32_t)__builtin_amdgcn_readlane((int)m_nbits, (int)k);
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(L.yrows + (size_t)j * L.y_stride64);
+        uint32_t n;
+        if (L.wah_scratch)
+            n = wave_wah_encode_row<true>(row, nbits, L.wah_scratch + (size_t)j * L.wah_scratch_stride);
+        else
+            n = wave_wah_encode_row<false>(row, nbits, nullptr);
+        if (lane == 0) L.wah_len[j] = n;
+    }
 }
 
 hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_total_wah, uint32_t max_wah) {
     if (!max_wah) return hipSuccess;
-    k_wah_sizes<<<dim3((max_wah + 3u) / 4u), dim3(256), 0, s>>>(L, d_total_wah);
+    const uint32_t per_wg = 4u * WAH_LINES_PER_WAVE;
+    k_wah_sizes<<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), 0, s>>>(L, d_total_wah);
     return hipGetLastError();
 }
 
@@ -1988,34 +1980,70 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
                                                    DecLines L, const uint32_t* __restrict__ d_totals) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* row = reinterpret_cast<uint32_t*>(smem);
-    const uint32_t j = blockIdx.x;
-    if (j >= d_totals[1] || d_totals[3]) return;
-    const uint32_t l = L.wah_lines[j];
-    const DecBlock& D = blocks[L.line_block[l]];
-    const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
+    const uint32_t j0 = blockIdx.x * WAH_LINES_PER_WAVE;
+    const uint32_t total = d_totals[1];
+    if (j0 >= total || d_totals[3]) return;
     const uint32_t lane = lane_id();
     const uint32_t rw = L.y_stride64 * 2u;
     for (uint32_t i = lane; i < rw; i += 64u) row[i] = 0;
-    __syncthreads();
-    const uint32_t start = L.wah_start[j];
-    const uint16_t* src = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah) + start;
-    uint32_t ones;
-    (void)wave_wah_expand_row(src, D.wah_words - start, nbits, row, &ones);
-    __syncthreads();
-    // {32 row bits, ones before them}: the decode chain's rank-select table for this line
-    uint2* dst = L.yp + (size_t)j * L.yp_stride;
-    uint32_t base = 0;
-    for (uint32_t i0 = 0; i0 < L.yp_stride; i0 += 64u) {
-        const uint32_t i = i0 + lane;
-        const uint32_t v = i < rw ? row[i] : 0u;
-        const uint32_t c = (uint32_t)__popc(v);
-        const uint32_t inc = wave_scan_incl(c);
-        if (i < L.yp_stride) dst[i] = make_uint2(v, base + inc - c);
-        base += __shfl(inc, 63, 64);
+    // lane k fetches the metadata of line j0 + k (a chain of four dependent loads, paid once per wave)
+    uint32_t m_l = 0, m_nbits = 0, m_maxw = 0;
+    uint64_t m_src = 0;
+    if (lane < WAH_LINES_PER_WAVE && j0 + lane < total) {
+        m_l = L.wah_lines[j0 + lane];
+        const DecBlock& D = blocks[L.line_block[m_l]];
+        const uint32_t start = L.wah_start[j0 + lane];
+        m_nbits = (L.kind[m_l] & KIND_HAPLOID) ? L.n_samples : L.N;
+        m_maxw = D.wah_words - start;
+        m_src = reinterpret_cast<uint64_t>(file + D.gt_off + D.off_wah) + 2ull * start;
     }
-    if (lane == 0) {
-        L.ones[l] = ones;
-        L.wah_z[j] = nbits - base;
+    auto src_of = [&](uint32_t k) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m_src, (int)k);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m_src >> 32), (int)k);
+        return reinterpret_cast<const uint16_t*>(((uint64_t)hi << 32) | lo);
+    };
+    const uint16_t* src = src_of(0);
+    uint32_t maxw = (uint32_t)__builtin_amdgcn_readlane((int)m_maxw, 0);
+    uint32_t pre = lane < maxw ? (uint32_t)src[lane] : 0u;
+    __syncthreads();
+    for (uint32_t k = 0; k < WAH_LINES_PER_WAVE && j0 + k < total; ++k) {
+        const uint32_t j = j0 + k;
+        const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)m_l, (int)k);
+        const uint32_t nbits = (uint32_t)__builtin_amdgcn_readlane((int)m_nbits, (int)k);
+        // first words of the next line while this one is expanded
+        const uint16_t* src_n = src;
+        uint32_t maxw_n = 0, pre_n = 0;
+        if (k + 1u < WAH_LINES_PER_WAVE && j + 1u < total) {
+            src_n = src_of(k + 1u);
+            maxw_n = (uint32_t)__builtin_amdgcn_readlane((int)m_maxw, (int)(k + 1u));
+            pre_n = lane < maxw_n ? (uint32_t)src_n[lane] : 0u;
+        }
+        uint32_t ones;
+        (void)wave_wah_expand_row(src, maxw, nbits, row, &ones, pre);
+        __syncthreads();
+        // {32 row bits, ones before them}: the decode chain's rank-select table for this line
+        uint2* dst = L.yp + (size_t)j * L.yp_stride;
+        uint32_t base = 0;
+        for (uint32_t i0 = 0; i0 < L.yp_stride; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            uint32_t v = 0;
+            if (i < rw) {
+                v = row[i];
+                row[i] = 0;  // ready for the next line
+            }
+            const uint32_t c = (uint32_t)__popc(v);
+            const uint32_t inc = wave_scan_incl_dpp(c);
+            if (i < L.yp_stride) dst[i] = make_uint2(v, base + inc - c);
+            base += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+        if (lane == 0) {
+            L.ones[l] = ones;
+            L.wah_z[j] = nbits - base;
+        }
+        __syncthreads();
+        src = src_n;
+        maxw = maxw_n;
+        pre = pre_n;
     }
 }
 
@@ -2026,7 +2054,8 @@ hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock*
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_expand),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_wah_expand<<<dim3(max_wah), dim3(64), lds, s>>>(file, blocks, L, d_totals);
+    k_wah_expand<<<dim3((max_wah + WAH_LINES_PER_WAVE - 1u) / WAH_LINES_PER_WAVE), dim3(64), lds, s>>>(file, blocks, L,
+                                                                                                  d_totals);
     return hipGetLastError();
 }
 
