@@ -24,6 +24,15 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// v_writelane_b32: put a wave-uniform value into one lane of a VGPR.  clang has no builtin for it;
+// binding the LLVM intrinsic by name keeps the compiler in charge of the SGPR hazards (an inline
+// asm version of this produced wrong rows).
+extern "C" __device__ uint32_t __xsi_writelane_u32(uint32_t value, uint32_t lane, uint32_t old)
+    __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t write_lane(uint32_t old, uint32_t uniform_value, uint32_t lane) {
+    return __xsi_writelane_u32(uniform_value, lane, old);
+}
+
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
 // popcount(mask & lanes below me)

@@ -218,15 +218,6 @@ constexpr uint32_t PRE_ID_CAP = 8192;  // line ids of a segment's prefix held in
 
 constexpr int CHAIN_RMAX = 4;
 
-// v_writelane_b32 with a constant lane select: put a wave-uniform value into one lane of a VGPR
-// (no clang builtin exists).  The lane select is an inline constant, so the VALU-writes-SGPR ->
-// lane-select hazard does not arise; the SGPR data operand is interlocked like any VALU source.
-template <int LANE>
-__device__ __forceinline__ uint32_t write_lane(uint32_t vdst, uint32_t sval) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(vdst) : "s"(sval), "n"(LANE));
-    return vdst;
-}
-
 // Per-lane key bits of up to 64 chunks, kept as two 32-bit halves so every access is one VALU op.
 template <int E>
 struct KeyBits {
@@ -674,10 +665,8 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
                     // v_bfe_u32 uses only the low 5 bits of its offset operand: no explicit v & 31
                     const uint32_t bit = __builtin_amdgcn_ubfe(c[v >> 5], v, 1u);
                     m = __ballot(bit != 0u);
-                    if (lane == (uint32_t)e) {
-                        mine_lo = (uint32_t)m;
-                        mine_hi = (uint32_t)(m >> 32);
-                    }
+                    mine_lo = write_lane(mine_lo, (uint32_t)m, (uint32_t)e);
+                    mine_hi = write_lane(mine_hi, (uint32_t)(m >> 32), (uint32_t)e);
                     if (!MASKS_IN_SGPR) keys.template set<e>(bit);
                 }
                 if constexpr (MASKS_IN_SGPR) ms[e] = m;
@@ -1034,10 +1023,8 @@ __global__ void __launch_bounds__(1024) k_chain_stream(const EncBlock* __restric
 #pragma unroll
             for (uint32_t u = 0; u < U; ++u) {
                 const uint64_t om = step(std::true_type{}, base + u * 64u, v[u]);
-                if (lane == u) {
-                    mine_lo = (uint32_t)om;
-                    mine_hi = (uint32_t)(om >> 32);
-                }
+                mine_lo = write_lane(mine_lo, (uint32_t)om, u);
+                mine_hi = write_lane(mine_hi, (uint32_t)(om >> 32), u);
             }
             if (lane < U) yr[(base >> 6) + lane] = make_uint2(mine_lo, mine_hi);
         }

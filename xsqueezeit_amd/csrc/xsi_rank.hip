@@ -99,10 +99,8 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
                 const uint32_t ob = pr.y + (uint32_t)__popc(pr.x & ((1u << (r[e] & 31u)) - 1u));
                 r[e] = bit ? Z + ob : r[e] - ob;
                 const uint64_t m = __ballot(bit != 0u);
-                if (lane == (uint32_t)e) {
-                    mine_lo = (uint32_t)m;
-                    mine_hi = (uint32_t)(m >> 32);
-                }
+                mine_lo = write_lane(mine_lo, (uint32_t)m, (uint32_t)e);
+                mine_hi = write_lane(mine_hi, (uint32_t)(m >> 32), (uint32_t)e);
             });
             if (store_lane) {
                 uint2* orow = reinterpret_cast<uint2*>(A.out + (size_t)line * A.out_stride_w);
@@ -171,10 +169,8 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
                 const uint32_t ob = pr[e].y + (uint32_t)__popc(pr[e].x & ((1u << (r[e] & 31u)) - 1u));
                 r[e] = bit ? Z + ob : r[e] - ob;
                 const uint64_t m = __ballot(bit != 0u);
-                if (lane == (uint32_t)e) {
-                    mine_lo = (uint32_t)m;
-                    mine_hi = (uint32_t)(m >> 32);
-                }
+                mine_lo = write_lane(mine_lo, (uint32_t)m, (uint32_t)e);
+                mine_hi = write_lane(mine_hi, (uint32_t)(m >> 32), (uint32_t)e);
             });
             if (store_lane) {
                 uint2* orow = reinterpret_cast<uint2*>(A.out + (size_t)line * A.out_stride_w);
@@ -272,10 +268,8 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
                 const uint32_t ob = pr[e].y + (uint32_t)__popc(pr[e].x & ((1u << (rr & 31u)) - 1u));
                 r[g0 + e] = bit ? Z + ob : rr - ob;
                 const uint64_t m = __ballot(bit != 0u);
-                if (lane == (uint32_t)(g0 + e)) {
-                    mine_lo = (uint32_t)m;
-                    mine_hi = (uint32_t)(m >> 32);
-                }
+                mine_lo = write_lane(mine_lo, (uint32_t)m, (uint32_t)(g0 + e));
+                mine_hi = write_lane(mine_hi, (uint32_t)(m >> 32), (uint32_t)(g0 + e));
             });
         });
         if (store_lane) {
