@@ -1865,31 +1865,51 @@ __global__ void __launch_bounds__(1024) k_wah_boundaries(const uint8_t* __restri
         __syncthreads();
     }
     uint64_t gbase = 0;
+    // words of the next tile are fetched before the current tile is scanned
+    uint32_t nxt[K];
+    auto fetch = [&](uint32_t c0) {
+        const uint32_t w0 = c0 + threadIdx.x * K;
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) nxt[k] = (w0 + k < nwords) ? (uint32_t)wm[w0 + k] : 0u;
+    };
+    fetch(0);
     for (uint32_t c0 = 0; c0 < nwords; c0 += blockDim.x * K) {
         const uint32_t w0 = c0 + threadIdx.x * K;
         uint32_t g[K];
         uint32_t sum = 0;
 #pragma unroll
         for (uint32_t k = 0; k < K; ++k) {
-            const uint32_t wi = w0 + k;
-            uint32_t ng = 0;
-            if (wi < nwords) {
-                const uint32_t word = wm[wi];
-                ng = (word & 0x8000u) ? (word & WAH_MAXC) : 1u;
-            }
+            const uint32_t word = nxt[k];
+            const uint32_t ng = (w0 + k < nwords) ? ((word & 0x8000u) ? (word & WAH_MAXC) : 1u) : 0u;
             g[k] = ng;
             sum += ng;
         }
+        if (c0 + blockDim.x * K < nwords) fetch(c0 + blockDim.x * K);
         uint64_t tot;
         uint64_t ex = gbase + block_scan_excl64(sum, s_scan, &tot);
+        // uniform lines: line index and offset inside the line by ONE division per thread, then
+        // carried along word by word (a word never spans two lines, so the offset wraps exactly)
+        uint64_t jline = 0;
+        uint32_t rem = 0;
+        if (!mixed && sum) {
+            if ((ex >> 32) == 0) {
+                jline = (uint32_t)ex / Gd;
+                rem = (uint32_t)ex - (uint32_t)jline * Gd;
+            } else {
+                jline = ex / Gd;
+                rem = (uint32_t)(ex - jline * Gd);
+            }
+        }
 #pragma unroll
         for (uint32_t k = 0; k < K; ++k) {
             const uint32_t wi = w0 + k;
             if (wi < nwords && g[k]) {
                 if (!mixed) {
-                    if (ex % Gd == 0) {
-                        const uint64_t j = ex / Gd;
-                        if (j < D.n_wah) L.wah_start[D.wah_first + (uint32_t)j] = wi;
+                    if (rem == 0 && jline < D.n_wah) L.wah_start[D.wah_first + (uint32_t)jline] = wi;
+                    rem += g[k];
+                    while (rem >= Gd) {
+                        rem -= Gd;
+                        ++jline;
                     }
                 } else {
                     // first line whose cumulative offset is >= ex
