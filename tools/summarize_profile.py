@@ -27,19 +27,20 @@ def per_kernel(counter_csv):
 
 
 def newest(pattern):
-    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    fs = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
     return fs[-1:]
 
 
 def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     os.makedirs(dst, exist_ok=True)
-    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "%s_bench.json" % tag))
-    stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+    if os.path.exists(os.path.join(src, "bench.json")):
+        shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "%s_bench.json" % tag))
+    stats = newest(os.path.join(src, "stats", "**", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
-    fetch = newest(os.path.join(src, "fetch", "*", "*_counter_collection.csv"))
-    write = newest(os.path.join(src, "write", "*", "*_counter_collection.csv"))
+    fetch = newest(os.path.join(src, "fetch", "**", "*_counter_collection.csv"))
+    write = newest(os.path.join(src, "write", "**", "*_counter_collection.csv"))
     traffic = {}
     if fetch and write:
         f = per_kernel(fetch[0])
