@@ -108,12 +108,16 @@ def main():
     def step():
         binding.check(L.xsi_hip_encode_packed(ctx.handle, ctypes.byref(p), d_bits.data_ptr(), S, stride,
                                               d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)))
+        handle = None
+        if distributed:
+            # the path's one exchange step: compressed block streams -> writer rank over RCCL/xGMI,
+            # started as soon as the encode is done and overlapped with the decode (both only read d_out)
+            handle = xdist.gather_block_streams_async(d_out, res.blocks_bytes, d_off - 256, tdist, dev)
         flen = make_file_image()
         binding.check(L.xsi_hip_decode_packed(ctx.handle, d_file.data_ptr(), flen, 0, n_blocks, d_dec.data_ptr(),
                                               stride, S, ctypes.byref(rows), None))
-        if distributed:
-            # the path's one exchange step: compressed block streams -> writer rank over RCCL/xGMI
-            state["gathered"] = xdist.gather_block_streams(d_out[:res.blocks_bytes], d_off - 256, tdist, dev)
+        if handle is not None:
+            state["gathered"] = handle.wait()
 
     def fence():
         torch.cuda.synchronize()
