@@ -436,9 +436,18 @@ __device__ __forceinline__ void chain_prepass(AT* a, uint32_t* pre_ids, uint32_t
     __syncthreads();
     const uint32_t n_pass = s0 >> 2;
     AT* aw = a + w * (E * 64u) + lane;
+    // LDS integer addresses with the arrays' own addresses folded into wave-uniform constants
+    using LdsU32 = __attribute__((address_space(3))) uint32_t;
+    using LdsAT = __attribute__((address_space(3))) AT;
+    constexpr uint32_t ASH = sizeof(AT) == 4 ? 2u : 1u;
+    constexpr uint32_t LOGW = (W == 16) ? 4u : 2u;
+    const uint32_t a_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)a;
+    const uint32_t nib_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)nib;
+    const uint32_t hist_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)hist;
     for (uint32_t p = 0; p < n_pass; ++p) {
         uint32_t* h_cur = hist + (p & 1u) * 16u * W;
         uint32_t* h_nxt = hist + ((p + 1u) & 1u) * 16u * W;
+        const uint32_t hcur_w = hist_lds + ((p & 1u) * 16u * W + w) * 4u;  // &h_cur[0][w]
         const bool more = p + 1u < n_pass;
         if (more) load_rows(p + 1u);
         uint32_t av[E], key[E], rk[E];
@@ -449,7 +458,8 @@ __device__ __forceinline__ void chain_prepass(AT* a, uint32_t* pre_ids, uint32_t
         static_for<0, E>([&](auto ecn) {
             constexpr int e = decltype(ecn)::value;
             const uint32_t v = av[e];
-            key[e] = (nib[v >> 3] >> ((v & 7u) * 4u)) & 15u;
+            const uint32_t word = *reinterpret_cast<LdsU32*>((uintptr_t)(nib_lds + ((v >> 1) & ~3u)));
+            key[e] = __builtin_amdgcn_ubfe(word, (v << 2) & 28u, 4u);
         });
         static_for<0, E>([&](auto ecn) {
             constexpr int e = decltype(ecn)::value;
@@ -463,10 +473,10 @@ __device__ __forceinline__ void chain_prepass(AT* a, uint32_t* pre_ids, uint32_t
             }
             const uint32_t before = __builtin_amdgcn_mbcnt_hi(pm_hi, __builtin_amdgcn_mbcnt_lo(pm_lo, 0u));
             const uint32_t cnt = (uint32_t)__popc(pm_lo) + (uint32_t)__popc(pm_hi);
-            uint32_t* hp = h_cur + key[e] * W + w;
+            LdsU32* hp = reinterpret_cast<LdsU32*>((uintptr_t)(hcur_w + (key[e] << (2u + LOGW))));
             const uint32_t old = *hp;  // same-key members in my wave's earlier chunks
             if (before == 0u) *hp = old + cnt;
-            rk[e] = old + before;
+            rk[e] = (old + before) << ASH;  // byte offset inside my bin
         });
         __syncthreads();  // counters complete; every wave has read `a` and nib
         // exclusive prefix over the 16 x W counters in bin-major order (every wave for itself)
@@ -481,11 +491,12 @@ __device__ __forceinline__ void chain_prepass(AT* a, uint32_t* pre_ids, uint32_t
             const uint32_t c = h_cur[lane];
             exv = wave_scan_incl_dpp(c) - c;
         }
+        exv = (exv << ASH) + a_lds;  // LDS byte address of the bin's first slot
+        const uint32_t src_base = (W == 16) ? (w >> 2) << 2 : w << 2;  // bpermute byte index of lane (key*4 + ...)
         static_for<0, E>([&](auto ecn) {
             constexpr int e = decltype(ecn)::value;
-            const uint32_t src_lane = (W == 16) ? key[e] * 4u + (w >> 2) : key[e] * 4u + w;
-            const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)exv);
-            a[base + rk[e]] = (AT)av[e];
+            const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((key[e] << 4) + src_base), (int)exv);
+            *reinterpret_cast<LdsAT*>((uintptr_t)(base + rk[e])) = (AT)av[e];
         });
         if (lane < 16u) h_nxt[lane * W + w] = 0;
         if (more) build_nib();
@@ -617,15 +628,19 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
     __syncthreads();
 
     AT* aw = a + w * (E * 64u) + lane;  // my element of chunk e is aw[e*64]
+    using LdsAT = __attribute__((address_space(3))) AT;
+    const uint32_t a_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     for (uint32_t bt = 0; bt < n_batches; ++bt) {
         const bool more = bt + 1u < n_batches;
         load_info(bt + 2u);
         if (more) load_cols(bt + 1u);
         const uint32_t jn = (n_wah - bt * B) < B ? (n_wah - bt * B) : B;
+        uint32_t info_v = linfo[(bt % 3u) * 16u];  // line id of the next step, read one step ahead
         for (uint32_t jj = 0; jj < jn; ++jj) {
             const uint32_t rank = wah_first + bt * B + jj;
             const uint32_t* c = col + ((bt & 1u) * B + jj) * CW;
-            const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)linfo[(bt % 3u) * 16u + jj]);
+            const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)info_v);
+            if (jj + 1u < jn) info_v = linfo[(bt % 3u) * 16u + jj + 1u];
             const uint32_t line = info & 0x7FFFFFFFu;
             if (info >> 31) {
                 uint32_t* orow = DECODE ? A.dst + (size_t)(line - A.out_row_base) * A.dst_stride_w
@@ -699,9 +714,10 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
             uint32_t sc = row16_scan_incl(lane < (uint32_t)W ? wcnt[lane] : 0u);
             const uint32_t tz = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
             constexpr uint32_t AS = sizeof(AT), ASH = sizeof(AT) == 4 ? 2u : 1u;
-            uint32_t zb2 = (w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u) * AS;
-            uint32_t ob2 = (tz + w * (E * 64u)) * AS - zb2;  // byte address of my wave's first one
-            unsigned char* abytes = reinterpret_cast<unsigned char*>(a);
+            // LDS byte addresses, with the array's own LDS address folded into the wave-uniform bases
+            // (one VALU op per chunk less than indexing through the `smem` symbol)
+            uint32_t zb2 = (w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u) * AS + a_lds;
+            uint32_t ob2 = (tz + w * (E * 64u)) * AS - zb2 + 2u * a_lds;  // my wave's first one
             static_for<0, E>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
                 uint64_t om;
@@ -712,8 +728,9 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
                 const uint32_t zpre = mbcnt64(~om);
                 const uint32_t d0 = zb2 + (zpre << ASH);
                 const uint32_t d1 = ob2 + ((lane - zpre) << ASH);
-                const uint32_t addr = ((om >> lane) & 1ull) ? d1 : d0;
-                *reinterpret_cast<AT*>(abytes + addr) = (AT)av[e];
+                // the ballot mask itself is the select condition (v_cndmask with an SGPR mask)
+                const uint32_t addr = __builtin_amdgcn_inverse_ballot_w64(om) ? d1 : d0;
+                *reinterpret_cast<LdsAT*>((uintptr_t)addr) = (AT)av[e];
                 const uint32_t no2 = (uint32_t)__popcll(om) * AS;
                 zb2 += 64u * AS - no2;
                 ob2 += no2;
@@ -1155,7 +1172,7 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
         }();
         static const double rho = [] {
             const char* e = getenv("XSI_CHAIN_RHO");
-            return e ? atof(e) : 0.47;  // measured best at the bench size (0.25 ... 0.6 swept)
+            return e ? atof(e) : 0.55;  // measured best at the bench size (0.25 ... 0.65 swept)
         }();
         uint32_t S = 256u / n_blocks;
         if (S > 4u) S = 4u;
