@@ -67,6 +67,12 @@ int xsi_hip_ctx_create(xsi_hip_ctx** out, int device, void* stream) {
         }
         c->owns_stream = true;
     }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        xsi_hip_ctx_destroy(c);
+        return set_error(XSI_ERR_HIP, "side stream / events could not be created");
+    }
     *out = c;
     return XSI_OK;
 }
@@ -75,6 +81,12 @@ void xsi_hip_ctx_destroy(xsi_hip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto& kv : c->bufs)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -602,15 +614,22 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
         if (b.off_line_haploid != VAL_UNDEFINED) any_haploid = true;
     if (any_haploid && !chain_geometry(L.N, true).in_lds)
         WS(scratch_a, "chain.a", 4ull * 2ull * (((size_t)L.N + 63u) & ~(size_t)63u) * P.n_blocks);
+    // Sparse lines never touch the PBWT order and write their own output rows: their pointer walk
+    // and fill run on the side stream, underneath the WAH boundary scan / expansion / chain (which
+    // leave most wave slots of every CU free), and are joined back before the call returns.
+    HIP_TRY(hipEventRecord(ctx->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    HIP_TRY(launch_sparse_walk(ctx->side, f, P.d_blocks, P.n_blocks, L));
+    HIP_TRY(launch_sparse_fill(ctx->side, f, P.d_blocks, L, P.n_sparse, P.d_totals, out, stride_w, apply_negation));
+    HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
     stage_mark(ctx, XSI_ST_DEC_BOUND);
     HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
     stage_mark(ctx, XSI_ST_DEC_EXPAND);
     HIP_TRY(launch_wah_expand(s, f, P.d_blocks, L, P.n_wah, P.d_totals));
     stage_mark(ctx, XSI_ST_CHAIN_DEC);
     HIP_TRY(launch_chain_decode(s, P.d_blocks, P.n_blocks, L, out, stride_w, scratch_a, any_haploid));
-    stage_mark(ctx, XSI_ST_DEC_SPARSE);
-    HIP_TRY(launch_sparse_walk(s, f, P.d_blocks, P.n_blocks, L));
-    HIP_TRY(launch_sparse_fill(s, f, P.d_blocks, L, P.n_sparse, P.d_totals, out, stride_w, apply_negation));
+    stage_mark(ctx, XSI_ST_DEC_SPARSE);  // what is left of the sparse work after the chain
+    HIP_TRY(hipStreamWaitEvent(s, ctx->ev_join, 0));
     stage_mark(ctx, -1);
     return XSI_OK;
 }

@@ -31,6 +31,10 @@ struct xsi_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    // side stream for work that is independent of the serial chain (sparse lines): forked from and
+    // joined back into `stream` with the two events, so callers still see one in-order stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     struct Buf {
         void* p = nullptr;
         size_t cap = 0;
