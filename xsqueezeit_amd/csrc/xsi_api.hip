@@ -98,6 +98,7 @@ void xsi_hip_ctx_destroy(xsi_hip_ctx* c) {
 int xsi_hip_ctx_synchronize(xsi_hip_ctx* c) {
     if (!c) return set_error(XSI_ERR_ARG, "null context");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->side) HIP_TRY(hipStreamSynchronize(c->side));  // normally already joined; covers error exits
     return XSI_OK;
 }
 
@@ -294,6 +295,24 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     HIP_TRY(launch_classify(s, d_blocks, n_blocks, L));
     HIP_TRY(launch_scan_blocks_wah(s, d_blocks, n_blocks, d_totals));
     HIP_TRY(launch_build_wah_list(s, d_blocks, n_blocks, L));
+    // Sparse lists depend on the classification only (their sizes are known from the counts), not on
+    // the chain: emit them into a scratch on the side stream underneath the chain, one fixed-size
+    // region per block, and move them into place once the block layout exists.
+    uint8_t* sp_scratch = nullptr;
+    uint64_t sp_stride = 0;
+    {
+        uint32_t max_bin = 0;
+        for (auto& b : blocks_h) max_bin = b.n_bin > max_bin ? b.n_bin : max_bin;
+        const uint64_t per_line = (1ull + (p->mac_threshold < N / 2u ? p->mac_threshold : N / 2u)) * L.aet;
+        sp_stride = (max_bin * per_line + 255u) & ~255ull;
+        if (sp_stride * n_blocks <= (1ull << 30)) WS(sp_scratch, "enc.sparse_scratch", sp_stride * n_blocks);
+    }
+    if (sp_scratch) {
+        HIP_TRY(hipEventRecord(ctx->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        HIP_TRY(launch_sparse_write(ctx->side, d_blocks, L, nullptr, nullptr, sp_scratch, sp_stride));
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
+    }
     stage_mark(ctx, XSI_ST_CHAIN_ENC);
     HIP_TRY(launch_chain_encode(s, d_blocks, n_blocks, L, scratch_a, L.bin_nbits != nullptr));
     stage_mark(ctx, XSI_ST_WAH_SIZE);
@@ -305,7 +324,12 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     stage_mark(ctx, XSI_ST_WRITE);
     HIP_TRY(launch_write_headers(s, d_blocks, n_blocks, L, p->default_phased, strategy, (uint8_t*)d_out, d_result));
     HIP_TRY(launch_wah_write(s, d_blocks, L, n_bin, (uint8_t*)d_out, d_result));
-    HIP_TRY(launch_sparse_write(s, d_blocks, L, (uint8_t*)d_out, d_result));
+    if (sp_scratch) {
+        HIP_TRY(hipStreamWaitEvent(s, ctx->ev_join, 0));
+        HIP_TRY(launch_sparse_copy(s, d_blocks, n_blocks, (uint8_t*)d_out, d_result, sp_scratch, sp_stride));
+    } else {
+        HIP_TRY(launch_sparse_write(s, d_blocks, L, (uint8_t*)d_out, d_result, nullptr, 0));
+    }
     if (S.bcf_flags) {
         int rc = encode_side_write(ctx, d_blocks, n_blocks, L, S, (uint8_t*)d_out, d_result);
         if (rc) return rc;

@@ -1375,14 +1375,17 @@ __device__ __forceinline__ uint32_t wave_sparse_emit(const uint32_t* __restrict_
     return base;
 }
 
+// scratch != nullptr: the lists go to scratch + block * scratch_stride + sparse_off (run before the
+// block layout exists, underneath the chain); k_sparse_copy then moves each block's region into place.
 __global__ void __launch_bounds__(256) k_sparse_write(const EncBlock* __restrict__ blocks, EncLines L,
-                                                      uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result) {
-    if (d_result[3]) return;
+                                                      uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result,
+                                                      uint8_t* __restrict__ scratch, uint64_t scratch_stride) {
+    if (!scratch && d_result[3]) return;
     const uint32_t l = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (l >= L.n_bin) return;
     const uint32_t k = L.kind[l];
     if (k & KIND_WAH) return;
-    const EncBlock& B = blocks[L.line_block[l]];
+    const uint32_t blk = L.line_block[l];
     const uint32_t nbits = nbits_of(L, l);
     const bool neg = (k & KIND_NEGATED) != 0u;
     const uint32_t* row;
@@ -1393,14 +1396,34 @@ __global__ void __launch_bounds__(256) k_sparse_write(const EncBlock* __restrict
         row = L.planes + (size_t)l * L.plane_stride_w;
         invert = neg;  // fully called bi-allelic line: REF positions = complement of ALT positions
     }
-    uint8_t* dst = out + B.out_off + 16u + B.off_sparse + L.sparse_off[l];
+    uint8_t* dst = scratch ? scratch + (size_t)blk * scratch_stride + L.sparse_off[l]
+                           : out + blocks[blk].out_off + 16u + blocks[blk].off_sparse + L.sparse_off[l];
     (void)wave_sparse_emit(row, nbits, invert, neg ? 1u : 0u, L.aet, dst);
 }
 
 hipError_t launch_sparse_write(hipStream_t s, const EncBlock* blocks, const EncLines& L, uint8_t* out,
-                               const uint64_t* d_result) {
+                               const uint64_t* d_result, uint8_t* scratch, uint64_t scratch_stride) {
     if (!L.n_bin) return hipSuccess;
-    k_sparse_write<<<dim3((L.n_bin + 3u) / 4u), dim3(256), 0, s>>>(blocks, L, out, d_result);
+    k_sparse_write<<<dim3((L.n_bin + 3u) / 4u), dim3(256), 0, s>>>(blocks, L, out, d_result, scratch, scratch_stride);
+    return hipGetLastError();
+}
+
+// each block's sparse matrix from the scratch into its place in the output (2-byte granular)
+__global__ void __launch_bounds__(256) k_sparse_copy(const EncBlock* __restrict__ blocks, uint8_t* __restrict__ out,
+                                                     const uint64_t* __restrict__ d_result,
+                                                     const uint8_t* __restrict__ scratch, uint64_t scratch_stride) {
+    if (d_result[3]) return;
+    const EncBlock& B = blocks[blockIdx.x];
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(scratch + (size_t)blockIdx.x * scratch_stride);
+    uint16_t* dst = reinterpret_cast<uint16_t*>(out + B.out_off + 16u + B.off_sparse);
+    const uint32_t n = B.sparse_bytes / 2u;
+    for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.y) dst[i] = src[i];
+}
+
+hipError_t launch_sparse_copy(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, uint8_t* out,
+                              const uint64_t* d_result, const uint8_t* scratch, uint64_t scratch_stride) {
+    if (!n_blocks) return hipSuccess;
+    k_sparse_copy<<<dim3(n_blocks, 8), dim3(256), 0, s>>>(blocks, out, d_result, scratch, scratch_stride);
     return hipGetLastError();
 }
 

@@ -78,7 +78,9 @@ hipError_t launch_write_headers(hipStream_t s, const EncBlock* blocks, uint32_t 
 hipError_t launch_wah_write(hipStream_t s, const EncBlock* blocks, const EncLines& L, uint32_t max_wah,
                             uint8_t* out, const uint64_t* d_result);
 hipError_t launch_sparse_write(hipStream_t s, const EncBlock* blocks, const EncLines& L, uint8_t* out,
-                               const uint64_t* d_result);
+                               const uint64_t* d_result, uint8_t* scratch /*nullable*/, uint64_t scratch_stride);
+hipError_t launch_sparse_copy(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, uint8_t* out,
+                              const uint64_t* d_result, const uint8_t* scratch, uint64_t scratch_stride);
 
 // ---- decode ----
 struct DecLines {
