@@ -766,7 +766,7 @@ int xsi_hip_decode_gt(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, u
     if (P.n_bcf != n_lines)
         return set_error(XSI_ERR_ARG, "decode_gt: blocks hold %u BCF lines, caller passed %llu", P.n_bcf, (unsigned long long)n_lines);
     if (gt_stride < P.L.N) return set_error(XSI_ERR_ARG, "gt_stride %llu < %u haplotypes", (unsigned long long)gt_stride, P.L.N);
-    const uint32_t n_bcf = P.n_bcf, n_bin = P.n_bin;
+    const uint32_t n_bcf = P.n_bcf;
     // BCF line -> first binary line; must agree with every block's dictionary
     std::vector<uint32_t> first_bin(n_bcf);
     {
@@ -783,7 +783,6 @@ int xsi_hip_decode_gt(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, u
                                  acc - P.blocks_h[b].first_bin, P.blocks_h[b].n_bin);
         }
     }
-    const uint32_t stride_w = P.L.y_stride64 * 2u;
     uint32_t *d_first_bin, *d_nallele, *d_line_ngt;
     WS(d_first_bin, "gt.bcf_first_bin", 4ull * n_bcf);
     WS(d_nallele, "gt.bcf_nallele", 4ull * n_bcf);

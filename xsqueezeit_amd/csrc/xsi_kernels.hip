@@ -196,7 +196,6 @@ hipError_t launch_build_wah_list(hipStream_t s, const EncBlock* blocks, uint32_t
 // Fully haploid lines (general path) use the slow sub-path chain_step_haploid.
 // ------------------------------------------------------------------------------------------
 struct ChainArgs {
-    const uint32_t* wah_first;   // unused (kept for symmetry)
     const uint32_t* wah_lines;   // [rank] binary line
     const uint8_t* kind;         // per binary line
     const uint32_t* src;         // encode: planes (by binary line); decode: yrows as uint32 (by rank)
