@@ -263,3 +263,44 @@ def test_argument_errors():
     # row capacity too small
     assert L.xsi_hip_decode_packed(h, d_file.data_ptr(), len(ref), 0, 2, d_out.data_ptr(), stride, 3,
                                    ctypes.byref(rows), None) == binding.XSI_ERR_CAPACITY
+
+
+@pytest.mark.gpu
+def test_corrupt_images_are_rejected_not_dereferenced():
+    """A damaged index or dictionary must come back as XSI_ERR_FORMAT: the parser checks every offset
+    against the image before anything is read through it."""
+    import gpu_util as G
+    n_haps, n_lines = 512, 300
+    bits, packed, stride = _mk(n_haps, n_lines, 77)
+    p = G.params(n_haps // 2, 100, 1)
+    good = bytearray(G.oracle_file_from_bits(bits, p))
+    io = struct.unpack_from("<Q", good, 72)[0]
+    blk0 = struct.unpack_from("<Q", good, io)[0]
+    n_outer = struct.unpack_from("<I", good, blk0 + 4)[0]
+    gt_rel_at = None
+    for i in range(n_outer):
+        if struct.unpack_from("<I", good, blk0 + 8 + 8 * i)[0] == 256:
+            gt_rel_at = blk0 + 12 + 8 * i
+    gt0 = blk0 + struct.unpack_from("<I", good, gt_rel_at)[0]
+    n_keys = struct.unpack_from("<I", good, gt0 + 4)[0]
+    key_at = {struct.unpack_from("<I", good, gt0 + 8 + 8 * i)[0]: gt0 + 12 + 8 * i for i in range(n_keys)}
+
+    def decode(img):
+        return G.decode_packed(bytes(img), n_haps, stride)
+
+    out, _ = decode(good)
+    assert np.array_equal(out, packed)
+    cases = {
+        "index entry beyond the image": (io, struct.pack("<Q", len(good) + 4096)),
+        "misaligned index entry": (io, struct.pack("<Q", blk0 + 2)),
+        "GT block offset beyond the image": (gt_rel_at, struct.pack("<I", 0x7FFFFFF0)),
+        "sparse matrix offset beyond the image": (key_at[0x21], struct.pack("<I", 0x7FFFFF00)),
+        "WAH matrix offset after the sparse matrix": (key_at[0x20], struct.pack("<I", struct.unpack_from("<I", good, key_at[0x21])[0] + 64)),
+        "more binary lines than a block can hold": (key_at[0x1], struct.pack("<I", 40000)),
+    }
+    for name, (at, val) in cases.items():
+        bad = bytearray(good)
+        bad[at:at + len(val)] = val
+        with pytest.raises(binding.XsiError) as ei:
+            decode(bad)
+        assert ei.value.code == -4, "%s: %s" % (name, ei.value)  # XSI_ERR_FORMAT

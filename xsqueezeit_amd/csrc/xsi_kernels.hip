@@ -1675,27 +1675,41 @@ __global__ void __launch_bounds__(256) k_parse_blocks(const uint8_t* __restrict_
     }
     D.file_off = off;
     D.error = 0;
+    // every read below stays inside the image: a corrupt index or dictionary becomes an error
+    // code (XSI_ERR_FORMAT on the host), never an out-of-bounds access
     if (off + 16u > file_len || (off & 3u)) {
         D.error = 1;
         blocks[b] = D;
         return;
     }
     const uint8_t* blk = file + off;
-    const uint32_t n_outer = rd32(blk + 4);
+    uint32_t n_outer = rd32(blk + 4);
+    if (n_outer > 64u) n_outer = 64u;
+    if (off + 8u + 8ull * n_outer > file_len) {
+        D.error = 1;
+        blocks[b] = D;
+        return;
+    }
     uint32_t gt_rel = VAL_UNDEFINED;
-    for (uint32_t i = 0; i < n_outer && i < 64u; ++i)
+    for (uint32_t i = 0; i < n_outer; ++i)
         if (rd32(blk + 8 + 8 * i) == KEY_GT_ENTRY) gt_rel = rd32(blk + 12 + 8 * i);
-    if (gt_rel == VAL_UNDEFINED) {
+    if (gt_rel == VAL_UNDEFINED || (gt_rel & 3u) || off + gt_rel + 8u > file_len) {
         D.error = 2;
         blocks[b] = D;
         return;
     }
     D.gt_off = off + gt_rel;
     const uint8_t* gt = file + D.gt_off;
-    const uint32_t n = rd32(gt + 4);
+    uint32_t n = rd32(gt + 4);
+    if (n > 64u) n = 64u;
+    if (D.gt_off + 8u + 8ull * n > file_len) {
+        D.error = 2;
+        blocks[b] = D;
+        return;
+    }
     uint32_t vals[0x40];
     for (int i = 0; i < 0x40; ++i) vals[i] = VAL_UNDEFINED;
-    for (uint32_t i = 0; i < n && i < 64u; ++i) {
+    for (uint32_t i = 0; i < n; ++i) {
         const uint32_t k = rd32(gt + 8 + 8 * i), v = rd32(gt + 12 + 8 * i);
         if (k < 0x40u) vals[k] = v;
     }
@@ -1720,6 +1734,12 @@ __global__ void __launch_bounds__(256) k_parse_blocks(const uint8_t* __restrict_
         D.off_select == VAL_UNDEFINED || D.off_wah == VAL_UNDEFINED || D.off_sparse == VAL_UNDEFINED ||
         D.off_sparse < D.off_wah)
         D.error = 3;
+    // every section must start inside the image (the WAH matrix must also end inside it)
+    const uint32_t sections[] = {D.off_select,       D.off_wah,      D.off_sparse,      D.off_line_missing, D.off_miss_wah,
+                                 D.off_miss_sparse,  D.off_line_eov, D.off_eov_wah,     D.off_eov_sparse,   D.off_line_phase,
+                                 D.off_phase,        D.off_line_haploid};
+    for (uint32_t x : sections)
+        if (x != VAL_UNDEFINED && D.gt_off + (uint64_t)x > file_len) D.error = 3;
     D.wah_words = D.error ? 0u : (D.off_sparse - D.off_wah) / 2u;
     blocks[b] = D;
 }
