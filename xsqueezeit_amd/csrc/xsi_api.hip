@@ -278,7 +278,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     L.y_stride64 = (N + 63u) / 64u;
     WS(L.yrows, "enc.yrows", 8ull * L.y_stride64 * (size_t)n_bin);
     // WAH16 words per line, worst case ceil(N/15) (+1 for the saturation split): encode once, then copy
-    L.wah_scratch_stride = (N + 14u) / 15u + 2u;
+    L.wah_scratch_stride = ((N + 14u) / 15u + 3u) & ~1u;  // even: rows stay 4-byte aligned for k_wah_write
     WS(L.wah_scratch, "enc.wah_scratch", 2ull * L.wah_scratch_stride * (size_t)n_bin);
     WS(L.flagbits, "enc.flagbits", 4ull * (MAX_BIN_PER_BLOCK / 32) * FV_COUNT * (size_t)n_blocks);
     WS(L.flagwah, "enc.flagwah", 2ull * FLAG_WORDS_MAX * FV_COUNT * (size_t)n_blocks);

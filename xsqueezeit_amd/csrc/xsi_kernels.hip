@@ -1306,27 +1306,58 @@ hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_
 __global__ void __launch_bounds__(256) k_wah_write(const EncBlock* __restrict__ blocks, EncLines L, uint32_t max_wah,
                                                    uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result) {
     if (d_result[3]) return;  // capacity error: nothing may be written
-    const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (j >= max_wah || j >= (uint32_t)d_result[2]) return;
-    const uint32_t l = L.wah_lines[j];
-    const EncBlock& B = blocks[L.line_block[l]];
-    const uint32_t nbits = nbits_of(L, l);
-    const uint32_t* row = reinterpret_cast<const uint32_t*>(L.yrows + (size_t)j * L.y_stride64);
-    uint16_t* dst = reinterpret_cast<uint16_t*>(out + B.out_off + 16u + B.off_wah) + L.wah_off[j];
-    if (L.wah_scratch) {
-        // the sizing pass already produced the words: move them to their final place
-        const uint16_t* src = L.wah_scratch + (size_t)j * L.wah_scratch_stride;
-        const uint32_t n = L.wah_len[j];
-        for (uint32_t i = lane_id(); i < n; i += 64u) dst[i] = src[i];
-    } else {
-        (void)wave_wah_encode_row<true>(row, nbits, dst);
+    const uint32_t lane = lane_id();
+    const uint32_t j0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * WAH_LINES_PER_WAVE;
+    const uint32_t total = max_wah < (uint32_t)d_result[2] ? max_wah : (uint32_t)d_result[2];
+    if (j0 >= total) return;
+    // lane k fetches the metadata of line j0 + k (dependent loads, paid once per wave)
+    uint64_t m_dst = 0;
+    uint32_t m_n = 0, m_nbits = 0;
+    if (lane < WAH_LINES_PER_WAVE && j0 + lane < total) {
+        const uint32_t l = L.wah_lines[j0 + lane];
+        const EncBlock& B = blocks[L.line_block[l]];
+        m_dst = reinterpret_cast<uint64_t>(out + B.out_off + 16u + B.off_wah) + 2ull * L.wah_off[j0 + lane];
+        m_n = L.wah_len[j0 + lane];
+        m_nbits = nbits_of(L, l);
+    }
+    for (uint32_t k = 0; k < WAH_LINES_PER_WAVE && j0 + k < total; ++k) {
+        const uint32_t j = j0 + k;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m_dst, (int)k);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m_dst >> 32), (int)k);
+        uint16_t* dst = reinterpret_cast<uint16_t*>(((uint64_t)hi << 32) | lo);
+        if (!L.wah_scratch) {
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(L.yrows + (size_t)j * L.y_stride64);
+            (void)wave_wah_encode_row<true>(row, (uint32_t)__builtin_amdgcn_readlane((int)m_nbits, (int)k), dst);
+            continue;
+        }
+        // the sizing pass already produced the words: move them to their final place, 4 bytes per
+        // store (the destination is only 2-byte aligned: an odd start takes one word by itself, the
+        // source words are then re-paired)
+        const uint16_t* src = L.wah_scratch + (size_t)j * L.wah_scratch_stride;  // 4-byte aligned rows
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)m_n, (int)k);
+        const uint32_t head = (uint32_t)((reinterpret_cast<uint64_t>(dst) >> 1) & 1ull);
+        if (head && n && lane == 0) dst[0] = src[0];
+        if (n <= head) continue;
+        const uint32_t m = n - head;  // words from src + head to the 4-byte aligned dst + head
+        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+        for (uint32_t i = lane; i < m / 2u; i += 64u) {
+            uint32_t v;
+            if (head)
+                v = (s32[i] >> 16) | (s32[i + 1u] << 16);
+            else
+                v = s32[i];
+            d32[i] = v;
+        }
+        if ((m & 1u) && lane == 0) dst[n - 1u] = src[n - 1u];
     }
 }
 
 hipError_t launch_wah_write(hipStream_t s, const EncBlock* blocks, const EncLines& L, uint32_t max_wah,
                             uint8_t* out, const uint64_t* d_result) {
     if (!max_wah) return hipSuccess;
-    k_wah_write<<<dim3((max_wah + 3u) / 4u), dim3(256), 0, s>>>(blocks, L, max_wah, out, d_result);
+    const uint32_t per_wg = 4u * WAH_LINES_PER_WAVE;
+    k_wah_write<<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), 0, s>>>(blocks, L, max_wah, out, d_result);
     return hipGetLastError();
 }
 
