@@ -62,9 +62,59 @@ __global__ void __launch_bounds__(256) k_count_rows(const uint32_t* __restrict__
     if (lane == 0) cnt[row] = c;
 }
 
+// Same for rows whose stride is a multiple of 16 bytes (the packed input: rows padded to 128 B): a
+// wave streams 8 consecutive rows as one run of 16-byte loads, all issued before the first popcount,
+// and adds into per-row LDS counters.  4 waves x 8 rows per workgroup.
+__global__ void __launch_bounds__(256) k_count_rows_v4(const uint4* __restrict__ planes, uint32_t stride_q,
+                                                       uint32_t nbits, uint32_t n_rows, uint32_t* __restrict__ cnt) {
+    constexpr uint32_t RPW = 8, MAXQ = 8;  // rows per wave; 16-byte loads per lane (RPW*stride_q <= 64*MAXQ)
+    __shared__ uint32_t s_cnt[4 * RPW];
+    const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
+    const uint32_t row0 = (blockIdx.x * 4u + w) * RPW;
+    if (threadIdx.x < 4u * RPW) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t rows = row0 < n_rows ? (n_rows - row0 < RPW ? n_rows - row0 : RPW) : 0u;
+    const uint32_t total_q = rows * stride_q;
+    const uint4* base = planes + (size_t)row0 * stride_q;
+    const uint32_t nw = (nbits + 31u) >> 5;
+    uint4 v[MAXQ];
+#pragma unroll
+    for (uint32_t i = 0; i < MAXQ; ++i) {
+        const uint32_t q = i * 64u + lane;
+        v[i] = q < total_q ? base[q] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < MAXQ; ++i) {
+        const uint32_t q = i * 64u + lane;
+        if (q < total_q) {
+            const uint32_t r = q / stride_q, w0 = (q - r * stride_q) * 4u;  // row in my group, first word of the quad
+            const uint32_t x[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            uint32_t c = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t wi = w0 + j;
+                uint32_t t = wi < nw ? x[j] : 0u;
+                if (wi == nw - 1u && (nbits & 31u)) t &= (1u << (nbits & 31u)) - 1u;
+                c += (uint32_t)__popc(t);
+            }
+            if (c) atomicAdd(&s_cnt[w * RPW + r], c);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4u * RPW) {
+        const uint32_t row = blockIdx.x * 4u * RPW + threadIdx.x;
+        if (row < n_rows) cnt[row] = s_cnt[threadIdx.x];
+    }
+}
+
 hipError_t launch_count_rows(hipStream_t s, const uint32_t* planes, uint32_t stride_w, uint32_t nbits,
                              uint32_t n_rows, uint32_t* cnt) {
     if (!n_rows) return hipSuccess;
+    if ((stride_w & 3u) == 0 && (reinterpret_cast<uintptr_t>(planes) & 15u) == 0 && stride_w / 4u * 8u <= 64u * 8u) {
+        k_count_rows_v4<<<dim3((n_rows + 31u) / 32u), dim3(256), 0, s>>>(reinterpret_cast<const uint4*>(planes),
+                                                                          stride_w / 4u, nbits, n_rows, cnt);
+        return hipGetLastError();
+    }
     k_count_rows<<<dim3((n_rows + 3u) / 4u), dim3(256), 0, s>>>(planes, stride_w, nbits, n_rows, cnt);
     return hipGetLastError();
 }
