@@ -610,6 +610,16 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
     L.yp_stride = L.y_stride64 * 2u;
     WS(L.yp, "dec.yp", 8ull * L.yp_stride * (size_t)(P->n_wah ? P->n_wah : 1));
     WS(L.wah_z, "dec.wah_z", 4ull * (P->n_wah ? P->n_wah : 1) + 64);
+    {
+        // tiles of the boundary scan (2048 WAH words each)
+        uint32_t max_words = 0;
+        for (auto& b : P->blocks_h)
+            if (!b.error && b.wah_words > max_words) max_words = b.wah_words;
+        L.max_tiles = (max_words + 2047u) / 2048u;
+        const size_t cells = (size_t)(L.max_tiles ? L.max_tiles : 1) * n_blocks;
+        WS(L.tile_sum, "dec.tile_sum", 4ull * cells);
+        WS(L.tile_base, "dec.tile_base", 8ull * cells);
+    }
     return XSI_OK;
 }
 

@@ -1976,21 +1976,54 @@ hipError_t launch_dec_line_lists(hipStream_t s, const DecBlock* blocks, uint32_t
 // WAH line boundaries.  Lines carry no length: a line ends when its
 // ceil(n/15) groups are covered, and this writer never lets a fill run cross a line.  So the
 // running group count over the whole matrix hits every line's cumulative group offset exactly
-// at that line's first word.  One workgroup per block: chunked scan of groups-per-word.
-__global__ void __launch_bounds__(1024) k_wah_boundaries(const uint8_t* __restrict__ file,
-                                                         const DecBlock* __restrict__ blocks, DecLines L) {
+// at that line's first word.  Three small kernels so that every block's matrix is scanned by many
+// workgroups: (1) groups per tile of 2048 words, (2) per block exclusive scan of the tile sums
+// (+ the cumulative line offsets of mixed-ploidy blocks), (3) per tile: scan inside the tile and
+// report the words at which a line starts.
+constexpr uint32_t BND_T = 256, BND_K = 8, BND_TILE = BND_T * BND_K;
+
+__device__ __forceinline__ uint32_t wah_groups_of(uint32_t word) { return (word & 0x8000u) ? (word & WAH_MAXC) : 1u; }
+
+__global__ void __launch_bounds__(BND_T) k_wah_tile_sums(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
+                                                          DecLines L) {
+    __shared__ uint32_t s_part[BND_T / 64];
+    const DecBlock& D = blocks[blockIdx.y];
+    const uint32_t c0 = blockIdx.x * BND_TILE;
+    if (D.error || D.n_wah == 0 || c0 >= D.wah_words) return;
+    const uint16_t* wm = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah);
+    const uint32_t w0 = c0 + threadIdx.x * BND_K;
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < BND_K; ++k)
+        if (w0 + k < D.wah_words) sum += wah_groups_of(wm[w0 + k]);
+    sum = wave_sum(sum);
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t i = 0; i < BND_T / 64; ++i) t += s_part[i];
+        L.tile_sum[(size_t)blockIdx.y * L.max_tiles + blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_wah_tile_scan(const DecBlock* __restrict__ blocks, DecLines L) {
     __shared__ uint64_t s_scan[20];
     const DecBlock& D = blocks[blockIdx.x];
     if (D.error || D.n_wah == 0) return;
-    const uint16_t* wm = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah);
-    const uint32_t nwords = D.wah_words;
-    constexpr uint32_t K = 8;  // consecutive words per thread
-    // cumulative group offsets of the lines: uniform G unless the block has haploid lines
-    const uint32_t Gd = (L.N + WAH_BITS - 1u) / WAH_BITS;
-    const uint32_t Gh = (L.n_samples + WAH_BITS - 1u) / WAH_BITS;
-    const bool mixed = D.off_line_haploid != VAL_UNDEFINED;
-    if (mixed) {
+    const uint32_t ntiles = (D.wah_words + BND_TILE - 1u) / BND_TILE;
+    uint64_t base = 0;
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += blockDim.x) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint64_t v = t < ntiles ? L.tile_sum[(size_t)blockIdx.x * L.max_tiles + t] : 0u;
+        uint64_t tot;
+        const uint64_t ex = block_scan_excl64(v, s_scan, &tot);
+        if (t < ntiles) L.tile_base[(size_t)blockIdx.x * L.max_tiles + t] = base + ex;
+        base += tot;
+    }
+    if (D.off_line_haploid != VAL_UNDEFINED) {
         // cumulative groups before each WAH line (haploid lines have n_samples bits)
+        const uint32_t Gd = (L.N + WAH_BITS - 1u) / WAH_BITS;
+        const uint32_t Gh = (L.n_samples + WAH_BITS - 1u) / WAH_BITS;
         uint32_t cb = 0;
         for (uint32_t j0 = 0; j0 < D.n_wah; j0 += blockDim.x) {
             const uint32_t j = j0 + threadIdx.x;
@@ -2001,79 +2034,78 @@ __global__ void __launch_bounds__(1024) k_wah_boundaries(const uint8_t* __restri
             if (j < D.n_wah) L.wah_cumg[D.wah_first + j] = cb + (uint32_t)ex;
             cb += (uint32_t)tot;
         }
-        __threadfence_block();
-        __syncthreads();
     }
-    uint64_t gbase = 0;
-    // words of the next tile are fetched before the current tile is scanned
-    uint32_t nxt[K];
-    auto fetch = [&](uint32_t c0) {
-        const uint32_t w0 = c0 + threadIdx.x * K;
+}
+
+__global__ void __launch_bounds__(BND_T) k_wah_boundaries(const uint8_t* __restrict__ file,
+                                                          const DecBlock* __restrict__ blocks, DecLines L) {
+    __shared__ uint64_t s_scan[20];
+    const DecBlock& D = blocks[blockIdx.y];
+    const uint32_t c0 = blockIdx.x * BND_TILE;
+    if (D.error || D.n_wah == 0 || c0 >= D.wah_words) return;
+    const uint16_t* wm = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah);
+    const uint32_t nwords = D.wah_words;
+    constexpr uint32_t K = BND_K;
+    const uint32_t Gd = (L.N + WAH_BITS - 1u) / WAH_BITS;
+    const bool mixed = D.off_line_haploid != VAL_UNDEFINED;
+    const uint32_t w0 = c0 + threadIdx.x * K;
+    uint32_t g[K];
+    uint32_t sum = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < K; ++k) nxt[k] = (w0 + k < nwords) ? (uint32_t)wm[w0 + k] : 0u;
-    };
-    fetch(0);
-    for (uint32_t c0 = 0; c0 < nwords; c0 += blockDim.x * K) {
-        const uint32_t w0 = c0 + threadIdx.x * K;
-        uint32_t g[K];
-        uint32_t sum = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < K; ++k) {
-            const uint32_t word = nxt[k];
-            const uint32_t ng = (w0 + k < nwords) ? ((word & 0x8000u) ? (word & WAH_MAXC) : 1u) : 0u;
-            g[k] = ng;
-            sum += ng;
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint32_t ng = (w0 + k < nwords) ? wah_groups_of(wm[w0 + k]) : 0u;
+        g[k] = ng;
+        sum += ng;
+    }
+    uint64_t tot;
+    uint64_t ex = L.tile_base[(size_t)blockIdx.y * L.max_tiles + blockIdx.x] + block_scan_excl64(sum, s_scan, &tot);
+    // uniform lines: line index and offset inside the line by ONE division per thread, then
+    // carried along word by word (a word never spans two lines, so the offset wraps exactly)
+    uint64_t jline = 0;
+    uint32_t rem = 0;
+    if (!mixed && sum) {
+        if ((ex >> 32) == 0) {
+            jline = (uint32_t)ex / Gd;
+            rem = (uint32_t)ex - (uint32_t)jline * Gd;
+        } else {
+            jline = ex / Gd;
+            rem = (uint32_t)(ex - jline * Gd);
         }
-        if (c0 + blockDim.x * K < nwords) fetch(c0 + blockDim.x * K);
-        uint64_t tot;
-        uint64_t ex = gbase + block_scan_excl64(sum, s_scan, &tot);
-        // uniform lines: line index and offset inside the line by ONE division per thread, then
-        // carried along word by word (a word never spans two lines, so the offset wraps exactly)
-        uint64_t jline = 0;
-        uint32_t rem = 0;
-        if (!mixed && sum) {
-            if ((ex >> 32) == 0) {
-                jline = (uint32_t)ex / Gd;
-                rem = (uint32_t)ex - (uint32_t)jline * Gd;
-            } else {
-                jline = ex / Gd;
-                rem = (uint32_t)(ex - jline * Gd);
-            }
-        }
+    }
 #pragma unroll
-        for (uint32_t k = 0; k < K; ++k) {
-            const uint32_t wi = w0 + k;
-            if (wi < nwords && g[k]) {
-                if (!mixed) {
-                    if (rem == 0 && jline < D.n_wah) L.wah_start[D.wah_first + (uint32_t)jline] = wi;
-                    rem += g[k];
-                    while (rem >= Gd) {
-                        rem -= Gd;
-                        ++jline;
-                    }
-                } else {
-                    // first line whose cumulative offset is >= ex
-                    uint32_t lo = 0, hi = D.n_wah;
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if ((uint64_t)L.wah_cumg[D.wah_first + mid] < ex)
-                            lo = mid + 1u;
-                        else
-                            hi = mid;
-                    }
-                    if (lo < D.n_wah && (uint64_t)L.wah_cumg[D.wah_first + lo] == ex) L.wah_start[D.wah_first + lo] = wi;
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint32_t wi = w0 + k;
+        if (wi < nwords && g[k]) {
+            if (!mixed) {
+                if (rem == 0 && jline < D.n_wah) L.wah_start[D.wah_first + (uint32_t)jline] = wi;
+                rem += g[k];
+                while (rem >= Gd) {
+                    rem -= Gd;
+                    ++jline;
                 }
+            } else {
+                // first line whose cumulative offset is >= ex
+                uint32_t lo = 0, hi = D.n_wah;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((uint64_t)L.wah_cumg[D.wah_first + mid] < ex)
+                        lo = mid + 1u;
+                    else
+                        hi = mid;
+                }
+                if (lo < D.n_wah && (uint64_t)L.wah_cumg[D.wah_first + lo] == ex) L.wah_start[D.wah_first + lo] = wi;
             }
-            ex += g[k];
         }
-        gbase += tot;
+        ex += g[k];
     }
 }
 
 hipError_t launch_wah_boundaries(hipStream_t s, const uint8_t* file, const DecBlock* blocks, uint32_t n_blocks,
                                  const DecLines& L) {
-    if (!n_blocks) return hipSuccess;
-    k_wah_boundaries<<<dim3(n_blocks), dim3(1024), 0, s>>>(file, blocks, L);
+    if (!n_blocks || !L.max_tiles) return hipSuccess;
+    k_wah_tile_sums<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L);
+    k_wah_tile_scan<<<dim3(n_blocks), dim3(1024), 0, s>>>(blocks, L);
+    k_wah_boundaries<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L);
     return hipGetLastError();
 }
 

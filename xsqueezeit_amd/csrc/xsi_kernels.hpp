@@ -101,6 +101,9 @@ struct DecLines {
     uint32_t y_stride64;   // ceil(N/64): 64-bit words of a plain bit row
     uint32_t* ones;        // per binary line: allele count (accessor "ones")
     uint32_t* wah_cumg;    // [wah rank] cumulative 15-bit groups before the line (mixed-ploidy blocks)
+    uint32_t* tile_sum;    // [block][max_tiles] 15-bit groups per 2048-word tile of the WAH matrix
+    uint64_t* tile_base;   // [block][max_tiles] groups before the tile
+    uint32_t max_tiles;
     uint64_t file_len;     // bytes of the file image (bounds every read)
 };
 
