@@ -106,16 +106,16 @@ __device__ __forceinline__ uint64_t block_scan_excl64(uint64_t v, uint64_t* lds,
 // 15-bit group g of a packed bit row (LSB-first in little-endian 32-bit words); bits at or
 // beyond nbits read as zero (the reference pads the last group with zeros, wah.hpp:547-565).
 __device__ __forceinline__ uint32_t load_group15(const uint32_t* __restrict__ row, uint32_t g, uint32_t nbits) {
+    // branch-free: word indices are clamped into the row, bits at or beyond nbits are masked off
+    // (g may lie beyond the last group: the result is then 0)
+    const uint32_t last = ((nbits + 31u) >> 5) - 1u;  // nbits >= 1
     const uint32_t o = g * WAH_BITS;
-    if (o >= nbits) return 0;
-    const uint32_t nwords = (nbits + 31u) >> 5;
-    const uint32_t wi = o >> 5, sh = o & 31u;
-    uint64_t lo = row[wi];
-    uint64_t hi = (wi + 1 < nwords) ? row[wi + 1] : 0u;
-    uint32_t v = (uint32_t)(((hi << 32) | lo) >> sh) & 0x7FFFu;
-    const uint32_t rem = nbits - o;
-    if (rem < WAH_BITS) v &= (1u << rem) - 1u;
-    return v;
+    const uint32_t wi = (o >> 5) < last ? (o >> 5) : last;
+    const uint32_t wi1 = wi < last ? wi + 1u : last;
+    const uint32_t v = __builtin_amdgcn_alignbit(row[wi1], row[wi], o & 31u);  // (hi:lo) >> (o & 31)
+    const uint32_t rem = o < nbits ? nbits - o : 0u;
+    const uint32_t keep = rem < WAH_BITS ? rem : WAH_BITS;
+    return v & ((1u << keep) - 1u);
 }
 
 // State carried between 64-group chunks of one WAH16 line.
@@ -206,11 +206,10 @@ __device__ __forceinline__ uint32_t wave_wah_encode_row(const uint32_t* __restri
     const uint32_t lane = lane_id();
     const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
     WahCarry c{3u, 0u, 0u};
-    uint32_t cur = lane < G ? load_group15(row, lane, nbits) : 0u;
-    uint32_t n1 = lane + 64u < G ? load_group15(row, lane + 64u, nbits) : 0u;
+    uint32_t cur = load_group15(row, lane, nbits);
+    uint32_t n1 = load_group15(row, lane + 64u, nbits);
     for (uint32_t g0 = 0; g0 < G; g0 += 64u) {
-        const uint32_t g2 = g0 + 128u + lane;
-        const uint32_t n2 = g2 < G ? load_group15(row, g2, nbits) : 0u;
+        const uint32_t n2 = load_group15(row, g0 + 128u + lane, nbits);
         const bool last = g0 + 64u >= G;
         const uint32_t next_val = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1);  // group g0+64 (0 past the end)
         wah_encode_chunk<WRITE>(cur, g0 + lane < G, last, next_val, c, dst);
