@@ -948,6 +948,9 @@ __global__ void __launch_bounds__(1024) k_chain_global(const EncBlock* __restric
 constexpr int STREAM_U = 8;
 constexpr int STREAM_ROW_REGS = 20;  // row words per thread: N <= 1024*20*32
 
+// AT: element type of `a` in HBM/L2: uint16_t while N <= 65536 (the array traffic, 2 x sizeof(AT) per
+// member per line, is what bounds this kernel once a few hundred blocks are in flight), else uint32_t.
+template <typename AT>
 __global__ void __launch_bounds__(1024) k_chain_stream(const EncBlock* __restrict__ eblocks, ChainArgs A,
                                                        uint32_t* __restrict__ scratch_a, uint32_t SS) {
     constexpr uint32_t T = 1024, W = 16, U = STREAM_U;
@@ -962,15 +965,15 @@ __global__ void __launch_bounds__(1024) k_chain_stream(const EncBlock* __restric
     const uint32_t n_wah = eblocks[blockIdx.x].n_wah;
     if (n_wah == 0) return;
     const size_t na = ((size_t)N + 63u) & ~(size_t)63u;
-    uint32_t* a0 = scratch_a + (size_t)blockIdx.x * 2u * na;
-    uint32_t* a1 = a0 + na;
+    AT* a0 = reinterpret_cast<AT*>(scratch_a + (size_t)blockIdx.x * 2u * na);  // region sized for uint32
+    AT* a1 = a0 + na;
     const uint32_t src_words = (N + 31u) >> 5;
     const uint32_t tail_mask = (N & 31u) ? ((1u << (N & 31u)) - 1u) : ~0u;
     auto load_word = [&](const uint32_t* srow, uint32_t i) -> uint32_t {
         const uint32_t v = srow[i < src_words ? i : 0u];
         return i >= src_words ? 0u : (i == src_words - 1u ? (v & tail_mask) : v);
     };
-    for (uint32_t i = tid; i < N; i += T) a0[i] = i;
+    for (uint32_t i = tid; i < N; i += T) a0[i] = (AT)i;
     {
         const uint32_t* r0 = A.src + (size_t)A.wah_lines[wah_first] * A.src_stride_w;
         for (uint32_t i = tid; i < cw; i += T) rows[i] = load_word(r0, i);
@@ -1021,8 +1024,8 @@ __global__ void __launch_bounds__(1024) k_chain_stream(const EncBlock* __restric
             zb = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
         }
         uint32_t ob = tz + (p_lo - zb);  // destination of my segment's first one
-        const uint32_t* ain = (j & 1u) ? a1 : a0;
-        uint32_t* aout = (j & 1u) ? a0 : a1;
+        const AT* ain = (j & 1u) ? a1 : a0;
+        AT* aout = (j & 1u) ? a0 : a1;
         uint2* yr = reinterpret_cast<uint2*>(A.dst + (size_t)rank * A.dst_stride_w);
         // look-ahead accumulators: zeros of line j+1 among the members I move, per destination segment
         uint32_t zseg = zb / SS, zacc = 0, zbound = (zseg + 1u) * SS;
@@ -1044,7 +1047,7 @@ __global__ void __launch_bounds__(1024) k_chain_stream(const EncBlock* __restric
             const uint64_t nz = __ballot(nbit == 0u);  // members whose bit on the next line is 0
             const uint32_t zpre = mbcnt64(zm);
             const uint32_t dest = bit ? ob + (lane - zpre) : zb + zpre;
-            if (FULL || valid) aout[dest] = vv;
+            if (FULL || valid) aout[dest] = (AT)vv;
             const uint32_t nzc = (uint32_t)__popcll(zm), noc = (uint32_t)__popcll(om);
             if (zb + nzc > zbound) {  // the zeros of this chunk cross into the next segment (rare)
                 const uint64_t hi = __ballot(valid && !bit && dest >= zbound);
@@ -1075,7 +1078,7 @@ __global__ void __launch_bounds__(1024) k_chain_stream(const EncBlock* __restric
         uint32_t vn[U];
         if (n_full) {
 #pragma unroll
-            for (uint32_t u = 0; u < U; ++u) vn[u] = ain[base + u * 64u + lane];
+            for (uint32_t u = 0; u < U; ++u) vn[u] = (uint32_t)ain[base + u * 64u + lane];
         }
         for (uint32_t g = 0; g < n_full; ++g, base += 64u * U) {
             uint32_t v[U];
@@ -1083,7 +1086,7 @@ __global__ void __launch_bounds__(1024) k_chain_stream(const EncBlock* __restric
             for (uint32_t u = 0; u < U; ++u) v[u] = vn[u];
             if (g + 1u < n_full) {
 #pragma unroll
-                for (uint32_t u = 0; u < U; ++u) vn[u] = ain[base + (U + u) * 64u + lane];
+                for (uint32_t u = 0; u < U; ++u) vn[u] = (uint32_t)ain[base + (U + u) * 64u + lane];
             }
             uint32_t mine_lo = 0, mine_hi = 0;
 #pragma unroll
@@ -1096,7 +1099,7 @@ __global__ void __launch_bounds__(1024) k_chain_stream(const EncBlock* __restric
         }
         for (; base < p_hi; base += 64u) {
             const uint32_t idx = base + lane;
-            const uint32_t vv = idx < p_hi ? ain[idx] : 0u;
+            const uint32_t vv = idx < p_hi ? (uint32_t)ain[idx] : 0u;
             const uint64_t om = step(std::false_type{}, base, vv);
             if (lane == 0) yr[base >> 6] = make_uint2((uint32_t)om, (uint32_t)(om >> 32));
         }
@@ -1194,10 +1197,18 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
             // streaming kernel for the blocks without fully haploid lines, the two-pass kernel for the rest
             const uint32_t seg = (((A.N + 15u) / 16u) + 63u) & ~63u;  // positions per wave
             const uint32_t lds = (2u * A.cw + 3u * 16u) * 4u;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_stream),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            k_chain_stream<<<dim3(n_blocks), dim3(1024), lds, s>>>(eb, A, scratch_a, seg);
+            hipError_t e;
+            if (A.N <= 65536u) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_stream<uint16_t>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                k_chain_stream<uint16_t><<<dim3(n_blocks), dim3(1024), lds, s>>>(eb, A, scratch_a, seg);
+            } else {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_stream<uint32_t>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                k_chain_stream<uint32_t><<<dim3(n_blocks), dim3(1024), lds, s>>>(eb, A, scratch_a, seg);
+            }
             e = hipGetLastError();
             if (e != hipSuccess || !any_haploid) return e;
             A.only_haploid_blocks = 1;
