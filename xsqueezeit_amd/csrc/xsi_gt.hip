@@ -73,46 +73,91 @@ __global__ void __launch_bounds__(256) k_unpack_gt(UnpackArgs U) {
     const uint32_t n_allele = U.bcf_n_allele[l];
     const uint32_t b0 = U.bcf_first_bin[l];
     const bool diploid = ngt == 2u * U.n_samples;
-    const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
+    const uint32_t lane = lane_id();
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave index, uniform
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x < 64) s_alt[threadIdx.x] = 0;
     __syncthreads();
     const int32_t* row = U.gt + (size_t)l * U.gt_stride;
     const uint32_t nchunks = U.stride_w / 2u;  // 64-bit words per plane row (all written, pad = 0)
-    uint32_t c_ref = 0, c_miss = 0, c_eov = 0, any_phase = 0;
-    for (uint32_t cgi = w; cgi < nchunks; cgi += 4u) {
-        const uint32_t i = cgi * 64u + lane;
-        const bool in = i < ngt;
-        const int32_t v = in ? row[i] : 0;
-        const bool missing = in && (((v >> 1) == 0) || v == GT_INT32_MISSING);
-        const bool eov = in && !missing && v == GT_VECTOR_END;
-        const bool called = in && !missing && !eov;
-        const int32_t allele = (v >> 1) - 1;
-        if (called && (allele < 0 || allele >= (int32_t)n_allele)) *U.d_error = 1;  // "Unknown allele error !"
-        const bool ph = in && diploid && (i & 1u) && ((v & 1) != U.default_phased);
-        const uint64_t m_ref = __ballot(called && allele == 0);
-        const uint64_t m_miss = __ballot(missing);
-        const uint64_t m_eov = __ballot(eov);
-        const uint64_t m_ph = __ballot(ph);
-        if (lane == 0) {
-            reinterpret_cast<uint64_t*>(U.ref_planes + (size_t)l * U.stride_w)[cgi] = m_ref;
-            reinterpret_cast<uint64_t*>(U.miss_planes + (size_t)l * U.stride_w)[cgi] = m_miss;
-            reinterpret_cast<uint64_t*>(U.eov_planes + (size_t)l * U.stride_w)[cgi] = m_eov;
-            reinterpret_cast<uint64_t*>(U.phase_planes + (size_t)l * U.stride_w)[cgi] = m_ph;
-        }
-        c_ref += (uint32_t)__popcll(m_ref);
-        c_miss += (uint32_t)__popcll(m_miss);
-        c_eov += (uint32_t)__popcll(m_eov);
-        any_phase |= m_ph ? 1u : 0u;
-        for (uint32_t k = 1; k < n_allele; ++k) {
-            const uint64_t m = __ballot(called && allele == (int32_t)k);
-            if (lane == 0) {
-                reinterpret_cast<uint64_t*>(U.planes + (size_t)(b0 + k - 1u) * U.stride_w)[cgi] = m;
-                if (m) atomicAdd(&s_alt[(k - 1u) & 63u], (uint32_t)__popcll(m));
+    uint32_t c_ref = 0, c_miss = 0, c_eov = 0, any_phase = 0, c_alt1 = 0;
+    // Each wave owns a contiguous quarter of the row.  The 64-bit ballot words of up to 64 chunks are
+    // parked one per lane (v_writelane) and leave as one coalesced store per plane; the int32 loads
+    // of four chunks are issued before the first one is used.
+    const uint32_t cpw = (nchunks + 3u) / 4u;
+    const uint32_t c_begin = w * cpw < nchunks ? w * cpw : nchunks;
+    const uint32_t c_end = (w + 1u) * cpw < nchunks ? (w + 1u) * cpw : nchunks;
+    uint64_t* p_ref = reinterpret_cast<uint64_t*>(U.ref_planes + (size_t)l * U.stride_w);
+    uint64_t* p_miss = reinterpret_cast<uint64_t*>(U.miss_planes + (size_t)l * U.stride_w);
+    uint64_t* p_eov = reinterpret_cast<uint64_t*>(U.eov_planes + (size_t)l * U.stride_w);
+    uint64_t* p_ph = reinterpret_cast<uint64_t*>(U.phase_planes + (size_t)l * U.stride_w);
+    uint64_t* p_alt = reinterpret_cast<uint64_t*>(U.planes + (size_t)b0 * U.stride_w);  // first ALT plane
+    for (uint32_t g0 = c_begin; g0 < c_end; g0 += 64u) {
+        const uint32_t gn = c_end - g0 < 64u ? c_end - g0 : 64u;  // chunks in this group
+        uint32_t a_ref[2] = {0, 0}, a_miss[2] = {0, 0}, a_eov[2] = {0, 0}, a_ph[2] = {0, 0}, a_alt[2] = {0, 0};
+        for (uint32_t q0 = 0; q0 < gn; q0 += 4u) {
+            int32_t vv[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t i = (g0 + q0 + u) * 64u + lane;
+                vv[u] = (q0 + u < gn && i < ngt) ? row[i] : 0;
             }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                if (q0 + u >= gn) break;  // wave-uniform
+                const uint32_t cgi = g0 + q0 + u;
+                const uint32_t i = cgi * 64u + lane;
+                const bool in = i < ngt;
+                const int32_t v = vv[u];
+                const bool missing = in && (((v >> 1) == 0) || v == GT_INT32_MISSING);
+                const bool eov = in && !missing && v == GT_VECTOR_END;
+                const bool called = in && !missing && !eov;
+                const int32_t allele = (v >> 1) - 1;
+                if (called && (allele < 0 || allele >= (int32_t)n_allele)) *U.d_error = 1;  // "Unknown allele error !"
+                const bool ph = in && diploid && (i & 1u) && ((v & 1) != U.default_phased);
+                const uint64_t m_ref = __ballot(called && allele == 0);
+                const uint64_t m_miss = __ballot(missing);
+                const uint64_t m_eov = __ballot(eov);
+                const uint64_t m_ph = __ballot(ph);
+                const uint32_t slot = q0 + u;
+                a_ref[0] = write_lane(a_ref[0], (uint32_t)m_ref, slot);
+                a_ref[1] = write_lane(a_ref[1], (uint32_t)(m_ref >> 32), slot);
+                a_miss[0] = write_lane(a_miss[0], (uint32_t)m_miss, slot);
+                a_miss[1] = write_lane(a_miss[1], (uint32_t)(m_miss >> 32), slot);
+                a_eov[0] = write_lane(a_eov[0], (uint32_t)m_eov, slot);
+                a_eov[1] = write_lane(a_eov[1], (uint32_t)(m_eov >> 32), slot);
+                a_ph[0] = write_lane(a_ph[0], (uint32_t)m_ph, slot);
+                a_ph[1] = write_lane(a_ph[1], (uint32_t)(m_ph >> 32), slot);
+                c_ref += (uint32_t)__popcll(m_ref);
+                c_miss += (uint32_t)__popcll(m_miss);
+                c_eov += (uint32_t)__popcll(m_eov);
+                any_phase |= m_ph ? 1u : 0u;
+                // first ALT allele through the lane-parked path, further ALT alleles directly
+                {
+                    const uint64_t m = __ballot(called && allele == 1);
+                    a_alt[0] = write_lane(a_alt[0], (uint32_t)m, slot);
+                    a_alt[1] = write_lane(a_alt[1], (uint32_t)(m >> 32), slot);
+                    c_alt1 += (uint32_t)__popcll(m);
+                }
+                for (uint32_t k = 2; k < n_allele; ++k) {
+                    const uint64_t m = __ballot(called && allele == (int32_t)k);
+                    if (lane == 0) {
+                        reinterpret_cast<uint64_t*>(U.planes + (size_t)(b0 + k - 1u) * U.stride_w)[cgi] = m;
+                        if (m) atomicAdd(&s_alt[(k - 1u) & 63u], (uint32_t)__popcll(m));
+                    }
+                }
+            }
+        }
+        if (lane < gn) {
+            p_ref[g0 + lane] = ((uint64_t)a_ref[1] << 32) | a_ref[0];
+            p_miss[g0 + lane] = ((uint64_t)a_miss[1] << 32) | a_miss[0];
+            p_eov[g0 + lane] = ((uint64_t)a_eov[1] << 32) | a_eov[0];
+            p_ph[g0 + lane] = ((uint64_t)a_ph[1] << 32) | a_ph[0];
+            p_alt[g0 + lane] = ((uint64_t)a_alt[1] << 32) | a_alt[0];
         }
     }
     if (lane == 0) {
+        if (c_alt1) atomicAdd(&s_alt[0], c_alt1);
         atomicAdd(&s_cnt[0], c_ref);
         atomicAdd(&s_cnt[1], c_miss);
         atomicAdd(&s_cnt[2], c_eov);
@@ -462,8 +507,8 @@ __global__ void __launch_bounds__(256) k_compose_gt(ComposeArgs C) {
     const uint32_t* ep = C.S.eov_planes ? C.S.eov_planes + (size_t)start * C.S.stride_w : nullptr;
     const uint32_t* pp = C.S.phase_planes ? C.S.phase_planes + (size_t)start * C.S.stride_w : nullptr;
     int32_t* orow = C.out + (size_t)li * C.out_stride;
-    // grid.y workgroups share one line (few lines of many haplotypes: random access)
-    for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < Nl; i += blockDim.x * gridDim.y) {
+    // value of haplotype i of this line
+    auto value_of = [&](uint32_t i) -> int32_t {
         const int32_t ph = (int32_t)(i & 1u) & DP;
         const uint32_t wi = i >> 5, bi = i & 31u;
         int32_t gt;
@@ -500,7 +545,18 @@ __global__ void __launch_bounds__(256) k_compose_gt(ComposeArgs C) {
         if ((f & 1u) && mp && ((mp[wi] >> bi) & 1u)) gt = 0 | ph;                       // bcf_gt_missing | phase
         if ((f & 2u) && ep && ((ep[wi] >> bi) & 1u)) gt = GT_VECTOR_END;
         if ((f & 4u) && pp && ((pp[wi] >> bi) & 1u) && gt != GT_VECTOR_END) gt ^= (int32_t)(i & 1u);
-        orow[i] = gt;
+        return gt;
+    };
+    // grid.y workgroups share one line (few lines of many haplotypes: random access); four values per
+    // thread leave as one 16-byte store when the row base allows it
+    if (((C.out_stride & 3u) | (reinterpret_cast<uintptr_t>(C.out) & 15u)) == 0) {
+        const uint32_t Nq = Nl / 4u;
+        int4* orow4 = reinterpret_cast<int4*>(orow);
+        for (uint32_t q = blockIdx.y * blockDim.x + threadIdx.x; q < Nq; q += blockDim.x * gridDim.y)
+            orow4[q] = make_int4(value_of(4u * q), value_of(4u * q + 1u), value_of(4u * q + 2u), value_of(4u * q + 3u));
+        if (blockIdx.y == 0 && threadIdx.x < (Nl & 3u)) orow[Nq * 4u + threadIdx.x] = value_of(Nq * 4u + threadIdx.x);
+    } else {
+        for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < Nl; i += blockDim.x * gridDim.y) orow[i] = value_of(i);
     }
     if (threadIdx.x == 0 && blockIdx.y == 0) {
         C.line_ngt[li] = Nl;
