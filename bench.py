@@ -81,10 +81,12 @@ def main():
     d_bits = torch.empty(S * stride, dtype=torch.uint8, device=dev)
     binding.check(L.xsi_hip_synth_packed(ctx.handle, args.seed, first_site, S, N, d_bits.data_ptr(), stride))
     cap = int(L.xsi_hip_encode_bound(ctypes.byref(p), S, S))
-    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    # the file image (header + blocks region + index) is assembled in place: the encoder writes the
+    # blocks region straight behind the 256 header bytes
+    d_file = torch.empty(256 + cap + 8 * n_blocks + 64, dtype=torch.uint8, device=dev)
+    d_out = d_file[256:256 + cap]
     d_off = torch.zeros(n_blocks, dtype=torch.int64, device=dev)
     d_dec = torch.empty(S * stride, dtype=torch.uint8, device=dev)
-    d_file = torch.empty(cap + 256 + 8 * n_blocks + 64, dtype=torch.uint8, device=dev)
     res = binding.EncodeResult()
     rows = ctypes.c_uint64(0)
     state = {}
@@ -99,8 +101,8 @@ def main():
         hdr = (ctypes.c_uint8 * 256)()
         binding.check(L.xsi_hip_make_header(ctypes.byref(hf), hdr))
         d_file[:256] = torch.frombuffer(bytearray(hdr), dtype=torch.uint8).to(dev, non_blocking=True)
-        d_file[256:256 + nb] = d_out[:nb]
-        d_file[256 + nb:io] = 0
+        if pad:
+            d_file[256 + nb:io] = 0
         d_file[io:so] = d_off.view(torch.uint8)
         state["file_len"] = so
         return so

@@ -202,3 +202,16 @@ def test_two_rank_gather_reproduces_single_process_file():
 
     got = xdist.assemble_file(region, offs, hdr, names)
     assert got == ref
+
+
+def test_header_is_plain_c():
+    """include/xsi_hip.h is the drop-in boundary: it must compile as C99 on its own (no C++ / HIP types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "xsi_hip.h")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
