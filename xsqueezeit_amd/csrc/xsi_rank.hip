@@ -79,10 +79,19 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
             vm_hi = (uint32_t)(vm >> 32);
         }
     }
-    const bool store_lane = lane < (uint32_t)E && (uint64_t)(cg0 + lane) * 64u < N;
-    // rows are padded (e.g. to 128 bytes): the words past the last chunk must read as zero
-    const uint32_t row_words = ((N + 63u) / 64u) * 2u;
-    const bool pad_writer = blockIdx.y == 0 && A.out_stride_w > row_words;
+    // rows are padded (e.g. to 128 bytes): the words past the last chunk must read as zero.  The wave
+    // that owns the last chunk also stores the (all-zero: their valid mask is 0) padding chunks behind
+    // it with the same 8-byte-per-lane store; only when the padding does not fit its 64 lanes does the
+    // first workgroup of the block zero it with a separate loop.
+    const uint32_t nch = (N + 63u) / 64u;
+    const uint32_t row_words = nch * 2u;
+    const uint32_t row_chunks = A.out_stride_w / 2u;  // 8-byte words per output row
+    const bool owns_tail = cg0 < nch && nch <= cg0 + (uint32_t)E;
+    const uint32_t tail_cg0 = (nch - 1u) / (uint32_t)E * (uint32_t)E;  // first chunk of the wave that owns the tail
+    const bool tail_fits = (A.out_stride_w & 1u) == 0u && row_chunks - tail_cg0 <= 64u;
+    const bool store_lane = (lane < (uint32_t)E && cg0 + lane < nch) ||
+                            (owns_tail && tail_fits && cg0 + lane >= nch && cg0 + lane < row_chunks);
+    const bool pad_writer = blockIdx.y == 0 && A.out_stride_w > row_words && !tail_fits;
 
     if (!STAGE) {
         // rows too long for LDS (N > 65536): rank-select straight from L2
@@ -221,9 +230,16 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
             vm_hi = (uint32_t)(vm >> 32);
         }
     }
-    const bool store_lane = lane < (uint32_t)E && (uint64_t)(cg0 + lane) * 64u < N;
-    const uint32_t row_words = ((N + 63u) / 64u) * 2u;
-    const bool pad_writer = blockIdx.x == 0 && A.out_stride_w > row_words;
+    // padding chunks behind the last real one: stored by the wave that owns the tail (see above)
+    const uint32_t nch = (N + 63u) / 64u;
+    const uint32_t row_words = nch * 2u;
+    const uint32_t row_chunks = A.out_stride_w / 2u;
+    const bool owns_tail = cg0 < nch && nch <= cg0 + (uint32_t)E;
+    const uint32_t tail_cg0 = (nch - 1u) / (uint32_t)E * (uint32_t)E;
+    const bool tail_fits = (A.out_stride_w & 1u) == 0u && row_chunks - tail_cg0 <= 64u;
+    const bool store_lane = (lane < (uint32_t)E && cg0 + lane < nch) ||
+                            (owns_tail && tail_fits && cg0 + lane >= nch && cg0 + lane < row_chunks);
+    const bool pad_writer = blockIdx.x == 0 && A.out_stride_w > row_words && !tail_fits;
 
     uint2 R[RP];
     auto load_row = [&](uint32_t j) {
