@@ -194,6 +194,9 @@ int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t
 int xsi_writer_finalize(xsi_writer* w, uint32_t max_ploidy);
 void xsi_writer_close(xsi_writer* w);
 
+/* Accessor(filename).get_number_of_samples() without a device: what c_xcf_nsamples (c_api.cpp:60-65)
+ * asks of an .xsi file.  Reads the 256-byte header only.  Returns the count or <0. */
+int64_t xsi_file_num_samples(const char* path);
 /* Accessor(filename) (accessor.cpp:26-82). */
 int xsi_accessor_open(xsi_accessor** a, xsi_hip_ctx* ctx, const char* path);
 /* Accessor::fill_genotype_array(gt_arr, gt_arr_size, n_alleles, position) (accessor.hpp:48-50):

@@ -215,3 +215,18 @@ def test_header_is_plain_c():
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_file_num_samples_without_a_device(tmp_path):
+    """c_xcf_nsamples-style query: header-only, works on a box without a GPU."""
+    from oracle import oracle
+    rng = np.random.default_rng(3)
+    n = 23
+    lines = [(((rng.random(2 * n) < 0.3).astype(np.int32) + 1) << 1 | np.tile([0, 1], n), 2) for _ in range(40)]
+    data = oracle.encode_file(lines, n, block_len=16, mac_thr=1, default_phased=1)
+    path = tmp_path / "s.xsi"
+    path.write_bytes(data)
+    assert binding.lib().xsi_file_num_samples(str(path).encode()) == n
+    (tmp_path / "bad.xsi").write_bytes(b"\0" * 300)
+    assert binding.lib().xsi_file_num_samples(str(tmp_path / "bad.xsi").encode()) == -4
+    assert binding.lib().xsi_file_num_samples(str(tmp_path / "missing.xsi").encode()) == -6

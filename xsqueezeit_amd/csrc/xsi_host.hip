@@ -508,6 +508,25 @@ static int accessor_compose(xsi_accessor* a, uint32_t first, uint32_t n, uint32_
 
 extern "C" {
 
+int64_t xsi_file_num_samples(const char* path) {
+    if (!path) return set_error(XSI_ERR_ARG, "file_num_samples: null path");
+    FILE* f = fopen(path, "rb");
+    if (!f) return set_error(XSI_ERR_IO, "Failed to open file %s", path);
+    uint8_t h[256];
+    const size_t got = fread(h, 1, sizeof(h), f);
+    fclose(f);
+    auto get = [&](size_t off, int bytes) {
+        uint64_t v = 0;
+        for (int i = 0; i < bytes; ++i) v |= (uint64_t)h[off + i] << (8 * i);
+        return v;
+    };
+    if (got != sizeof(h) || get(4, 4) != 0xfeed1767u || get(252, 4) != 0xfeed1767u) return set_error(XSI_ERR_FORMAT, "Bad magic");
+    const uint64_t version = get(8, 4);
+    if (version != 4 && version != 5) return set_error(XSI_ERR_FORMAT, "Bad version");
+    if (h[12] == 0) return set_error(XSI_ERR_FORMAT, "PLOIDY ERROR");
+    return (int64_t)(get(32, 8) / h[12]);  // hap_samples / ploidy names are stored (accessor.cpp:53-60)
+}
+
 int xsi_accessor_open(xsi_accessor** out, xsi_hip_ctx* ctx, const char* path) {
     if (!out || !ctx || !path) return set_error(XSI_ERR_ARG, "accessor_open: null argument");
     FILE* f = fopen(path, "rb");
