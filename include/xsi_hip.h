@@ -168,6 +168,20 @@ int xsi_hip_decode_counts(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_le
                           uint64_t n_blocks, uint32_t* d_ones, uint8_t* d_kind, uint64_t capacity,
                           uint64_t* h_n_bin);
 
+/*
+ * Phenotype dot products on the decoded blocks — the GPU form of the reference's compute-on-compressed
+ * consumer (Accessor::get_internal_access, include/accessor.hpp:69-75, + dot_prod/dot_prod.hpp:122-245):
+ * d_out[r * n_pheno + k] = sum, over the haplotypes that carry the ALT allele of binary line r, of
+ * d_pheno[sample * n_pheno + k] (sample = haplotype / 2; = haplotype on fully haploid lines).  float64,
+ * fixed summation order; agrees with the reference's sum (taken in PBWT order) up to rounding.
+ * Works on the bit planes alone, so it covers bi-allelic, fully called lines (diploid or fully haploid);
+ * blocks with multi-allelic lines or missing / end-of-vector entries return XSI_ERR_UNSUPPORTED (use
+ * xsi_hip_decode_gt and contract the genotypes).
+ */
+int xsi_hip_decode_dot(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block,
+                       uint64_t n_blocks, const double* d_pheno, uint32_t n_pheno, double* d_out,
+                       uint64_t capacity_lines, uint64_t* h_n_bin);
+
 /* Deterministic synthetic haplotype matrix: writes n_lines packed rows starting
  * at site index first_line.  Generator defined in DESIGN.md; mirrored in numpy for the tests. */
 int xsi_hip_synth_packed(xsi_hip_ctx* ctx, uint64_t seed, uint64_t first_line, uint64_t n_lines, uint32_t n_haps,

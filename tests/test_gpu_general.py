@@ -375,3 +375,45 @@ def test_accessor_random_access_block_cache(tmp_path, budget):
     else:
         assert nb.value == 0
     L.xsi_accessor_close(a)
+
+
+@pytest.mark.gpu
+def test_phenotype_dot_products_on_decoded_planes():
+    """Sxy per ALT allele = sum of the phenotype over the carrying haplotypes
+    (dot_prod/dot_prod.hpp), float64.  Expected values from the oracle-decoded genotypes; the GPU sums in
+    a different (fixed) order than the reference's PBWT-order walk, hence a relative tolerance of 1e-12
+    on sums of O(1) values."""
+    import gpu_util as G
+    from oracle import oracle
+    torch = G.torch_mod()
+    L = binding.lib()
+    rng = np.random.default_rng(808)
+    n, n_lines, block_len, K = 700, 500, 128, 3
+    lines = _random_lines(rng, n, n_lines, phase=True)           # bi-allelic, fully called, mixed phase
+    for i in range(0, n_lines, 9):                                # some lines with the ALT allele in the majority
+        gt = lines[i][0]
+        flip = ((gt >> 1) - 1) ^ 1
+        lines[i] = ((((flip + 1) << 1) | (gt & 1)).astype(np.int32), 2)
+    dp = oracle.default_phased_of(lines, n)
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=14, default_phased=dp)
+    y = rng.normal(0.0, 10.0, size=(n, K))
+    d_file = G.dev_u8(np.frombuffer(ref, dtype=np.uint8))
+    d_y = torch.from_numpy(y).cuda()
+    d_out = torch.zeros((n_lines, K), dtype=torch.float64, device="cuda")
+    nb = ctypes.c_uint64(0)
+    n_blocks = (n_lines + block_len - 1) // block_len
+    binding.check(L.xsi_hip_decode_dot(G.ctx().handle, d_file.data_ptr(), len(ref), 0, n_blocks, d_y.data_ptr(), K,
+                                       d_out.data_ptr(), n_lines, ctypes.byref(nb)))
+    assert nb.value == n_lines
+    got = d_out.cpu().numpy()
+    dec = oracle.decode_file(ref, [2] * n_lines, block_len=block_len)
+    exp = np.stack([((((g >> 1) - 1) == 1).astype(np.float64)[:, None] * np.repeat(y, 2, axis=0)).sum(0) for g, _ in dec])
+    assert np.allclose(got, exp, rtol=1e-12, atol=1e-9)
+    # files the planes alone cannot answer are refused, not answered approximately
+    lines2 = _random_lines(rng, 40, 60, multi=True, missing=True)
+    ref2 = oracle.encode_file(lines2, 40, block_len=32, mac_thr=1, default_phased=oracle.default_phased_of(lines2, 40))
+    d_file2 = G.dev_u8(np.frombuffer(ref2, dtype=np.uint8))
+    y2 = torch.zeros((40, 1), dtype=torch.float64, device="cuda")
+    o2 = torch.zeros((400, 1), dtype=torch.float64, device="cuda")
+    rc = L.xsi_hip_decode_dot(G.ctx().handle, d_file2.data_ptr(), len(ref2), 0, 2, y2.data_ptr(), 1, o2.data_ptr(), 400, None)
+    assert rc == -5  # XSI_ERR_UNSUPPORTED

@@ -49,7 +49,7 @@ SYMBOLS = [
     "xsi_writer_finalize", "xsi_writer_close", "xsi_accessor_open", "xsi_accessor_fill_genotype_array",
     "xsi_accessor_get_genotypes", "xsi_accessor_allele_counts", "xsi_accessor_hap_samples",
     "xsi_accessor_num_samples", "xsi_accessor_sample_name", "xsi_accessor_close",
-    "xsi_accessor_set_cache_bytes", "xsi_accessor_cache_stats", "xsi_file_num_samples",
+    "xsi_accessor_set_cache_bytes", "xsi_accessor_cache_stats", "xsi_file_num_samples", "xsi_hip_decode_dot",
 ]
 
 _LIB = None
@@ -133,6 +133,8 @@ def lib():
     L.xsi_accessor_set_cache_bytes.argtypes = [vp, u64]
     L.xsi_accessor_cache_stats.restype = c.c_int
     L.xsi_accessor_cache_stats.argtypes = [vp, c.POINTER(u64), c.POINTER(u64), c.POINTER(u64), c.POINTER(u64)]
+    L.xsi_hip_decode_dot.restype = c.c_int
+    L.xsi_hip_decode_dot.argtypes = [vp, vp, u64, u64, u64, vp, u32, vp, u64, c.POINTER(u64)]
     L.xsi_file_num_samples.restype = c.c_int64
     L.xsi_file_num_samples.argtypes = [c.c_char_p]
     L.xsi_accessor_close.restype = None

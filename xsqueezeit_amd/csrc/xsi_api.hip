@@ -505,6 +505,40 @@ int xsi_hip_decode_counts(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_le
     return XSI_OK;
 }
 
+int xsi_hip_decode_dot(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block,
+                       uint64_t n_blocks64, const double* d_pheno, uint32_t n_pheno, double* d_out, uint64_t capacity,
+                       uint64_t* h_n_bin) {
+    if (!ctx || !d_file || !d_pheno || !d_out) return set_error(XSI_ERR_ARG, "decode_dot: null argument");
+    if (!n_pheno) return set_error(XSI_ERR_ARG, "decode_dot: n_pheno must be > 0");
+    if (file_len < 256) return set_error(XSI_ERR_FORMAT, "file image shorter than the 256-byte header");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DecodePlan P;
+    int rc = decode_prepare(ctx, d_file, file_len, first_block, n_blocks64, &P);
+    if (rc) return rc;
+    if (P.n_bin > capacity) return set_error(XSI_ERR_CAPACITY, "decode_dot: %u binary lines, capacity %llu", P.n_bin,
+                                             (unsigned long long)capacity);
+    // Exact for what the planes can say by themselves: bi-allelic, fully called lines.  A negated sparse
+    // line lists its REF haplotypes, so with other ALT alleles or missing / end-of-vector entries on the
+    // line the complement is not the carrier set; such blocks need the composed genotypes (decode_gt).
+    for (auto& b : P.blocks_h)
+        if (b.n_bin != b.n_bcf || b.off_line_missing != VAL_UNDEFINED || b.off_line_eov != VAL_UNDEFINED)
+            return set_error(XSI_ERR_UNSUPPORTED, "decode_dot: multi-allelic lines or missing / end-of-vector entries in the "
+                             "requested blocks; compose the genotypes with xsi_hip_decode_gt instead");
+    // ALT-carrier bit planes of every binary line (negated sparse lines flipped back), then the product
+    const uint32_t stride_w = P.L.y_stride64 * 2u;
+    uint32_t* planes;
+    WS(planes, "dot.planes", 4ull * stride_w * (size_t)(P.n_bin ? P.n_bin : 1));
+    rc = decode_planes(ctx, d_file, P, planes, stride_w, /*apply_negation=*/1);
+    if (rc) return rc;
+    rc = dot_planes(ctx, P, planes, stride_w, d_pheno, n_pheno, d_out);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    stage_collect(ctx);
+    if (h_n_bin) *h_n_bin = P.n_bin;
+    return XSI_OK;
+}
+
 int xsi_hip_synth_packed(xsi_hip_ctx* ctx, uint64_t seed, uint64_t first_line, uint64_t n_lines, uint32_t n_haps,
                          void* d_bits, uint32_t row_stride_bytes) {
     if (!ctx || !d_bits) return set_error(XSI_ERR_ARG, "synth_packed: null argument");

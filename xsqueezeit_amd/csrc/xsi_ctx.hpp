@@ -85,6 +85,8 @@ struct DecodedPlanes {
 };
 
 int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, DecodedPlanes* out);
+int dot_planes(xsi_hip_ctx* ctx, const DecodePlan& P, const uint32_t* planes, uint32_t stride_w, const double* d_y,
+               uint32_t n_pheno, double* d_out);
 int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D, const uint32_t* d_first_bin,
                   const uint32_t* d_n_allele, uint32_t n_out, int32_t* d_gt_out, uint64_t gt_stride,
                   uint32_t* d_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles);

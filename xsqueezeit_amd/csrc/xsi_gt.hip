@@ -577,6 +577,76 @@ __global__ void __launch_bounds__(256) k_compose_gt(ComposeArgs C) {
 
 namespace xsi {
 
+// ------------------------------------------------------------------------------------------
+// Phenotype dot products (dot_prod/dot_prod.hpp:122-245): Sxy[line][k] = sum over the haplotypes
+// that carry the line's ALT allele of y[sample of the haplotype][k].  The reference walks the WAH
+// words / sparse list of the line through the current `a`; here the decoded bit planes are in HBM
+// already, so this is a bit-matrix x dense-matrix product streamed at one bit per cell.  One wave
+// per binary line, float64 accumulation, fixed summation order (lane partial sums, then a wave
+// tree), so results are reproducible run to run; they differ from the reference's `a`-order sum
+// only in rounding.
+// ------------------------------------------------------------------------------------------
+template <int KB>
+__global__ void __launch_bounds__(256) k_dot_planes(const uint32_t* __restrict__ planes, uint32_t stride_w,
+                                                    const uint8_t* __restrict__ kind, uint32_t n_lines, uint32_t N,
+                                                    uint32_t n_samples, const double* __restrict__ y, uint32_t n_pheno,
+                                                    uint32_t k0, double* __restrict__ out) {
+    // phenotypes k0 .. k0+KB-1 of every line; a lane takes one SAMPLE per step: its dosage (0, 1, 2 ALT
+    // copies; 0 / 1 on fully haploid lines) is formed once and reused for the KB phenotypes
+    const uint32_t l = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (l >= n_lines) return;
+    const uint32_t lane = lane_id();
+    const bool haploid = (kind[l] & KIND_HAPLOID) != 0u;
+    const uint32_t* row = planes + (size_t)l * stride_w;
+    const uint32_t nw = stride_w;
+    double acc[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) acc[k] = 0.0;
+    for (uint32_t s0 = 0; s0 < n_samples; s0 += 64u) {
+        const uint32_t smp = s0 + lane;
+        uint32_t dosage = 0;
+        if (smp < n_samples) {
+            if (haploid) {
+                dosage = (row[smp >> 5] >> (smp & 31u)) & 1u;
+            } else {
+                const uint32_t h = 2u * smp;  // even: both haplotypes of the sample sit in one word
+                const uint32_t two = (h >> 5) < nw ? (row[h >> 5] >> (h & 31u)) & 3u : 0u;
+                dosage = (two & 1u) + (two >> 1);
+            }
+        }
+        if (dosage) {
+            const double d = (double)dosage;
+            const double* yp = y + (size_t)smp * n_pheno + k0;
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (k0 + (uint32_t)k < n_pheno) acc[k] += d * yp[k];
+        }
+    }
+    (void)N;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        double a = acc[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+        if (lane == 0 && k0 + (uint32_t)k < n_pheno) out[(size_t)l * n_pheno + k0 + (uint32_t)k] = a;
+    }
+}
+
+int dot_planes(xsi_hip_ctx* ctx, const DecodePlan& P, const uint32_t* planes, uint32_t stride_w, const double* d_y,
+               uint32_t n_pheno, double* d_out) {
+    if (!P.n_bin) return XSI_OK;
+    const dim3 grid((P.n_bin + 3u) / 4u), block(256);
+    uint32_t k0 = 0;
+    for (; k0 + 4u <= n_pheno; k0 += 4u)
+        k_dot_planes<4><<<grid, block, 0, ctx->stream>>>(planes, stride_w, P.L.kind, P.n_bin, P.L.N, P.L.n_samples, d_y,
+                                                         n_pheno, k0, d_out);
+    for (; k0 < n_pheno; ++k0)
+        k_dot_planes<1><<<grid, block, 0, ctx->stream>>>(planes, stride_w, P.L.kind, P.n_bin, P.L.N, P.L.n_samples, d_y,
+                                                         n_pheno, k0, d_out);
+    HIP_TRY(hipGetLastError());
+    return XSI_OK;
+}
+
 // Planes of every binary line of the parsed blocks, plus the side-channel planes when present.
 int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, DecodedPlanes* out) {
     hipStream_t s = ctx->stream;
