@@ -44,6 +44,8 @@ def test_synth_matches_numpy():
     (16390, 80, 64, 16),
     (64976, 24, 16, 64),
     (70002, 12, 8, 70),
+    (12000, 260, 130, 12),    # 12 chunks per wave: segment pre-pass with two nibble words per thread
+    (16384, 200, 100, 16),    # 16 chunks per wave, exact capacity
     (65600, 120, 60, 65),     # streaming chain: short last segment, long look-ahead history
     (131074, 200, 100, 131),
     (200000, 64, 64, 200),
@@ -86,6 +88,7 @@ def test_chain_matches_numpy(n_haps, n_lines, block_len, thr):
     (70002, 12, 8, 70),      # 35001 samples: header A_T=4, block A_T=2 -> encode-only
     (131074, 12, 8, 131),    # 65537 samples: u32 A_T everywhere, global-memory chain
     (200000, 10, 8, 200),
+    (10000, 520, 260, 10),    # 10 chunks per wave, chain cut into line segments
     (140000, 260, 128, 140),  # streaming encode chain + LDS-staged long-row decode chain, long blocks
     (530000, 24, 12, 530),    # > 16384 rank-select pairs per row: deepest prefetch variant
 ])

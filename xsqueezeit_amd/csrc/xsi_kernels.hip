@@ -447,37 +447,44 @@ __device__ __forceinline__ void chain_prepass(AT* a, uint32_t* pre_ids, uint32_t
                                               uint32_t lane, uint32_t w) {
     constexpr int W = T / 64;
     constexpr uint32_t NA = (uint32_t)T * E, NW = NA / 8u;  // nibble words: 8 haplotypes each
-    static_assert(NW <= (uint32_t)T, "one nibble word per thread");
+    constexpr uint32_t KW = (NW + (uint32_t)T - 1u) / (uint32_t)T;  // nibble words per thread (1 for E <= 8)
     static_assert(W == 16 || W == 4, "scan layouts below");
     const uint32_t N = A.N;
     const uint32_t src_words = (N + 31u) >> 5;
     for (uint32_t i = tid; i < s0; i += T) pre_ids[i] = A.wah_lines[wah_first + i];
     for (uint32_t i = tid; i < 2u * 16u * W; i += T) hist[i] = 0;
     __syncthreads();
-    const uint32_t rw = tid >> 2, rb = (tid & 3u) * 8u;  // my row word / byte within it
-    const bool builder = tid < NW;
-    uint32_t pad_or = 0;  // bits at or beyond N read as 1
-    if (rw * 32u + 32u > N) pad_or = (rw * 32u >= N) ? 0xFFFFFFFFu : (0xFFFFFFFFu << (N - rw * 32u));
-    uint32_t R4[4];
+    // my nibble word q covers haplotypes 8*(q*T + tid) ..+7: byte (tid & 3) of row word (q*T + tid) / 4
+    uint32_t R4[KW][4];
     auto load_rows = [&](uint32_t p) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t line = pre_ids[4u * p + (uint32_t)k];
-            R4[k] = (builder && rw < src_words) ? A.src[(size_t)line * A.src_stride_w + rw] : 0u;
+        for (uint32_t q = 0; q < KW; ++q) {
+            const uint32_t nwi = q * (uint32_t)T + tid, rw = nwi >> 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t line = pre_ids[4u * p + (uint32_t)k];
+                R4[q][k] = (nwi < NW && rw < src_words) ? A.src[(size_t)line * A.src_stride_w + rw] : 0u;
+            }
         }
     };
     auto build_nib = [&]() {
-        if (builder) {
-            uint32_t out = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t x = ((R4[k] | pad_or) >> rb) & 0xFFu;  // 8 haplotypes of line 4p+k
-                x = (x | (x << 12)) & 0x000F000Fu;
-                x = (x | (x << 6)) & 0x03030303u;
-                x = (x | (x << 3)) & 0x11111111u;               // bit i -> bit 4i
-                out |= x << k;
+        for (uint32_t q = 0; q < KW; ++q) {
+            const uint32_t nwi = q * (uint32_t)T + tid, rw = nwi >> 2, rb = (nwi & 3u) * 8u;
+            if (nwi < NW) {
+                uint32_t pad_or = 0;  // bits at or beyond N read as 1
+                if (rw * 32u + 32u > N) pad_or = (rw * 32u >= N) ? 0xFFFFFFFFu : (0xFFFFFFFFu << (N - rw * 32u));
+                uint32_t out = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t x = ((R4[q][k] | pad_or) >> rb) & 0xFFu;  // 8 haplotypes of line 4p+k
+                    x = (x | (x << 12)) & 0x000F000Fu;
+                    x = (x | (x << 6)) & 0x03030303u;
+                    x = (x | (x << 3)) & 0x11111111u;                  // bit i -> bit 4i
+                    out |= x << k;
+                }
+                nib[nwi] = out;
             }
-            nib[tid] = out;
         }
     };
     load_rows(0);
@@ -574,7 +581,7 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
     // the wave index is uniform: telling the compiler so turns per-wave arithmetic into SALU
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 
-    constexpr bool CAN_SPLIT = !DECODE && E <= 8;  // segment pre-pass: one nibble word per thread
+    constexpr bool CAN_SPLIT = !DECODE && E <= 16;  // segment pre-pass (3 registers per chunk: E <= 16)
     uint32_t wah_first, n_wah;
     uint32_t seg_start = 0;
     if (DECODE) {
@@ -1225,7 +1232,7 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
     uint32_t segs = 1;
     uint32_t lds_bytes = g.lds_bytes;
     A.segments = 1;
-    if (!DECODE && g.chunks <= 8 && !A.only_haploid_blocks) {
+    if (!DECODE && g.chunks <= 16 && !A.only_haploid_blocks) {
         static const int env_s = [] {
             const char* e = getenv("XSI_CHAIN_SEGMENTS");
             return e ? atoi(e) : 0;
