@@ -409,6 +409,16 @@ def test_phenotype_dot_products_on_decoded_planes():
     dec = oracle.decode_file(ref, [2] * n_lines, block_len=block_len)
     exp = np.stack([((((g >> 1) - 1) == 1).astype(np.float64)[:, None] * np.repeat(y, 2, axis=0)).sum(0) for g, _ in dec])
     assert np.allclose(got, exp, rtol=1e-12, atol=1e-9)
+    # many phenotypes: float64 matrix cores (16 per pass; 21 = one full and one partial group)
+    K2 = 21
+    y2m = rng.normal(0.0, 10.0, size=(n, K2))
+    d_y2 = torch.from_numpy(y2m).cuda()
+    d_out2 = torch.zeros((n_lines, K2), dtype=torch.float64, device="cuda")
+    binding.check(L.xsi_hip_decode_dot(G.ctx().handle, d_file.data_ptr(), len(ref), 0, n_blocks, d_y2.data_ptr(), K2,
+                                       d_out2.data_ptr(), n_lines, None))
+    alt = np.stack([(((g >> 1) - 1) == 1).astype(np.float64) for g, _ in dec])
+    exp2 = alt @ np.repeat(y2m, 2, axis=0)
+    assert np.allclose(d_out2.cpu().numpy(), exp2, rtol=1e-12, atol=1e-9)
     # files the planes alone cannot answer are refused, not answered approximately
     lines2 = _random_lines(rng, 40, 60, multi=True, missing=True)
     ref2 = oracle.encode_file(lines2, 40, block_len=32, mac_thr=1, default_phased=oracle.default_phased_of(lines2, 40))

@@ -3,6 +3,7 @@
 // lists) is shared with the packed path; this file only adds the conversion kernels around it.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -632,9 +633,79 @@ __global__ void __launch_bounds__(256) k_dot_planes(const uint32_t* __restrict__
     }
 }
 
+// Many phenotypes: the product is a real dense contraction, [lines x N] 0/1 times [N x K] float64, and
+// goes to the float64 matrix cores.  v_mfma_f64_16x16x4_f64: lane l holds A[row l&15][k l>>4] and
+// B[k l>>4][col l&15]; result register i of lane l is C[row (l>>4) + 4i][col l&15].  Rows = lines,
+// k = 4 consecutive haplotypes, columns = 16 phenotypes.  A wave owns 64 lines (4 tiles) so that one
+// B fragment (read from L2) feeds four MFMAs; products are exact (0/1 times y), accumulation is
+// float64.  Diploid lines only (haplotype h -> sample h/2); blocks with fully haploid lines take
+// the scalar kernel.
+typedef double xsi_d4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) k_dot_mfma(const uint32_t* __restrict__ planes, uint32_t stride_w, uint32_t n_lines,
+                                                  uint32_t N, const double* __restrict__ y, uint32_t n_pheno, uint32_t k0,
+                                                  double* __restrict__ out) {
+    const uint32_t lane = lane_id();
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t line0 = (blockIdx.x * 4u + w) * 64u;
+    if (line0 >= n_lines) return;
+    const uint32_t r = lane & 15u, kk = lane >> 4, c = lane & 15u;
+    const bool cvalid = k0 + c < n_pheno;
+    const uint32_t* rowp[4];
+    bool lvalid[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t line = line0 + 16u * (uint32_t)t + r;
+        lvalid[t] = line < n_lines;
+        rowp[t] = planes + (size_t)(lvalid[t] ? line : 0u) * stride_w;
+    }
+    xsi_d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (xsi_d4){0.0, 0.0, 0.0, 0.0};
+    const double* ycol = y + k0 + c;
+    for (uint32_t h32 = 0; h32 < N; h32 += 32u) {
+        // one 32-haplotype word per line and tile, eight B values per lane, then 8 x 4 MFMAs
+        uint32_t word[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) word[t] = lvalid[t] ? rowp[t][h32 >> 5] : 0u;
+        double b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t hap = h32 + 4u * (uint32_t)q + kk;
+            b[q] = (cvalid && hap < N) ? ycol[(size_t)(hap >> 1) * n_pheno] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t sh = 4u * (uint32_t)q + kk;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double a = ((word[t] >> sh) & 1u) ? 1.0 : 0.0;
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[q], acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t line = line0 + 16u * (uint32_t)t + kk + 4u * (uint32_t)i;
+            if (line < n_lines && cvalid) out[(size_t)line * n_pheno + k0 + c] = acc[t][i];
+        }
+}
+
 int dot_planes(xsi_hip_ctx* ctx, const DecodePlan& P, const uint32_t* planes, uint32_t stride_w, const double* d_y,
                uint32_t n_pheno, double* d_out) {
     if (!P.n_bin) return XSI_OK;
+    bool any_haploid = false;
+    for (auto& b : P.blocks_h)
+        if (b.off_line_haploid != VAL_UNDEFINED) any_haploid = true;
+    if (n_pheno >= 8u && !any_haploid && !getenv("XSI_DOT_SCALAR")) {
+        for (uint32_t k0 = 0; k0 < n_pheno; k0 += 16u)
+            k_dot_mfma<<<dim3((P.n_bin + 255u) / 256u), dim3(256), 0, ctx->stream>>>(planes, stride_w, P.n_bin, P.L.N, d_y,
+                                                                                      n_pheno, k0, d_out);
+        HIP_TRY(hipGetLastError());
+        return XSI_OK;
+    }
     const dim3 grid((P.n_bin + 3u) / 4u), block(256);
     uint32_t k0 = 0;
     for (; k0 + 4u <= n_pheno; k0 += 4u)
