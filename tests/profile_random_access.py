@@ -20,7 +20,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this script lives in tests/: it times the CPU oracle beside the GPU)
 sys.path.insert(0, ROOT)
 
 
