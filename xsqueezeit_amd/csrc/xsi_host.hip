@@ -72,7 +72,10 @@ struct xsi_writer {
     uint64_t N = 0;
     // current block
     int32_t* d_rows = nullptr;   // [block_len][N]
-    int32_t* h_chunk = nullptr;  // pinned staging
+    int32_t* h_chunk = nullptr;  // pinned staging chunk being filled
+    int32_t* h_chunks[2] = {nullptr, nullptr};  // two chunks: one fills while the other is on its way to HBM
+    hipEvent_t chunk_done[2] = {nullptr, nullptr};
+    int cur_chunk = 0;
     uint32_t chunk_rows = 0, chunk_fill = 0;
     uint32_t lines_in_block = 0, lines_on_device = 0;
     std::vector<uint32_t> ngt, n_allele;
@@ -89,9 +92,13 @@ static int writer_ship_chunk(xsi_writer* w) {
     if (!w->chunk_fill) return XSI_OK;
     HIP_TRY(hipMemcpyAsync(w->d_rows + (size_t)w->lines_on_device * w->N, w->h_chunk,
                            (size_t)w->chunk_fill * w->N * sizeof(int32_t), hipMemcpyHostToDevice, w->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(w->ctx->stream));  // the staging buffer is reused right away
+    HIP_TRY(hipEventRecord(w->chunk_done[w->cur_chunk], w->ctx->stream));
     w->lines_on_device += w->chunk_fill;
     w->chunk_fill = 0;
+    // keep filling the other chunk while this one is copied; wait only if that one is still in flight
+    w->cur_chunk ^= 1;
+    w->h_chunk = w->h_chunks[w->cur_chunk];
+    HIP_TRY(hipEventSynchronize(w->chunk_done[w->cur_chunk]));
     return XSI_OK;
 }
 
@@ -187,8 +194,17 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
     w->chunk_rows = (uint32_t)(chunk_bytes / row_bytes);
     if (w->chunk_rows < 1) w->chunk_rows = 1;
     if (w->chunk_rows > p->block_len) w->chunk_rows = p->block_len;
-    e = hipHostMalloc((void**)&w->h_chunk, row_bytes * w->chunk_rows, hipHostMallocDefault);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipHostMalloc((void**)&w->h_chunks[i], row_bytes * w->chunk_rows, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&w->chunk_done[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(w->chunk_done[i], w->ctx->stream);  // "free" from the start
+    }
+    w->h_chunk = w->h_chunks[0];
     if (e != hipSuccess) {
+        for (int i = 0; i < 2; ++i) {
+            if (w->h_chunks[i]) (void)hipHostFree(w->h_chunks[i]);
+            if (w->chunk_done[i]) (void)hipEventDestroy(w->chunk_done[i]);
+        }
         (void)hipFree(w->d_rows);
         fclose(w->f);
         delete w;
@@ -261,7 +277,10 @@ void xsi_writer_close(xsi_writer* w) {
     if (w->f) fclose(w->f);
     if (w->d_rows) (void)hipFree(w->d_rows);
     if (w->d_out) (void)hipFree(w->d_out);
-    if (w->h_chunk) (void)hipHostFree(w->h_chunk);
+    for (int i = 0; i < 2; ++i) {
+        if (w->h_chunks[i]) (void)hipHostFree(w->h_chunks[i]);
+        if (w->chunk_done[i]) (void)hipEventDestroy(w->chunk_done[i]);
+    }
     delete w;
 }
 
