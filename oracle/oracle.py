@@ -100,6 +100,9 @@ class Writer:
 
     def __init__(self, n_samples, block_len=8192, mac_thr=0, default_phased=1, wah_encode_missing=False,
                  sample_names=None):
+        if 32768 <= n_samples <= 65535:
+            raise ValueError("%d samples: the reference's A_T mismatch window (uint16 prefix array wraps, "
+                             "gt_block.hpp:171,179); neither the oracle nor the product encodes it" % n_samples)
         names = sample_names or ["S%d" % i for i in range(n_samples)]
         assert len(names) == n_samples
         arr = (ctypes.c_char_p * max(n_samples, 1))(*[s.encode() for s in names])

@@ -329,6 +329,12 @@ static void block_reset(xo_writer* w) {
 
 xo_writer* xo_writer_new(uint32_t n_samples, uint32_t block_len, uint32_t mac_thr, int32_t default_phased,
                          int wah_encode_missing, const char* const* sample_names) {
+    /* A_T mismatch window: the reference's GtBlock<uint16_t> keeps
+     * `std::vector<uint16_t> a(2*n_samples)` (gt_block.hpp:171,179), which wraps modulo 65536 for
+     * 32768 <= n_samples <= 65535, under a header that says A_T = 4 bytes: it cannot decode its own
+     * output there.  This restatement keeps `a` in uint32_t, so it would NOT be bug-compatible in the
+     * window; it refuses it instead (as the product does, XSI_ERR_UNSUPPORTED). */
+    if (n_samples >= 32768u && n_samples <= 65535u) return NULL;
     xo_writer* w = (xo_writer*)calloc(1, sizeof(*w));
     if (!w) return NULL;
     w->n_samples = n_samples;

@@ -48,7 +48,7 @@ def test_micro_fixture_through_gpu(name, golden_dir):
     (333, 500, 128, 0.02, dict(missing=True, eov=True, phase=True, multi=True)),
     (2504, 300, 100, 0.001, dict(missing=True, phase=True)),
     (2504, 200, 64, 0.001, dict(multi=True, eov=True)),
-    (40000, 12, 8, 0.001, dict(multi=True)),        # u16 blocks / u32 header (encode-only window)
+    (32767, 12, 8, 0.001, dict(multi=True)),        # largest u16 A_T size (65534 haplotypes)
     (70000, 10, 4, 0.001, dict(multi=True, missing=True, eov=True, phase=True)),  # u32, global-memory chain
 ])
 def test_general_encode_bit_exact_and_decode(n_samples, n_lines, block_len, maf, kw):
@@ -65,8 +65,6 @@ def test_general_encode_bit_exact_and_decode(n_samples, n_lines, block_len, maf,
     if got != ref:
         first = next(i for i in range(min(len(got), len(ref))) if got[i] != ref[i])
         raise AssertionError("file differs at offset %d (sizes %d vs %d)" % (first, len(got), len(ref)))
-    if 32768 <= n_samples <= 65535:
-        return
     nal = [na for _, na in lines]
     rows, counts = G.decode_gt(got, nal)
     oref = oracle.decode_file(ref, nal, block_len=block_len)

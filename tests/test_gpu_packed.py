@@ -43,10 +43,10 @@ def test_synth_matches_numpy():
     (5008, 600, 256, 5),
     (16390, 80, 64, 16),
     (64976, 24, 16, 64),
-    (70002, 12, 8, 70),
+    (65534, 12, 8, 65),       # 32767 samples: last size below the A_T mismatch window
     (12000, 260, 130, 12),    # 12 chunks per wave: segment pre-pass with two nibble words per thread
     (16384, 200, 100, 16),    # 16 chunks per wave, exact capacity
-    (65600, 120, 60, 65),     # streaming chain: short last segment, long look-ahead history
+    (65410, 120, 60, 65),     # 64 chunks per wave with padding members, long history
     (131074, 200, 100, 131),
     (200000, 64, 64, 200),
 ])
@@ -85,7 +85,7 @@ def test_chain_matches_numpy(n_haps, n_lines, block_len, thr):
     (5008, 700, 64, 0),
     (16390, 200, 64, 16),
     (64976, 40, 16, 64),
-    (70002, 12, 8, 70),      # 35001 samples: header A_T=4, block A_T=2 -> encode-only
+    (65534, 12, 8, 65),      # 32767 samples: largest count below the A_T mismatch window
     (131074, 12, 8, 131),    # 65537 samples: u32 A_T everywhere, global-memory chain
     (200000, 10, 8, 200),
     (10000, 520, 260, 10),    # 10 chunks per wave, chain cut into line segments
@@ -108,8 +108,6 @@ def test_encode_bit_exact_and_roundtrip(n_haps, n_lines, block_len, thr):
         first = next(i for i in range(min(len(got), len(ref))) if got[i] != ref[i])
         raise AssertionError("blocks region differs at file offset %d (sizes %d vs %d)" % (first, len(got), len(ref)))
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(ref).hexdigest()
-    if 32768 <= n_haps // 2 <= 65535:
-        return  # the reference cannot decode its own file in this window; the quirk is kept, not exercised
     # decode what we encoded
     out, counts = G.decode_packed(got, n_haps, stride)
     assert out.shape[0] == n_lines
@@ -178,7 +176,6 @@ def test_capacity_error_is_reported():
 
 @pytest.mark.parametrize("n_haps,n_lines,block_len,thr", [
     (65534, 20, 8, 65),     # largest count with u16 A_T in header AND blocks (32767 samples)
-    (65536, 12, 8, 65),     # 32768 samples: first size of the A_T mismatch window (encode-only)
     (131072, 10, 8, 131),   # 65536 samples: first size with u32 A_T everywhere
     (64, 200, 50, 0),       # exactly one wave chunk
     (66, 200, 50, 0),       # one sample past a chunk boundary
@@ -193,10 +190,42 @@ def test_size_boundaries(n_haps, n_lines, block_len, thr):
     region, offsets, res = G.encode_packed(packed, n_haps, p)
     got = G.assemble_file(region, offsets, p, n_lines, n_lines, names)
     assert got == ref
-    if 32768 <= n_haps // 2 <= 65535:
-        return
     out, counts = G.decode_packed(got, n_haps, stride)
     assert np.array_equal(out, packed)
+
+
+@pytest.mark.parametrize("n_samples", [32768, 35001, 40000, 65535])
+def test_at_mismatch_window_is_refused(n_samples, tmp_path):
+    """32768 <= n_samples <= 65535: the reference writes 16-bit block data (with a prefix array that
+    wraps modulo 65536, gt_block.hpp:171,179) under a header that says 32-bit A_T and cannot decode
+    it; every encode entry point returns XSI_ERR_UNSUPPORTED instead of writing such a file."""
+    import gpu_util as G
+    torch = G.torch_mod()
+    L = binding.lib()
+    n_haps = 2 * n_samples
+    stride = synth.row_stride_bytes(n_haps)
+    p = G.params(n_samples, 8, 10)
+    d_bits = G.dev_empty(4 * stride)
+    d_bits.zero_()
+    d_out = G.dev_empty(1 << 20)
+    d_off = torch.zeros(1, dtype=torch.int64, device="cuda")
+    res = binding.EncodeResult()
+    rc = L.xsi_hip_encode_packed(G.ctx().handle, ctypes.byref(p), d_bits.data_ptr(), 4, stride, d_out.data_ptr(),
+                                 1 << 20, d_off.data_ptr(), ctypes.byref(res))
+    assert rc == binding.XSI_ERR_UNSUPPORTED
+    assert b"mismatch window" in L.xsi_hip_last_error()
+    d_gt = torch.full((2, n_haps), 2, dtype=torch.int32, device="cuda")
+    ngt = np.full(2, n_haps, dtype=np.uint32)
+    nal = np.full(2, 2, dtype=np.uint32)
+    rc = L.xsi_hip_encode_gt(G.ctx().handle, ctypes.byref(p), d_gt.data_ptr(), n_haps, 2, ngt.ctypes.data,
+                             nal.ctypes.data, d_out.data_ptr(), 1 << 20, d_off.data_ptr(), ctypes.byref(res))
+    assert rc == binding.XSI_ERR_UNSUPPORTED
+    w = ctypes.c_void_p()
+    rc = L.xsi_writer_open(ctypes.byref(w), G.ctx().handle, str(tmp_path / "w.xsi").encode(), ctypes.byref(p), None)
+    assert rc == binding.XSI_ERR_UNSUPPORTED and not w.value
+    from oracle import oracle
+    with pytest.raises(ValueError):
+        oracle.Writer(n_samples)
 
 
 def test_all_sparse_and_all_wah_blocks():

@@ -134,11 +134,7 @@ def _rank_main(rank, world, port, n_haps, n_lines, bl, thr, q):
     data = w.finalize(2)
     io, so = struct.unpack_from("<QQ", data, 72)
     offs = np.frombuffer(data, dtype="<u8", count=(so - io) // 8, offset=io).astype(np.int64) - 256
-    end = io
-    while end > 256 and (end - 256) % 4 == 0 and False:
-        end -= 1
     # blocks region without the final pad-to-8 (each block already padded to 4)
-    last_len = None
     region = np.frombuffer(data, dtype=np.uint8, count=io - 256, offset=256)
     # strip the region's pad to 8: block sizes are multiples of 4, so at most 4 zero bytes were added
     n_real = int(offs[-1]) + _block_len(data, 256 + int(offs[-1]))

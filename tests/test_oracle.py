@@ -181,21 +181,27 @@ def _random_lines(rng, n_samples, n_lines, multi=False, missing=False, eov=False
     (50, 200, 64, dict(multi=True)),
     (37, 150, 32, dict(missing=True, eov=True, phase=True, multi=True)),
     (2504, 40, 16, {}),
-    (40000, 6, 4, {}),       # n_samples > 32767: header aet=4, block aet=2 -> skip decode
+    (32767, 6, 4, {}),       # largest size with u16 A_T in header and blocks
     (70000, 4, 4, {}),       # u32 A_T everywhere
 ])
 def test_oracle_roundtrip_synthetic(n_samples, n_lines, block_len, kw):
     rng = np.random.default_rng(n_samples * 1000 + n_lines)
     lines = _random_lines(rng, n_samples, n_lines, **kw)
     data = oracle.encode_file(lines, n_samples, maf=0.01, block_len=block_len)
-    if 32768 <= n_samples <= 65535:
-        return  # the reference cannot decode its own file here (quirk kept, not exercised)
     dec = oracle.decode_file(data, [n for _, n in lines], block_len=block_len)
     for (gt, counts), (src, n_allele) in zip(dec, lines):
         assert np.array_equal(gt, src)
         alleles = (src >> 1) - 1
         for k in range(1, n_allele):
             assert counts[k] == int(np.sum((alleles == k) & (src != oracle.INT32_VECTOR_END)))
+
+
+@pytest.mark.parametrize("n_samples", [32768, 40000, 65535])
+def test_oracle_refuses_at_mismatch_window(n_samples):
+    """The reference's uint16 prefix array wraps in this window (gt_block.hpp:171,179); the
+    restatement keeps uint32 and therefore refuses the window instead of claiming compatibility."""
+    with pytest.raises(ValueError):
+        oracle.Writer(n_samples)
 
 
 def test_oracle_wah_encode_missing_strategy():

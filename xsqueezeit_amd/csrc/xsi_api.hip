@@ -364,6 +364,10 @@ int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const vo
     if (p->block_len > MAX_BIN_PER_BLOCK)
         return set_error(XSI_ERR_ARG, "block_len %u exceeds the BM offset range (%u binary lines per block)", p->block_len,
                          MAX_BIN_PER_BLOCK);
+    if (at_mismatch_window(p->n_samples))
+        return set_error(XSI_ERR_UNSUPPORTED, "%s: %u samples fall in the reference's A_T mismatch window (32768..65535: 16-bit "
+                         "block data under a 32-bit header, prefix array wraps modulo 65536); it cannot be encoded decodably", "encode_packed",
+                         p->n_samples);
     const uint64_t N64 = 2ull * p->n_samples;
     if (row_stride_bytes % 8u || (uint64_t)row_stride_bytes * 8u < N64)
         return set_error(XSI_ERR_ARG, "row_stride_bytes %u must be a multiple of 8 and hold %llu bits", row_stride_bytes,
@@ -401,6 +405,10 @@ int xsi_hip_debug_chain_encode(xsi_hip_ctx* ctx, const xsi_encode_params* p, con
                                uint32_t row_stride_bytes, void* d_yrows, uint32_t y_stride_bytes, uint32_t* d_line_kind,
                                uint64_t* h_n_wah) {
     if (!ctx || !p || !d_bits || !d_yrows) return set_error(XSI_ERR_ARG, "debug_chain_encode: null argument");
+    if (at_mismatch_window(p->n_samples))
+        return set_error(XSI_ERR_UNSUPPORTED, "%s: %u samples fall in the reference's A_T mismatch window (32768..65535: 16-bit "
+                         "block data under a 32-bit header, prefix array wraps modulo 65536); it cannot be encoded decodably", "debug_chain_encode",
+                         p->n_samples);
     const uint32_t N = 2u * p->n_samples;
     if (y_stride_bytes % 8u || y_stride_bytes * 8ull < (((uint64_t)N + 63u) & ~63ull))
         return set_error(XSI_ERR_ARG, "y_stride_bytes too small");

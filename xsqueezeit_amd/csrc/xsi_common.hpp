@@ -32,6 +32,13 @@ constexpr uint32_t KEY_GT_ENTRY = 256;  // interfaces.hpp:167
 constexpr uint32_t BM_BLOCK_BITS = 15;  // accessor_internals.hpp:412
 constexpr uint32_t MAX_BIN_PER_BLOCK = 1u << BM_BLOCK_BITS;
 
+// A_T mismatch window of the reference: for 32768 <= n_samples <= 65535 the file
+// header says 4-byte A_T (2*n_samples > 65535, gt_compressor_new.hpp:177-187) while the block encoder
+// is instantiated with uint16_t (n_samples <= 65535, xsi_factory.hpp:424-427), whose prefix array
+// `std::vector<uint16_t> a(2*n_samples)` wraps modulo 65536 (gt_block.hpp:171,179).  The reference
+// cannot decode what it writes there, so every encode entry point refuses the window.
+inline bool at_mismatch_window(uint64_t n_samples) { return n_samples >= 32768u && n_samples <= 65535u; }
+
 // per-binary-line kind bits
 constexpr uint32_t KIND_WAH = 1u;       // WAH + PBWT line (else sparse)
 constexpr uint32_t KIND_NEGATED = 2u;   // sparse line lists the REF positions (MSB of the count set)

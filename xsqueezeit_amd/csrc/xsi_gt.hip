@@ -816,6 +816,10 @@ int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_
                       uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result) {
     if (!ctx || !p || !d_gt || !h_ngt || !h_n_allele || !d_out) return set_error(XSI_ERR_ARG, "encode_gt: null argument");
     if (!p->n_samples || !p->block_len) return set_error(XSI_ERR_ARG, "encode_gt: n_samples and block_len must be > 0");
+    if (at_mismatch_window(p->n_samples))
+        return set_error(XSI_ERR_UNSUPPORTED, "%s: %u samples fall in the reference's A_T mismatch window (32768..65535: 16-bit "
+                         "block data under a 32-bit header, prefix array wraps modulo 65536); it cannot be encoded decodably", "encode_gt",
+                         p->n_samples);
     if (n_lines == 0 || n_lines > 0x7FFFFFFFull) return set_error(XSI_ERR_ARG, "n_lines out of range");
     const uint32_t N = 2u * p->n_samples;
     if (gt_stride < N) return set_error(XSI_ERR_ARG, "gt_stride %llu < 2*n_samples", (unsigned long long)gt_stride);
@@ -986,6 +990,9 @@ int xsi_hip_decode_gt(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, u
     WS(d_line_ngt, "gt.line_ngt", 4ull * n_bcf);
     HIP_TRY(hipMemcpyAsync(d_first_bin, first_bin.data(), 4ull * n_bcf, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_nallele, h_n_allele, 4ull * n_bcf, hipMemcpyHostToDevice, s));
+    // first_bin is a local vector and h_n_allele the caller's: the copies must have left host memory
+    // before any error return below can unwind this frame
+    HIP_TRY(hipStreamSynchronize(s));
     DecodedPlanes DPn;
     rc = decode_all_planes(ctx, d_file, P, &DPn);
     if (rc) return rc;

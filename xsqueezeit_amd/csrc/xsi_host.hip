@@ -134,7 +134,7 @@ static int writer_flush_block(xsi_writer* w) {
             return set_error(XSI_ERR_IO, "short write");
         w->file_pos += 16 + csize;
         while (w->file_pos % 4) {
-            fputc(0, w->f);
+            if (fputc(0, w->f) == EOF) return set_error(XSI_ERR_IO, "short write");
             w->file_pos++;
         }
     } else {
@@ -167,6 +167,10 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
     if (!out || !ctx || !path || !p) return set_error(XSI_ERR_ARG, "writer_open: null argument");
     if (!p->n_samples || !p->block_len || p->block_len > MAX_BIN_PER_BLOCK)
         return set_error(XSI_ERR_ARG, "writer_open: bad n_samples / block_len");
+    if (at_mismatch_window(p->n_samples))
+        return set_error(XSI_ERR_UNSUPPORTED, "%s: %u samples fall in the reference's A_T mismatch window (32768..65535: 16-bit "
+                         "block data under a 32-bit header, prefix array wraps modulo 65536); it cannot be encoded decodably", "writer_open",
+                         p->n_samples);
     if (p->zstd_level && !zstd_api().ok) return set_error(XSI_ERR_UNSUPPORTED, "--zstd requested but libzstd.so.1 could not be loaded");
     HIP_TRY(hipSetDevice(ctx->device));
     xsi_writer* w = new xsi_writer();
@@ -244,7 +248,7 @@ int xsi_writer_finalize(xsi_writer* w, uint32_t max_ploidy) {
     if (rc) return rc;
     // xsi_factory.hpp:558-605
     while (w->file_pos % 8) {
-        fputc(0, w->f);
+        if (fputc(0, w->f) == EOF) return set_error(XSI_ERR_IO, "short write");
         w->file_pos++;
     }
     xsi_header_fields hf{};
@@ -261,14 +265,15 @@ int xsi_writer_finalize(xsi_writer* w, uint32_t max_ploidy) {
         return set_error(XSI_ERR_IO, "short write");
     w->file_pos += 8 * w->indices.size();
     hf.samples_offset = w->file_pos;
-    for (auto& s : w->names) fwrite(s.c_str(), 1, s.size() + 1, w->f);
+    for (auto& s : w->names)
+        if (fwrite(s.c_str(), 1, s.size() + 1, w->f) != s.size() + 1) return set_error(XSI_ERR_IO, "short write");
     uint8_t h[256];
     xsi_hip_make_header(&hf, h);
-    fflush(w->f);
-    fseek(w->f, 0, SEEK_SET);
+    if (fflush(w->f) != 0 || fseek(w->f, 0, SEEK_SET) != 0) return set_error(XSI_ERR_IO, "header rewrite failed");
     if (fwrite(h, 1, 256, w->f) != 256) return set_error(XSI_ERR_IO, "short write");
-    fclose(w->f);
+    const int crc = fclose(w->f);
     w->f = nullptr;
+    if (crc != 0) return set_error(XSI_ERR_IO, "close failed");
     return XSI_OK;
 }
 
@@ -357,10 +362,12 @@ static int accessor_block_image(xsi_accessor* a, uint64_t block, const uint8_t**
     };
     const uint64_t io = get(72, 8);
     const uint64_t off = a->version >= 5 ? get(io + block * 8, 8) : get(io + block * 4, 4);
-    const int sz = a->version >= 5 ? 8 : 4;
-    if (off + 2 * sz > a->file.size()) return set_error(XSI_ERR_FORMAT, "block offset outside the file");
-    const uint64_t csize = get(off, sz), usize = get(off + sz, sz);
-    if (off + 2 * sz + csize > a->file.size() || usize > (1ull << 34)) return set_error(XSI_ERR_FORMAT, "corrupt zstd block header");
+    const uint64_t sz = a->version >= 5 ? 8 : 4;
+    // untrusted file values: every comparison is written so that it cannot wrap
+    const uint64_t fsz = a->file.size();
+    if (off > fsz || fsz - off < 2 * sz) return set_error(XSI_ERR_FORMAT, "block offset outside the file");
+    const uint64_t csize = get(off, (int)sz), usize = get(off + sz, (int)sz);
+    if (csize > fsz - off - 2 * sz || usize > (1ull << 34)) return set_error(XSI_ERR_FORMAT, "corrupt zstd block header");
     const ZstdApi& z = zstd_api();
     if (!z.ok) return set_error(XSI_ERR_UNSUPPORTED, "zstd-compressed file but libzstd.so.1 could not be loaded");
     size_t body = (size_t)usize;
@@ -739,6 +746,13 @@ int xsi_accessor_fill_allele_counts(xsi_accessor* a, uint32_t n_alleles, uint64_
         uint64_t len, blk;
         int rc = accessor_block_image(a, block, &img, &len, &blk);
         if (rc) return rc;
+        if (a->cur_in_workspace) {
+            // decode_prepare reuses the context workspace the current block's planes live in: drop that
+            // view before anything is overwritten, so that an error below cannot leave it half valid
+            a->cur_block = -1;
+            a->win_n = 0;
+        }
+        a->cnt_block = -1;
         rc = decode_prepare(a->ctx, img, len, blk, 1, &P);
         if (rc) return rc;
         rc = decode_counts_only(a->ctx, img, P);
@@ -749,10 +763,6 @@ int xsi_accessor_fill_allele_counts(xsi_accessor* a, uint32_t n_alleles, uint64_
         HIP_TRY(hipMemcpyAsync(a->cnt_kind.data(), P.L.kind, P.n_bin, hipMemcpyDeviceToHost, a->ctx->stream));
         HIP_TRY(hipStreamSynchronize(a->ctx->stream));
         a->cnt_block = (int64_t)block;
-        if (a->cur_in_workspace) {
-            a->cur_block = -1;  // the shared workspace now holds the counts-only state of this block
-            a->win_n = 0;
-        }
     }
     if ((size_t)offset + (n_alleles - 1) > a->cnt_ones.size())
         return set_error(XSI_ERR_ARG, "position offset %u (+%u alleles) beyond the block", offset, n_alleles - 1);

@@ -2331,15 +2331,16 @@ __global__ void __launch_bounds__(64) k_sparse_fill(const uint8_t* __restrict__ 
     const uint32_t lane = lane_id();
     for (uint32_t i = lane; i < out_stride_w; i += 64u) row[i] = 0;
     __syncthreads();
-    const uint8_t* p = file + D.gt_off + D.off_sparse + L.sparse_start[k];
-    uint32_t num = rd_at(p, L.aet);
+    const uint64_t at = D.gt_off + D.off_sparse + L.sparse_start[k];
+    const uint8_t* p = file + at;
+    const bool in_file = at <= L.file_len && L.file_len - at >= L.aet;  // corrupt image: never read past it
+    uint32_t num = in_file ? rd_at(p, L.aet) : 0u;
     const uint32_t msb = (L.aet == 2u) ? 0x8000u : 0x80000000u;
     const bool neg = (num & msb) != 0u;
     num &= ~msb;
     {
-        const uint64_t at = D.gt_off + D.off_sparse + L.sparse_start[k];
-        const uint64_t room = at + L.aet <= L.file_len ? (L.file_len - at) / L.aet - 1u : 0u;
-        if (num > room) num = (uint32_t)room;  // corrupt image: stay inside it
+        const uint64_t room = in_file ? (L.file_len - at) / L.aet - 1u : 0u;
+        if (num > room) num = (uint32_t)room;
     }
     for (uint32_t i = lane; i < num; i += 64u) {
         const uint32_t idx = rd_at(p + (size_t)(1u + i) * L.aet, L.aet);
