@@ -58,12 +58,21 @@ int xsi_hip_ctx_synchronize(xsi_hip_ctx* ctx);
 /* Bytes of device workspace currently held by the context. */
 uint64_t xsi_hip_ctx_workspace_bytes(const xsi_hip_ctx* ctx);
 
+/* Bytes of per-line device workspace one block-level call may hold.  A job that needs more (e.g. 153 blocks
+ * of 500 000 haplotypes) is run as several batches of whole blocks inside the call; the bytes written are
+ * those of a single pass, since blocks are independent.  0 (default) = 40 % of the HBM that is free at
+ * the call; the environment variable XSI_WS_BUDGET_MB overrides the default. */
+int xsi_hip_ctx_set_workspace_budget(xsi_hip_ctx* ctx, uint64_t bytes);
+
 /* Per-stage device timing with HIP events recorded on the context's stream (used by bench.py for
  * the roofline of the dominant kernel).  get_timing fills h_ms[i] / h_launches[i] for stage i and
  * returns the number of stages; xsi_hip_stage_name(i) names them. */
 int xsi_hip_ctx_set_timing(xsi_hip_ctx* ctx, int on);
 int xsi_hip_ctx_get_timing(xsi_hip_ctx* ctx, double* h_ms, uint64_t* h_launches, int n);
 const char* xsi_hip_stage_name(int i);
+/* Name of the kernel that runs the PBWT chain (the dominant kernel) for a batch of n_blocks blocks of
+ * n_haps haplotypes without fully haploid lines: what bench.py names in its roofline object. */
+const char* xsi_hip_chain_kernel(uint32_t n_haps, uint64_t n_blocks, int decode);
 
 /* Parameters of one encode job (the arguments of XsiFactoryExt's constructor that reach
  * GtBlock: include/xsi_factory.hpp:439-449, include/gt_block.hpp:159-181). */

@@ -50,6 +50,7 @@ SYMBOLS = [
     "xsi_accessor_get_genotypes", "xsi_accessor_allele_counts", "xsi_accessor_hap_samples",
     "xsi_accessor_num_samples", "xsi_accessor_sample_name", "xsi_accessor_close",
     "xsi_accessor_set_cache_bytes", "xsi_accessor_cache_stats", "xsi_file_num_samples", "xsi_hip_decode_dot",
+    "xsi_hip_ctx_set_workspace_budget", "xsi_hip_chain_kernel",
 ]
 
 _LIB = None
@@ -82,6 +83,10 @@ def lib():
     L.xsi_hip_ctx_get_timing.argtypes = [vp, c.POINTER(c.c_double), c.POINTER(u64), c.c_int]
     L.xsi_hip_stage_name.restype = c.c_char_p
     L.xsi_hip_stage_name.argtypes = [c.c_int]
+    L.xsi_hip_ctx_set_workspace_budget.restype = c.c_int
+    L.xsi_hip_ctx_set_workspace_budget.argtypes = [vp, u64]
+    L.xsi_hip_chain_kernel.restype = c.c_char_p
+    L.xsi_hip_chain_kernel.argtypes = [u32, u64, c.c_int]
     L.xsi_hip_encode_bound.restype = u64
     L.xsi_hip_encode_bound.argtypes = [c.POINTER(EncodeParams), u64, u64]
     L.xsi_hip_encode_gt_bound.restype = u64

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -109,6 +110,12 @@ uint64_t xsi_hip_ctx_workspace_bytes(const xsi_hip_ctx* c) {
     return t;
 }
 
+int xsi_hip_ctx_set_workspace_budget(xsi_hip_ctx* c, uint64_t bytes) {
+    if (!c) return set_error(XSI_ERR_ARG, "null context");
+    c->ws_budget = bytes;
+    return XSI_OK;
+}
+
 int xsi_hip_ctx_set_timing(xsi_hip_ctx* c, int on) {
     if (!c) return set_error(XSI_ERR_ARG, "null context");
     c->timing = on != 0;
@@ -127,6 +134,10 @@ int xsi_hip_ctx_get_timing(xsi_hip_ctx* c, double* h_ms, uint64_t* h_launches, i
         h_launches[i] = i < XSI_STAGE_COUNT ? c->stage_n[i] : 0;
     }
     return XSI_STAGE_COUNT;
+}
+
+const char* xsi_hip_chain_kernel(uint32_t n_haps, uint64_t n_blocks, int decode) {
+    return chain_kernel_name(n_haps, (uint32_t)(n_blocks > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_blocks), decode != 0);
 }
 
 const char* xsi_hip_stage_name(int i) {
@@ -189,6 +200,17 @@ int xsi_hip_make_header(const xsi_header_fields* f, uint8_t h[256]) {
 }  // extern "C"
 
 namespace xsi {
+
+uint64_t ws_budget_now(const xsi_hip_ctx* c) {
+    if (c->ws_budget) return c->ws_budget;
+    if (const char* e = getenv("XSI_WS_BUDGET_MB")) return (uint64_t)strtoull(e, nullptr, 10) << 20;
+    // what is free now plus what this context already holds and will reuse
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 8ull << 30;
+    uint64_t held = 0;
+    for (auto& kv : c->bufs) held += kv.second.cap;
+    return (uint64_t)((free_b + held) * 0.4);
+}
 
 void stage_mark(xsi_hip_ctx* c, int stage) {
     if (!c->timing) return;
@@ -261,7 +283,8 @@ int pinned_ensure(xsi_hip_ctx* c, size_t bytes, void** out) {
 // Shared tail of both encode entry points: everything after the per-line bit planes, counts
 // and kinds exist.  Lines/side describe the batch; blocks_h holds the host-filled part.
 int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide S, std::vector<EncBlock>& blocks_h,
-               void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result) {
+               void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result,
+               uint64_t region_offset, bool use_wah_scratch) {
     hipStream_t s = ctx->stream;
     const uint32_t n_blocks = (uint32_t)blocks_h.size();
     const uint32_t n_bin = L.n_bin;
@@ -279,7 +302,8 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     WS(L.yrows, "enc.yrows", 8ull * L.y_stride64 * (size_t)n_bin);
     // WAH16 words per line, worst case ceil(N/15) (+1 for the saturation split): encode once, then copy
     L.wah_scratch_stride = ((N + 14u) / 15u + 3u) & ~1u;  // even: rows stay 4-byte aligned for k_wah_write
-    WS(L.wah_scratch, "enc.wah_scratch", 2ull * L.wah_scratch_stride * (size_t)n_bin);
+    L.wah_scratch = nullptr;  // without it the lines are sized first and encoded again straight into place
+    if (use_wah_scratch) WS(L.wah_scratch, "enc.wah_scratch", 2ull * L.wah_scratch_stride * (size_t)n_bin);
     WS(L.flagbits, "enc.flagbits", 4ull * (MAX_BIN_PER_BLOCK / 32) * FV_COUNT * (size_t)n_blocks);
     WS(L.flagwah, "enc.flagwah", 2ull * FLAG_WORDS_MAX * FV_COUNT * (size_t)n_blocks);
     uint32_t* d_totals;
@@ -319,7 +343,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     HIP_TRY(launch_wah_sizes(s, L, d_totals, n_bin));
     stage_mark(ctx, XSI_ST_LAYOUT);
     HIP_TRY(launch_block_layout(s, d_blocks, n_blocks, L, S, p->default_phased));
-    HIP_TRY(launch_scan_blocks_out(s, d_blocks, n_blocks, out_capacity, d_block_offsets, d_result));
+    HIP_TRY(launch_scan_blocks_out(s, d_blocks, n_blocks, out_capacity, d_block_offsets, d_result, 256u + region_offset));
     const uint32_t strategy = p->wah_encode_missing ? WS_WAH : WS_SPARSE;
     stage_mark(ctx, XSI_ST_WRITE);
     HIP_TRY(launch_write_headers(s, d_blocks, n_blocks, L, p->default_phased, strategy, (uint8_t*)d_out, d_result));
@@ -376,29 +400,61 @@ int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const vo
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const uint32_t N = (uint32_t)N64;
-    const uint32_t n_bin = (uint32_t)n_lines;
-    const uint32_t n_blocks = (uint32_t)((n_lines + p->block_len - 1) / p->block_len);
-    std::vector<EncBlock> blocks(n_blocks);
-    for (uint32_t b = 0; b < n_blocks; ++b) {
-        memset(&blocks[b], 0, sizeof(EncBlock));
-        blocks[b].first_bcf = blocks[b].first_bin = b * p->block_len;
-        const uint64_t left = n_lines - (uint64_t)b * p->block_len;
-        blocks[b].n_bcf = blocks[b].n_bin = (uint32_t)(left < p->block_len ? left : p->block_len);
+    const uint64_t n_blocks_all = (n_lines + p->block_len - 1) / p->block_len;
+    // Per-line workspace: the permuted row y and (optionally) the WAH16 words of the line, encoded once and
+    // copied into place.  A job whose workspace exceeds the budget drops the WAH scratch first (lines are then
+    // sized and encoded twice), then runs as batches of whole blocks: blocks are independent
+    // (gt_block.hpp:179-180, xsi_factory.hpp:527-539), so the bytes are those of a single call.
+    const uint64_t y_line = 8ull * ((N + 63u) / 64u), scratch_line = 2ull * (((N + 14u) / 15u + 3u) & ~1u), misc_line = 40;
+    const uint64_t budget = ws_budget_now(ctx);
+    bool use_scratch = (y_line + scratch_line + misc_line) * n_lines <= budget;
+    const uint64_t per_block = (y_line + (use_scratch ? scratch_line : 0) + misc_line) * p->block_len;
+    uint64_t max_batch = budget / (per_block ? per_block : 1);
+    if (max_batch < 1) max_batch = 1;
+    const uint64_t n_batches = (n_blocks_all + max_batch - 1) / max_batch;
+    const uint64_t batch_blocks = (n_blocks_all + n_batches - 1) / n_batches;  // balanced
+    xsi_encode_result total{};
+    uint64_t region_off = 0;
+    for (uint64_t b0 = 0; b0 < n_blocks_all; b0 += batch_blocks) {
+        const uint64_t nb = b0 + batch_blocks <= n_blocks_all ? batch_blocks : n_blocks_all - b0;
+        const uint64_t l0 = b0 * p->block_len;
+        const uint64_t nl = (l0 + nb * p->block_len <= n_lines) ? nb * p->block_len : n_lines - l0;
+        const uint32_t n_bin = (uint32_t)nl;
+        std::vector<EncBlock> blocks((size_t)nb);
+        for (uint32_t b = 0; b < (uint32_t)nb; ++b) {
+            memset(&blocks[b], 0, sizeof(EncBlock));
+            blocks[b].first_bcf = blocks[b].first_bin = b * p->block_len;
+            const uint64_t left = nl - (uint64_t)b * p->block_len;
+            blocks[b].n_bcf = blocks[b].n_bin = (uint32_t)(left < p->block_len ? left : p->block_len);
+        }
+        EncLines L{};
+        L.planes = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(d_bits) + l0 * row_stride_bytes);
+        L.plane_stride_w = row_stride_bytes / 4u;
+        L.n_bin = n_bin;
+        L.N = N;
+        L.aet = p->n_samples <= 65535u ? 2u : 4u;  // xsi_factory.hpp:424-427
+        L.thr = p->mac_threshold;
+        WS(L.cnt, "enc.cnt", 4ull * n_bin);
+        WS(L.kind, "enc.kind", (size_t)n_bin);
+        HIP_TRY(hipMemsetAsync(L.kind, 0, n_bin, s));
+        stage_mark(ctx, XSI_ST_COUNT);
+        HIP_TRY(launch_count_rows(s, L.planes, L.plane_stride_w, N, n_bin, L.cnt));
+        EncSide S{};
+        xsi_encode_result r{};
+        if (region_off > out_capacity) return set_error(XSI_ERR_CAPACITY, "encode: output capacity exhausted");
+        int rc = encode_run(ctx, p, L, S, blocks, reinterpret_cast<uint8_t*>(d_out) + region_off, out_capacity - region_off,
+                            d_block_offsets ? d_block_offsets + b0 : nullptr, &r, region_off, use_scratch);
+        if (rc) return rc;
+        region_off += r.blocks_bytes;
+        total.n_blocks += r.n_blocks;
+        total.n_binary_lines += r.n_binary_lines;
+        total.n_wah_lines += r.n_wah_lines;
+        total.max_ploidy = r.max_ploidy;
+        total.last_block_bytes = r.last_block_bytes;
     }
-    EncLines L{};
-    L.planes = reinterpret_cast<const uint32_t*>(d_bits);
-    L.plane_stride_w = row_stride_bytes / 4u;
-    L.n_bin = n_bin;
-    L.N = N;
-    L.aet = p->n_samples <= 65535u ? 2u : 4u;  // xsi_factory.hpp:424-427
-    L.thr = p->mac_threshold;
-    WS(L.cnt, "enc.cnt", 4ull * n_bin);
-    WS(L.kind, "enc.kind", (size_t)n_bin);
-    HIP_TRY(hipMemsetAsync(L.kind, 0, n_bin, s));
-    stage_mark(ctx, XSI_ST_COUNT);
-    HIP_TRY(launch_count_rows(s, L.planes, L.plane_stride_w, N, n_bin, L.cnt));
-    EncSide S{};
-    return encode_run(ctx, p, L, S, blocks, d_out, out_capacity, d_block_offsets, h_result);
+    total.blocks_bytes = region_off;
+    if (h_result) *h_result = total;
+    return XSI_OK;
 }
 
 int xsi_hip_debug_chain_encode(xsi_hip_ctx* ctx, const xsi_encode_params* p, const void* d_bits, uint64_t n_lines,
@@ -470,25 +526,53 @@ int xsi_hip_decode_packed(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_le
     if (file_len < 256) return set_error(XSI_ERR_FORMAT, "file image shorter than the 256-byte header");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    DecodePlan P;
-    int rc = decode_prepare(ctx, d_file, file_len, first_block, n_blocks64, &P);
-    if (rc) return rc;
-    if (row_stride_bytes % 8u || (uint64_t)row_stride_bytes * 8u < P.L.N)
-        return set_error(XSI_ERR_ARG, "row_stride_bytes %u must be a multiple of 8 and hold %u bits", row_stride_bytes, P.L.N);
-    if (P.n_bin > out_rows_capacity)
-        return set_error(XSI_ERR_CAPACITY, "decode_packed: %u rows, capacity %llu", P.n_bin, (unsigned long long)out_rows_capacity);
-    if (P.has_side)
-        return set_error(XSI_ERR_UNSUPPORTED, "decode_packed: blocks carry missing / end-of-vector / phase / haploid data; use xsi_hip_decode_gt");
-    if (P.n_bin != P.n_bcf)
-        return set_error(XSI_ERR_UNSUPPORTED, "decode_packed: multi-allelic lines present; use xsi_hip_decode_gt");
-    uint32_t* out = reinterpret_cast<uint32_t*>(d_bits_out);
-    const uint32_t stride_w = row_stride_bytes / 4u;
-    rc = decode_planes(ctx, d_file, P, out, stride_w, /*apply_negation=*/1);
-    if (rc) return rc;
-    if (d_counts) HIP_TRY(hipMemcpyAsync(d_counts, P.L.ones, 4ull * P.n_bin, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    stage_collect(ctx);
-    if (h_rows_written) *h_rows_written = P.n_bin;
+    // Per-line workspace of the decode is the expanded row of every WAH line ({bits, prefix} pairs, N/4
+    // bytes); a block range that needs more than the budget is decoded as batches of whole blocks.
+    uint64_t batch_blocks = n_blocks64;
+    {
+        uint8_t h[256];
+        HIP_TRY(hipMemcpyAsync(h, d_file, 256, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        auto get = [&](size_t off, int bytes) {
+            uint64_t v = 0;
+            for (int i = 0; i < bytes; ++i) v |= (uint64_t)h[off + i] << (8 * i);
+            return v;
+        };
+        const uint64_t ns = get(112, 8), N64 = ns ? ns * 2 : get(32, 8), bl = get(56, 4) ? get(56, 4) : 8192;
+        const uint64_t per_block = (16ull * ((N64 + 63u) / 64u) + 64u) * bl;
+        uint64_t max_batch = ws_budget_now(ctx) / (per_block ? per_block : 1);
+        if (max_batch < 1) max_batch = 1;
+        if (n_blocks64 > max_batch) {
+            const uint64_t n_batches = (n_blocks64 + max_batch - 1) / max_batch;
+            batch_blocks = (n_blocks64 + n_batches - 1) / n_batches;
+        }
+    }
+    uint64_t rows_done = 0;
+    for (uint64_t b0 = 0; b0 < n_blocks64 || b0 == 0; b0 += batch_blocks) {
+        const uint64_t nb = b0 + batch_blocks <= n_blocks64 ? batch_blocks : n_blocks64 - b0;
+        DecodePlan P;
+        int rc = decode_prepare(ctx, d_file, file_len, first_block + b0, nb, &P);
+        if (rc) return rc;
+        if (row_stride_bytes % 8u || (uint64_t)row_stride_bytes * 8u < P.L.N)
+            return set_error(XSI_ERR_ARG, "row_stride_bytes %u must be a multiple of 8 and hold %u bits", row_stride_bytes, P.L.N);
+        if (rows_done + P.n_bin > out_rows_capacity)
+            return set_error(XSI_ERR_CAPACITY, "decode_packed: %llu rows, capacity %llu", (unsigned long long)(rows_done + P.n_bin),
+                             (unsigned long long)out_rows_capacity);
+        if (P.has_side)
+            return set_error(XSI_ERR_UNSUPPORTED, "decode_packed: blocks carry missing / end-of-vector / phase / haploid data; use xsi_hip_decode_gt");
+        if (P.n_bin != P.n_bcf)
+            return set_error(XSI_ERR_UNSUPPORTED, "decode_packed: multi-allelic lines present; use xsi_hip_decode_gt");
+        uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(d_bits_out) + rows_done * row_stride_bytes);
+        const uint32_t stride_w = row_stride_bytes / 4u;
+        rc = decode_planes(ctx, d_file, P, out, stride_w, /*apply_negation=*/1);
+        if (rc) return rc;
+        if (d_counts) HIP_TRY(hipMemcpyAsync(d_counts + rows_done, P.L.ones, 4ull * P.n_bin, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        stage_collect(ctx);
+        rows_done += P.n_bin;
+        if (n_blocks64 == 0) break;
+    }
+    if (h_rows_written) *h_rows_written = rows_done;
     return XSI_OK;
 }
 

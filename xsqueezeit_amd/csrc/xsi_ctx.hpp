@@ -40,6 +40,9 @@ struct xsi_hip_ctx {
         size_t cap = 0;
     };
     std::map<std::string, Buf> bufs;  // named device workspace, grown on demand, reused across calls
+    // Bytes of per-line workspace one encode / decode call may hold (0 = 40 % of the free HBM at the call).
+    // A job that needs more runs as several batches of whole blocks (blocks are independent).
+    uint64_t ws_budget = 0;
     void* pinned = nullptr;           // pinned host staging
     size_t pinned_cap = 0;
     // optional per-stage timing with HIP events recorded on `stream` (bench.py roofline leg)
@@ -95,8 +98,12 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
 int decode_counts_only(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P);
 int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t* out, uint32_t stride_w,
                   int apply_negation);
+// region_offset: bytes of the blocks region that earlier batches of the same job already wrote before d_out
 int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide S, std::vector<EncBlock>& blocks_h,
-               void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result);
+               void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result,
+               uint64_t region_offset = 0, bool use_wah_scratch = true);
+// bytes of per-line workspace budget in force for a call made now
+uint64_t ws_budget_now(const xsi_hip_ctx* ctx);
 int encode_side_write(xsi_hip_ctx* ctx, const EncBlock* d_blocks, uint32_t n_blocks, const EncLines& L,
                       const EncSide& S, uint8_t* out, const uint64_t* d_result);
 

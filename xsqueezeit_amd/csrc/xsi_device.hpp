@@ -35,6 +35,17 @@ __device__ __forceinline__ uint32_t write_lane(uint32_t old, uint32_t uniform_va
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Workgroup barrier for LDS hand-offs that involve 16-bit stores or LDS atomics.  hipcc (ROCm 7.2) emits
+// no s_waitcnt lgkmcnt before the s_barrier of __syncthreads(): it assumes the LDS executes the
+// operations of all waves of a workgroup in one total order.  On MI355X that did not hold for
+// ds_write_b16 followed, behind the barrier, by another wave's ds_read of the same dword: about one
+// run in three of a 3000-line decode read a stale member (tools history: r02, xsi_pair.hip).  Waiting
+// for this wave's own LDS operations to complete before it arrives at the barrier removes the window.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0); vmcnt / expcnt untouched
+    __syncthreads();
+}
+
 // popcount(mask & lanes below me)
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));

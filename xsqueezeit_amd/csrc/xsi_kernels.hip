@@ -299,7 +299,7 @@ __device__ __forceinline__ void chain_scatter(AT* a, uint32_t* wcnt, const uint3
                                               uint32_t N, uint32_t na) {
     constexpr int W = T / 64;
     if (lane == 0) wcnt[w] = zc;
-    __syncthreads();
+    lds_barrier();
     uint32_t sc = row16_scan_incl(lane < (uint32_t)W ? wcnt[lane] : 0u);
     const uint32_t tz = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
     uint32_t zb = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
@@ -327,7 +327,7 @@ __device__ __forceinline__ void chain_scatter(AT* a, uint32_t* wcnt, const uint3
             ob += (PADS_ARE_ONES ? 64u : nv) - nz;
         }
     });
-    __syncthreads();
+    lds_barrier();
 }
 
 // Fully haploid line (ngt == n_samples): gt_block.hpp:304-309 + pbwt_sort1
@@ -366,7 +366,7 @@ __device__ __attribute__((noinline)) void chain_step_haploid(uint32_t a_off, uin
         }
     });
     if (lane == 0) ev[w] = ec;
-    __syncthreads();
+    lds_barrier();
     uint32_t eb = 0;
     for (uint32_t i = 0; i < w; ++i) eb += ev[i];
     if (DECODE) {
@@ -386,7 +386,7 @@ __device__ __attribute__((noinline)) void chain_step_haploid(uint32_t a_off, uin
                 ebw += (uint32_t)__popcll(evm);
             }
         });
-        __syncthreads();
+        lds_barrier();
     }
     const uint32_t* keycol = DECODE ? xrow : c;
     uint32_t zc = 0;
@@ -403,7 +403,7 @@ __device__ __attribute__((noinline)) void chain_step_haploid(uint32_t a_off, uin
         }
     });
     if (DECODE) {
-        __syncthreads();  // every wave has read its keys from xrow
+        lds_barrier();  // every wave has read its keys from xrow
     } else {
         // y[p] = key of the p-th even member
         uint32_t ebw = eb;
@@ -418,7 +418,7 @@ __device__ __attribute__((noinline)) void chain_step_haploid(uint32_t a_off, uin
                 ebw += (uint32_t)__popcll(evm);
             }
         });
-        __syncthreads();
+        lds_barrier();
     }
     // publish xrow (decode: x by sample; encode: y in a1 order), n_samples bits
     const uint32_t nbits = N >> 1;
@@ -460,7 +460,7 @@ __device__ __forceinline__ void chain_prepass(AT* a, uint32_t* pre_ids, uint32_t
     const uint32_t src_words = (N + 31u) >> 5;
     for (uint32_t i = tid; i < s0; i += T) pre_ids[i] = A.wah_lines[wah_first + i];
     for (uint32_t i = tid; i < 2u * 16u * W; i += T) hist[i] = 0;
-    __syncthreads();
+    lds_barrier();
     // my nibble word q covers haplotypes 8*(q*T + tid) ..+7: byte (tid & 3) of row word (q*T + tid) / 4
     uint32_t R4[KW][4];
     auto load_rows = [&](uint32_t p) {
@@ -496,7 +496,7 @@ __device__ __forceinline__ void chain_prepass(AT* a, uint32_t* pre_ids, uint32_t
     };
     load_rows(0);
     build_nib();
-    __syncthreads();
+    lds_barrier();
     const uint32_t n_pass = s0 >> 2;
     AT* aw = a + w * (E * 64u) + lane;
     // LDS integer addresses with the arrays' own addresses folded into wave-uniform constants
@@ -541,7 +541,7 @@ __device__ __forceinline__ void chain_prepass(AT* a, uint32_t* pre_ids, uint32_t
             if (before == 0u) *hp = old + cnt;
             rk[e] = (old + before) << ASH;  // byte offset inside my bin
         });
-        __syncthreads();  // counters complete; every wave has read `a` and nib
+        lds_barrier();  // counters complete; every wave has read `a` and nib
         // exclusive prefix over the 16 x W counters in bin-major order (every wave for itself)
         uint32_t exv;
         if constexpr (W == 16) {
@@ -563,7 +563,7 @@ __device__ __forceinline__ void chain_prepass(AT* a, uint32_t* pre_ids, uint32_t
         });
         if (lane < 16u) h_nxt[lane * W + w] = 0;
         if (more) build_nib();
-        __syncthreads();  // scatter done, next keys in place
+        lds_barrier();  // scatter done, next keys in place
     }
 }
 
@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
             uint32_t* pre_ids = linfo + 48;
             uint32_t* nib = pre_ids + PRE_ID_CAP;
             uint32_t* hist = nib + NA / 8u;
-            __syncthreads();
+            lds_barrier();
             chain_prepass<T, E, AT>(a, pre_ids, nib, hist, A, wah_first, seg_start, tid, lane, w);
             wah_first += seg_start;
             n_wah -= seg_start;
@@ -685,10 +685,10 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
     store_info(0);
     load_info(1);
     store_info(1);
-    __syncthreads();
+    lds_barrier();
     load_cols(0);
     store_cols(0);
-    __syncthreads();
+    lds_barrier();
 
     AT* aw = a + w * (E * 64u) + lane;  // my element of chunk e is aw[e*64]
     using LdsAT = __attribute__((address_space(3))) AT;
@@ -759,7 +759,7 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
                 }
             }
             if (lane == 0) wcnt[w] = E * 64u - ones;
-            __syncthreads();
+            lds_barrier();
             if (DECODE) {
                 uint32_t* orow = A.dst + (size_t)(line - A.out_row_base) * A.dst_stride_w;
                 for (uint32_t i = tid; i < A.dst_stride_w; i += T) {
@@ -798,11 +798,11 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
                 zb2 += 64u * AS - no2;
                 ob2 += no2;
             });
-            __syncthreads();
+            lds_barrier();
         }
         if (more) store_cols((bt + 1u) & 1u);
         store_info(bt + 2u);
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -1145,14 +1145,10 @@ static const int k_chain_E[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 
 
 ChainGeom chain_geometry(uint32_t N, bool decode) {
     ChainGeom g{};
-    // Encode: from ~48k haplotypes on the streaming kernel (prefix array in HBM/L2, one pass per line)
-    // beats the LDS kernel with its 48+ chunks per wave (measured: 90 ms against 110 ms per 8192-line
-    // block at 64976 haplotypes, 61 against 54 ms at 40000).  XSI_STREAM_MIN_N overrides (tuning aid).
-    static const uint32_t stream_min = [] {
-        const char* e = getenv("XSI_STREAM_MIN_N");
-        return e ? (uint32_t)atoi(e) : 49152u;
-    }();
-    g.in_lds = N <= 65536u && (decode || N < stream_min);
+    // N <= 65536: prefix array in LDS (k_chain_pair for the bulk, k_chain_lds for small N and for blocks
+    // with fully haploid lines); beyond that it streams through HBM/L2 (k_chain_stream / k_chain_global).
+    (void)decode;
+    g.in_lds = N <= 65536u;
     if (!g.in_lds) {
         const uint32_t cw = (((N + 31u) >> 5) + 1u) & ~1u;
         g.threads = 1024;
@@ -1211,18 +1207,10 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
             // streaming kernel for the blocks without fully haploid lines, the two-pass kernel for the rest
             const uint32_t seg = (((A.N + 15u) / 16u) + 63u) & ~63u;  // positions per wave
             const uint32_t lds = (2u * A.cw + 3u * 16u) * 4u;
-            hipError_t e;
-            if (A.N <= 65536u) {
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_stream<uint16_t>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-                k_chain_stream<uint16_t><<<dim3(n_blocks), dim3(1024), lds, s>>>(eb, A, scratch_a, seg);
-            } else {
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_stream<uint32_t>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-                k_chain_stream<uint32_t><<<dim3(n_blocks), dim3(1024), lds, s>>>(eb, A, scratch_a, seg);
-            }
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_stream<uint32_t>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            k_chain_stream<uint32_t><<<dim3(n_blocks), dim3(1024), lds, s>>>(eb, A, scratch_a, seg);
             e = hipGetLastError();
             if (e != hipSuccess || !any_haploid) return e;
             A.only_haploid_blocks = 1;
@@ -1306,12 +1294,52 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
     return hipErrorInvalidValue;
 }
 
+// Which kernel takes the blocks without fully haploid lines (measured on MI355X, profiles/r02_chain_sweep.txt):
+//   encode  rank tracking (xsi_rankenc.hip) from ~20k haplotypes on, and from ~12k when there are enough
+//           blocks that k_chain_lds could not cut them into line segments anyway;
+//   decode  packed-pair position-major (xsi_pair.hip) when every CU gets a block of its own and the rows are
+//           long; otherwise the element-major kernels of xsi_rank.hip, which split a block over workgroups.
+// XSI_RANKENC_MIN_N / XSI_PAIR_MIN_N_DEC override the size rule (testing: force a kernel for every N).
+static bool use_rank_encode(uint32_t N, uint32_t n_blocks) {
+    static const int env = [] {
+        const char* e = getenv("XSI_RANKENC_MIN_N");
+        return e ? atoi(e) : -1;
+    }();
+    if (!chain_rank_enc_supported(N)) return false;
+    if (env >= 0) return N >= (uint32_t)env;
+    return N >= 20480u || (N >= 12288u && n_blocks >= 192u);
+}
+static bool use_pair_decode(uint32_t N, uint32_t n_blocks) {
+    static const int env = [] {
+        const char* e = getenv("XSI_PAIR_MIN_N_DEC");
+        return e ? atoi(e) : -1;
+    }();
+    if (!chain_pair_supported(N)) return false;
+    if (env >= 0) return N >= (uint32_t)env;
+    return N >= 40960u && n_blocks >= 192u;
+}
+
+const char* chain_kernel_name(uint32_t N, uint32_t n_blocks, bool decode) {
+    if (decode) {
+        if (use_pair_decode(N, n_blocks)) return "k_chain_pair_dec";
+        return N >= 49152u ? "k_chain_decode_rank_big" : "k_chain_decode_rank";
+    }
+    if (use_rank_encode(N, n_blocks)) return "k_chain_rank_enc";
+    return N <= 65536u ? "k_chain_lds" : "k_chain_stream";
+}
+
 hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
                                uint32_t* scratch_a, bool any_haploid) {
+    bool rank_done = false;
+    if (use_rank_encode(L.N, n_blocks)) {
+        hipError_t e = launch_rank_encode(s, blocks, n_blocks, L);
+        if (e != hipSuccess || !any_haploid) return e;
+        rank_done = true;  // k_chain_lds below only takes the blocks with fully haploid lines
+    }
     ChainArgs A{};
     // LDS kernel: handles haploid lines itself.  N > 65536: the streaming kernel takes the blocks
     // without haploid lines, k_chain_global the others (only_haploid_blocks makes it skip the rest).
-    A.only_haploid_blocks = (any_haploid && !chain_geometry(L.N, false).in_lds) ? 1u : 0u;
+    A.only_haploid_blocks = (rank_done || (any_haploid && !chain_geometry(L.N, false).in_lds)) ? 1u : 0u;
     A.wah_lines = L.wah_lines;
     A.kind = L.kind;
     A.src = L.planes;
@@ -1326,8 +1354,11 @@ hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n
 hipError_t launch_chain_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                                uint32_t* out_rows, uint32_t out_stride_w, uint32_t* scratch_a, bool any_haploid) {
     if (!n_blocks) return hipSuccess;
-    // element-major kernels (xsi_rank.hip): every block without fully haploid lines
-    hipError_t e = launch_rank_decode(s, blocks, n_blocks, L, out_rows, out_stride_w);
+    // blocks without fully haploid lines: element-major kernels (xsi_rank.hip) at small N, where the two
+    // barriers per line of a position-major step dominate; packed-pair position-major kernel (xsi_pair.hip)
+    // at large N, where the rank-select gather does
+    hipError_t e = use_pair_decode(L.N, n_blocks) ? launch_pair_decode(s, blocks, n_blocks, L, out_rows, out_stride_w)
+                                                  : launch_rank_decode(s, blocks, n_blocks, L, out_rows, out_stride_w);
     if (e != hipSuccess || !any_haploid) return e;
     // position-major kernel: the blocks with fully haploid lines (it skips the others)
     ChainArgs A{};
@@ -1656,7 +1687,7 @@ hipError_t launch_block_layout(hipStream_t s, EncBlock* blocks, uint32_t n_block
 // d_result: [0] total bytes, [1] n_blocks, [2] total WAH lines, [3] error (1 = capacity)
 __global__ void __launch_bounds__(1024) k_scan_blocks_out(EncBlock* __restrict__ blocks, uint32_t n_blocks,
                                                           uint64_t capacity, uint64_t* __restrict__ d_block_offsets,
-                                                          uint64_t* __restrict__ d_result) {
+                                                          uint64_t* __restrict__ d_result, uint64_t file_base) {
     __shared__ uint64_t s_scan[20];
     uint64_t base = 0;
     uint32_t wah = 0;
@@ -1667,7 +1698,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks_out(EncBlock* __restrict__
         const uint64_t ex = block_scan_excl64(v, s_scan, &tot);
         if (i < n_blocks) {
             blocks[i].out_off = base + ex;
-            if (d_block_offsets) d_block_offsets[i] = 256u + base + ex;
+            if (d_block_offsets) d_block_offsets[i] = file_base + base + ex;  // 256 + bytes of earlier blocks
         }
         base += tot;
     }
@@ -1682,8 +1713,8 @@ __global__ void __launch_bounds__(1024) k_scan_blocks_out(EncBlock* __restrict__
 }
 
 hipError_t launch_scan_blocks_out(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, uint64_t capacity,
-                                  uint64_t* d_block_offsets, uint64_t* d_result) {
-    k_scan_blocks_out<<<dim3(1), dim3(1024), 0, s>>>(blocks, n_blocks, capacity, d_block_offsets, d_result);
+                                  uint64_t* d_block_offsets, uint64_t* d_result, uint64_t file_base) {
+    k_scan_blocks_out<<<dim3(1), dim3(1024), 0, s>>>(blocks, n_blocks, capacity, d_block_offsets, d_result, file_base);
     return hipGetLastError();
 }
 

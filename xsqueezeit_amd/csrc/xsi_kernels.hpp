@@ -72,7 +72,7 @@ hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_
 hipError_t launch_block_layout(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
                                const EncSide& S, int32_t default_phased);
 hipError_t launch_scan_blocks_out(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, uint64_t capacity,
-                                  uint64_t* d_block_offsets, uint64_t* d_result /*[4]*/);
+                                  uint64_t* d_block_offsets, uint64_t* d_result /*[5]*/, uint64_t file_base);
 hipError_t launch_write_headers(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
                                 int32_t default_phased, uint32_t strategy, uint8_t* out, const uint64_t* d_result);
 hipError_t launch_wah_write(hipStream_t s, const EncBlock* blocks, const EncLines& L, uint32_t max_wah,
@@ -133,6 +133,15 @@ hipError_t launch_sparse_fill(hipStream_t s, const uint8_t* file, const DecBlock
 hipError_t launch_line_counts(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
                               uint32_t max_wah, uint32_t max_sparse, const uint32_t* d_totals);
 
+// packed-pair position-major decode chain (xsi_pair.hip): blocks without fully haploid lines, N <= 65536
+bool chain_pair_supported(uint32_t N);
+hipError_t launch_pair_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
+                              uint32_t* out_rows, uint32_t out_stride_w);
+
+// element-major encode chain (xsi_rankenc.hip): blocks without fully haploid lines, N <= 65536
+bool chain_rank_enc_supported(uint32_t N);
+hipError_t launch_rank_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L);
+
 // ---- synthetic data ----
 hipError_t launch_synth_packed(hipStream_t s, uint64_t seed, uint64_t first_line, uint64_t n_lines, uint32_t n_haps,
                                uint32_t* bits, uint32_t stride_w);
@@ -145,5 +154,7 @@ struct ChainGeom {
     bool in_lds;
 };
 ChainGeom chain_geometry(uint32_t N, bool decode);
+// name of the kernel that runs the PBWT chain of the blocks without fully haploid lines
+const char* chain_kernel_name(uint32_t N, uint32_t n_blocks, bool decode);
 
 }  // namespace xsi

@@ -1,0 +1,268 @@
+// xsi_rankenc.hip — element-major ("rank tracking") PBWT encode chain for gfx950, N <= 65536.
+//
+// Reference behaviour (per block, for every WAH line k in order; sparse lines never touch `a`,
+// gt_block.hpp:299-326):
+//   y_k[i]  = x_k[a_k[i]]                                         (wah.hpp:530-537, gather through a)
+//   a_{k+1} = [a_k[i] : y_k[i]=0] ++ [a_k[i] : y_k[i]=1]            (internal_gt_record.hpp:32-59)
+// with a_0 the identity (gt_block.hpp:179).  The position-major kernels move `a` around: per member
+// and line a gather of its key bit, a ballot, two lane-prefix counts and a scatter, ~18-24 vector
+// instructions per 64 members — and on this chip a wave64 vector instruction takes the SIMD for four
+// cycles, so the instruction count is the bound, not LDS or HBM.
+//
+// This kernel never materialises `a`.  Let r_k(h) be the position of haplotype h in a_k (the inverse
+// permutation, r_0(h) = h).  Then
+//   y_k[r_k(h)] = x_k(h)                                            -> only the ONES of x_k are written
+//   r_{k+1}(h)  = x_k(h) ? Z_k + ones_k(r_k(h)) : r_k(h) - ones_k(r_k(h))
+// where ones_k(r) = set bits of y_k before position r and Z_k = zeros of y_k (a stable partition moves
+// a zero at r to "zeros before r" and a one to Z + "ones before r").  A lane owns haplotype
+// 64*chunk + lane, so the key bits of a chunk are one 64-bit word of the INPUT row: they arrive in
+// SGPRs by scalar loads and act as the select mask directly — no gather of key bits, no ballot, no
+// v_mbcnt, no v_readlane / v_writelane.  Per line:
+//   M  every lane advances its E ranks: one ds_read_b64 gather of {32 row bits, ones before them},
+//      v_bfm/v_and/v_bcnt, subtract, add, select (8 vector instructions per 64 haplotypes); and with
+//      the new rank it deposits its bit of the NEXT line into that line's row (LDS atomic OR, chunks
+//      whose 64 input bits are all zero are skipped: most chunks of most lines);
+//   A  (barrier) the finished row y_{k+1}: two words per thread -> popcounts, wave scan, stored to HBM;
+//   B  (barrier) cross-wave prefix -> the rank-select table {bits, ones before} of line k+1, row cleared;
+//      (barrier).
+// Bits at or beyond N never enter a row; lanes beyond N idle on rank 0.
+#include "xsi_kernels.hpp"
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "xsi_device.hpp"
+
+namespace xsi {
+
+struct RankEncArgs {
+    const uint32_t* wah_lines;  // [rank] binary line
+    const uint32_t* src;        // planes by binary line (natural haplotype order)
+    uint32_t src_stride_w;
+    uint32_t* dst;              // permuted rows y by rank
+    uint32_t dst_stride_w;
+    uint32_t N;
+};
+
+using LdsU32 = __attribute__((address_space(3))) uint32_t;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+using LdsU2 = __attribute__((address_space(3))) u32x2;
+using ConstU32 = __attribute__((address_space(4))) const uint32_t;
+
+// Uniform (scalar) loads: casting to the constant address space makes the compiler use s_load for
+// addresses it knows to be wave-uniform.  The input rows and the line list are never written by this
+// kernel, so the scalar cache cannot go stale.
+__device__ __forceinline__ const ConstU32* as_const(const uint32_t* p) {
+    return reinterpret_cast<const ConstU32*>(reinterpret_cast<uintptr_t>(p));
+}
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v8u __attribute__((ext_vector_type(8)));
+typedef uint32_t v16u __attribute__((ext_vector_type(16)));
+// s_buffer_load_dwordx8: clang has no builtin for it; the LLVM intrinsic is bound by name
+extern "C" __device__ v8u __xsi_s_buffer_load_v8(v4u rsrc, uint32_t byte_offset, uint32_t cache_policy)
+    __asm("llvm.amdgcn.s.buffer.load.v8i32");
+extern "C" __device__ v16u __xsi_s_buffer_load_v16(v4u rsrc, uint32_t byte_offset, uint32_t cache_policy)
+    __asm("llvm.amdgcn.s.buffer.load.v16i32");
+template <int G>
+__device__ __forceinline__ void sbuf_load_chunks(v4u rsrc, uint32_t chunk, uint64_t (&out)[G]) {
+    static_assert(G == 4 || G == 8, "s_buffer_load_dwordx8 / x16");
+    if constexpr (G == 4) {
+        const v8u v = __xsi_s_buffer_load_v8(rsrc, chunk * 8u, 0u);
+#pragma unroll
+        for (int e = 0; e < G; ++e) out[e] = ((uint64_t)v[2 * e + 1] << 32) | v[2 * e];
+    } else {
+        const v16u v = __xsi_s_buffer_load_v16(rsrc, chunk * 8u, 0u);
+#pragma unroll
+        for (int e = 0; e < G; ++e) out[e] = ((uint64_t)v[2 * e + 1] << 32) | v[2 * e];
+    }
+}
+
+template <int E, int RG>
+__global__ void __launch_bounds__(1024) k_chain_rank_enc(const EncBlock* __restrict__ eblocks, RankEncArgs A) {
+    constexpr uint32_t T = 1024, W = 16;
+    constexpr uint32_t NA = W * E * 64u;  // haplotype capacity
+    constexpr uint32_t CW = NA / 32u;     // words of a row over NA positions (= 2 per active thread)
+    constexpr int G = RG;                 // chunks per group: their gathers are all in flight together
+    static_assert(E % G == 0 && E >= 4 && E <= 64, "E in steps of the gather group");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [0, 8 CW)          rank-select table of the current line: CW pairs {32 row bits, ones before them}
+    // [16384, +4 CW)     row under construction (next line), zero between lines
+    // [16384 + 4 CW, ..) per-wave ones of the row
+    // Both arrays start on a power of two above their size, so "index bits | base" forms an address.
+    constexpr uint32_t YOFF = 16384u;
+    static_assert(8u * CW <= YOFF, "table of at most 2048 pairs");
+    uint2* table = reinterpret_cast<uint2*>(smem);
+    uint32_t* ybits = reinterpret_cast<uint32_t*>(smem + YOFF);
+    uint32_t* wtot = ybits + CW;
+    const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    uint32_t y_lds = tab_lds + YOFF;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(y_lds) : "s"(y_lds));  // per-lane: v_and_or_b32 takes one scalar/literal
+    const uint32_t N = A.N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const EncBlock& B = eblocks[blockIdx.x];
+    if (B.has_haploid) return;  // k_chain_lds takes the blocks with fully haploid lines
+    const uint32_t wah_first = B.wah_first, n_wah = B.n_wah;
+    if (n_wah == 0) return;
+
+    const uint32_t c0 = w * E;  // my first chunk
+    uint32_t r[E];
+    static_for<0, E>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        const uint32_t h = (c0 + (uint32_t)e) * 64u + lane;
+        r[e] = h < N ? h : 0u;
+    });
+    for (uint32_t i = tid; i < CW; i += T) ybits[i] = 0;
+
+    const ConstU32* lines = as_const(A.wah_lines) + wah_first;
+    const uint32_t row_bytes = ((N + 63u) / 64u) * 8u;  // bytes of an input row that hold haplotypes
+    // Key bits of G consecutive chunks of a line: one s_buffer_load_dwordx8 / x16 through a buffer descriptor
+    // whose range is the row, so chunks past the end of the row read as zero (hardware range check) and
+    // every wave runs the same straight-line code.
+    auto row_rsrc = [&](uint32_t line) -> v4u {
+        const uint64_t base = reinterpret_cast<uint64_t>(A.src + (size_t)line * A.src_stride_w);
+        v4u d;
+        d[0] = (uint32_t)base;
+        d[1] = (uint32_t)(base >> 32) & 0xFFFFu;  // stride 0: raw buffer, offsets and range in bytes
+        d[2] = row_bytes;
+        d[3] = 0x00020000u;                       // 32-bit data format (the descriptor word CDNA raw buffers use)
+        return d;
+    };
+    auto xgroup = [&](v4u rsrc, uint32_t cb, uint64_t (&out)[G]) { sbuf_load_chunks<G>(rsrc, cb, out); };
+    // deposit my bit of a line into its row at my current rank (ones only)
+    auto deposit = [&](uint64_t xm, uint32_t rr) {
+        if (xm) {
+            if (__builtin_amdgcn_inverse_ballot_w64(xm)) {
+                LdsU32* p = reinterpret_cast<LdsU32*>((uintptr_t)(((rr >> 3) & 0x1FFCu) | y_lds));
+                __hip_atomic_fetch_or(p, 1u << (rr & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
+    // phases A + B for the row in ybits -> table, y row `rank` to HBM; returns the row's zeros
+    auto finish_row = [&](uint32_t rank) -> uint32_t {
+        lds_barrier();  // every deposit has landed
+        uint32_t w0 = 0, w1 = 0;
+        const bool act = tid < CW / 2u;
+        if (act) {
+            const uint2 v = *reinterpret_cast<const uint2*>(ybits + 2u * tid);
+            w0 = v.x;
+            w1 = v.y;
+        }
+        const uint32_t c = (uint32_t)__popc(w0) + (uint32_t)__popc(w1);
+        const uint32_t inc = wave_scan_incl_dpp(c);
+        if (lane == 63u) wtot[w] = inc;
+        if (tid < A.dst_stride_w / 2u)
+            reinterpret_cast<uint2*>(A.dst + (size_t)rank * A.dst_stride_w)[tid] = make_uint2(w0, w1);
+        lds_barrier();
+        uint32_t sc = row16_scan_incl(lane < W ? wtot[lane] : 0u);
+        const uint32_t ones = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
+        const uint32_t base = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
+        if (act) {
+            const uint32_t pre0 = base + inc - c;
+            *reinterpret_cast<uint4*>(table + 2u * tid) = make_uint4(w0, pre0, w1, pre0 + (uint32_t)__popc(w0));
+            *reinterpret_cast<uint2*>(ybits + 2u * tid) = make_uint2(0u, 0u);
+        }
+        lds_barrier();
+        return N - ones;
+    };
+
+    // line 0: ranks are the identity, so its row is the input row itself
+    {
+        const v4u rs0 = row_rsrc(lines[0]);
+        lds_barrier();  // row cleared
+        static_for<0, E / G>([&](auto gc) {
+            constexpr int g0 = decltype(gc)::value * G;
+            uint64_t x0[G];
+            xgroup(rs0, c0 + (uint32_t)g0, x0);
+            static_for<0, G>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                deposit(x0[e], r[g0 + e]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    uint32_t Z = finish_row(wah_first);
+
+    for (uint32_t j = 0; j < n_wah; ++j) {
+        const bool more = j + 1u < n_wah;
+        // after the last line the deposits (of the same line again) go into a row nobody reads
+        const v4u rsc = row_rsrc(lines[j]);
+        const v4u rsn = row_rsrc(lines[more ? j + 1u : j]);
+        static_for<0, E / G>([&](auto gc) {
+            constexpr int g0 = decltype(gc)::value * G;
+            uint64_t xc[G], xn[G];
+            u32x2 pr[G];
+            xgroup(rsc, c0 + (uint32_t)g0, xc);
+            xgroup(rsn, c0 + (uint32_t)g0, xn);
+            static_for<0, G>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                pr[e] = *reinterpret_cast<const LdsU2*>((uintptr_t)(((r[g0 + e] >> 2) & 0x3FF8u) | tab_lds));
+            });
+            static_for<0, G>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                const uint32_t rr = r[g0 + e];
+                // ones before my position: table prefix + set bits below me in my word; v_bfe_u32 reads
+                // only the low 5 bits of its width operand, so rr itself serves as "rr & 31"
+                const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
+                const uint32_t rn = __builtin_amdgcn_inverse_ballot_w64(xc[e]) ? Z + ob : rr - ob;
+                r[g0 + e] = rn;
+                deposit(xn[e], rn);
+            });
+            // keep the groups apart: hoisting every group's scalar loads to the top of the line would
+            // need 4 E SGPRs and spill them lane by lane
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (more) Z = finish_row(wah_first + j + 1u);
+    }
+}
+
+static const int k_rankenc_E[] = {8, 16, 24, 32, 40, 48, 56, 64};
+
+static int rankenc_e_for(uint32_t N) {
+    for (int e : k_rankenc_E)
+        if ((uint32_t)e * 1024u >= N) return e;
+    return 0;
+}
+
+bool chain_rank_enc_supported(uint32_t N) { return N >= 2u && N <= 65536u; }
+
+hipError_t launch_rank_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L) {
+    if (!n_blocks) return hipSuccess;
+    RankEncArgs A{};
+    A.wah_lines = L.wah_lines;
+    A.src = L.planes;
+    A.src_stride_w = L.plane_stride_w;
+    A.dst = reinterpret_cast<uint32_t*>(L.yrows);
+    A.dst_stride_w = L.y_stride64 * 2u;
+    A.N = L.N;
+    const int e = rankenc_e_for(L.N);
+    if (!e) return hipErrorInvalidValue;
+    const uint32_t CW = 16u * (uint32_t)e * 64u / 32u;
+    const uint32_t lds = 16384u + 4u * CW + 64u;
+    static const int rg = [] {
+        const char* e = getenv("XSI_RANKENC_G");
+        return (e && atoi(e) == 4) ? 4 : 8;
+    }();
+#define XSI_RE_CASE(EE)                                                                               \
+    if (e == EE) {                                                                                    \
+        auto kern = rg == 4 ? &k_chain_rank_enc<EE, 4> : &k_chain_rank_enc<EE, 8>;                    \
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                     \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        if (err != hipSuccess) return err;                                                            \
+        kern<<<dim3(n_blocks), dim3(1024), lds, s>>>(blocks, A);                                      \
+        return hipGetLastError();                                                                     \
+    }
+    XSI_RE_CASE(8)
+    XSI_RE_CASE(16)
+    XSI_RE_CASE(24)
+    XSI_RE_CASE(32)
+    XSI_RE_CASE(40)
+    XSI_RE_CASE(48)
+    XSI_RE_CASE(56)
+    XSI_RE_CASE(64)
+#undef XSI_RE_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace xsi
