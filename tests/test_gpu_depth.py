@@ -1,0 +1,221 @@
+"""GPU parity tests at depth: one full-depth block per chain kernel against the oracle (the short
+blocks of test_gpu_packed.py never reach a deep PBWT order, long look-ahead histories or the later
+batches of a block-batched call), the u32 accessor under random access with an evicting cache, and a
+version-4 file image (u32 index)."""
+import ctypes
+import struct
+
+import numpy as np
+import pytest
+
+from xsqueezeit_amd import binding, synth
+from test_oracle import _random_lines
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _torch_first():
+    """torch must initialise HIP before libxsi_hip.so is loaded: the wheel carries its own HIP runtime,
+    and with the system one mapped first no device is found."""
+    import gpu_util as G
+    G.ctx()
+
+
+def _device_synth(n_haps, n_lines, seed):
+    """Synthetic matrix made on the device (the numpy mirror is checked elsewhere and is slow at this
+    size); returns (bits01 [n_lines, n_haps] uint8, packed rows, stride)."""
+    import gpu_util as G
+    stride = synth.row_stride_bytes(n_haps)
+    d = G.dev_empty(n_lines * stride)
+    binding.check(binding.lib().xsi_hip_synth_packed(G.ctx().handle, seed, 0, n_lines, n_haps, d.data_ptr(), stride))
+    G.torch_mod().cuda.synchronize()
+    packed = d.cpu().numpy().reshape(n_lines, stride)
+    return synth.unpack_rows(packed, n_haps), packed, stride
+
+
+@pytest.mark.parametrize("n_haps,n_lines,thr,kernels", [
+    (64976, 8192, 64, ("k_chain_rank_enc", "k_chain_decode_rank_big")),   # BASELINE configs[2] shape, one whole block
+    (200000, 2048, 200, ("k_chain_stream", "k_chain_decode_rank_big")),   # configs[4] haplotype count
+    (500000, 2048, 500, ("k_chain_stream", "k_chain_decode_rank_big")),   # configs[3] haplotype count
+])
+def test_full_depth_block_against_oracle(n_haps, n_lines, thr, kernels):
+    import gpu_util as G
+    L = binding.lib()
+    assert L.xsi_hip_chain_kernel(n_haps, 1, 0).decode() == kernels[0]
+    assert L.xsi_hip_chain_kernel(n_haps, 1, 1).decode() == kernels[1]
+    bits, packed, stride = _device_synth(n_haps, n_lines, 43)
+    p = G.params(n_haps // 2, n_lines, thr)
+    ref = G.oracle_file_from_bits(bits, p)
+    region, offsets, res = G.encode_packed(packed, n_haps, p)
+    assert res.n_wah_lines > n_lines // 3  # a deep chain, not a block of sparse lines
+    names = ["S%d" % i for i in range(n_haps // 2)]
+    got = G.assemble_file(region, offsets, p, n_lines, n_lines, names)
+    io = struct.unpack_from("<Q", ref, 72)[0]
+    if got[:io] != ref[:io]:
+        first = next(i for i in range(min(len(got), len(ref))) if got[i] != ref[i])
+        raise AssertionError("blocks region differs at file offset %d (sizes %d vs %d)" % (first, len(got), len(ref)))
+    assert got == ref
+    out, counts = G.decode_packed(got, n_haps, stride)
+    assert np.array_equal(out, packed)
+    assert np.array_equal(counts, bits.sum(1, dtype=np.int64).astype(np.int32))
+
+
+@pytest.mark.parametrize("n_haps,n_blocks,block_len,thr,force", [
+    (64976, 3, 700, 64, dict(XSI_PAIR_MIN_N_DEC="2")),   # packed-pair decode chain at depth (it needs >= 192 blocks by default)
+    (24576, 3, 900, 24, dict()),                          # rank-tracking encode below 64 chunks per wave
+    (12300, 2, 1200, 12, dict(XSI_RANKENC_MIN_N="2")),
+])
+def test_chain_kernel_variants_at_depth(n_haps, n_blocks, block_len, thr, force, monkeypatch):
+    """The kernels the size rules pick for other block counts, forced through the environment (the
+    library reads these two variables on every call)."""
+    import gpu_util as G
+    L = binding.lib()
+    for k, v in force.items():
+        monkeypatch.setenv(k, v)
+    if "XSI_PAIR_MIN_N_DEC" in force:
+        assert L.xsi_hip_chain_kernel(n_haps, n_blocks, 1).decode() == "k_chain_pair_dec"
+    assert L.xsi_hip_chain_kernel(n_haps, n_blocks, 0).decode() == "k_chain_rank_enc"
+    n_lines = n_blocks * block_len
+    bits, packed, stride = _device_synth(n_haps, n_lines, 7)
+    p = G.params(n_haps // 2, block_len, thr)
+    ref = G.oracle_file_from_bits(bits, p)
+    region, offsets, res = G.encode_packed(packed, n_haps, p)
+    got = G.assemble_file(region, offsets, p, n_lines, n_lines, ["S%d" % i for i in range(n_haps // 2)])
+    assert got == ref
+    out, _ = G.decode_packed(got, n_haps, stride)
+    assert np.array_equal(out, packed)
+
+
+def test_block_batched_calls_equal_single_call():
+    """A workspace budget smaller than the job: encode and decode run as several batches of whole
+    blocks inside one call and must produce the bytes / rows of the unbatched call."""
+    import gpu_util as G
+    L = binding.lib()
+    n_haps, block_len, n_blocks = 5008, 256, 11
+    n_lines = n_blocks * block_len - 37  # ragged last block
+    bits, packed, stride = _device_synth(n_haps, n_lines, 11)
+    p = G.params(n_haps // 2, block_len, 5)
+    region1, offs1, res1 = G.encode_packed(packed, n_haps, p)
+    file1 = G.assemble_file(region1, offs1, p, n_lines, n_lines, ["S%d" % i for i in range(n_haps // 2)])
+    h = G.ctx().handle
+    try:
+        # room for about three blocks of per-line workspace: 4 batches of 3, 3, 3, 2 blocks
+        per_block = (8 * ((n_haps + 63) // 64) + 2 * ((n_haps + 14) // 15 + 4) + 40) * block_len
+        binding.check(L.xsi_hip_ctx_set_workspace_budget(h, 3 * per_block + 1000))
+        region2, offs2, res2 = G.encode_packed(packed, n_haps, p)
+        assert res2.n_blocks == n_blocks and res2.n_wah_lines == res1.n_wah_lines
+        assert region2 == region1
+        assert np.array_equal(offs2, offs1)
+        out, counts = G.decode_packed(file1, n_haps, stride)
+        assert np.array_equal(out, packed)
+        assert np.array_equal(counts, bits.sum(1).astype(np.int32))
+        # a budget below one block still makes progress, one block at a time
+        binding.check(L.xsi_hip_ctx_set_workspace_budget(h, 1000))
+        region3, offs3, _ = G.encode_packed(packed, n_haps, p)
+        assert region3 == region1 and np.array_equal(offs3, offs1)
+        out, _ = G.decode_packed(file1, n_haps, stride, first_block=2, n_blocks=5, max_rows=5 * block_len)
+        assert np.array_equal(out, packed[2 * block_len:7 * block_len])
+    finally:
+        binding.check(L.xsi_hip_ctx_set_workspace_budget(h, 0))
+
+
+def test_accessor_u32_random_access_evicting_cache(tmp_path):
+    """BASELINE configs[4] in small: > 131 072 haplotypes (u32 A_T in header and blocks), multi-allelic
+    lines, end-of-vector ("male") samples, missing values and fully haploid lines, random BM positions
+    through the accessor with a cache that holds two blocks, against the oracle's reader."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    rng = np.random.default_rng(20260)
+    n, block_len = 66000, 6
+    lines = []
+    for b in range(5):
+        for i in range(block_len):
+            if b % 2 == 1 and i % 3 == 1:
+                # fully haploid lines only in blocks without multi-allelic lines: the reference writes
+                # KEY_LINE_HAPLOID per BCF line and reads it per binary line
+                al = (rng.random(n) < 0.2).astype(np.int32)
+                lines.append((((al + 1) << 1).astype(np.int32), 2))
+            else:
+                lines.extend(_random_lines(rng, n, 1, multi=(b % 2 == 0 and i % 2 == 0), eov=(i % 2 == 0),
+                                           missing=(i % 5 == 0)))
+    dp = oracle.default_phased_of(lines, n)
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=n // 500, default_phased=dp)
+    assert ref[14] == 4  # aet_bytes
+    path = tmp_path / "u32.xsi"
+    path.write_bytes(ref)
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
+    buf = np.zeros(2 * n, dtype=np.int32)
+    assert L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, lines[0][1], 0) > 0
+    nb, by = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    binding.check(L.xsi_accessor_cache_stats(a, ctypes.byref(nb), ctypes.byref(by), None, None))
+    binding.check(L.xsi_accessor_set_cache_bytes(a, 2 * by.value + 4096))
+    bms = []
+    block = off = 0
+    for i, (_, na) in enumerate(lines):
+        if i and i % block_len == 0:
+            block += 1
+            off = 0
+        bms.append((block << 15) | off)
+        off += na - 1
+    order = [int(x) for x in rng.integers(0, len(lines), 60)]
+    rd = oracle.Reader(ref)
+    expect = {i: rd.fill_genotype_array(lines[i][1], bms[i]) for i in sorted(set(order))}
+    cnt = np.zeros(8, dtype=np.uint64)
+    for k, i in enumerate(order):
+        egt, ecnt = expect[i]
+        r = L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, lines[i][1], bms[i])
+        assert r == len(egt), "line %d: %s" % (i, L.xsi_hip_last_error())
+        assert np.array_equal(buf[:r], egt), "line %d (query %d)" % (i, k)
+        assert np.array_equal(buf[:r], lines[i][0]), "line %d vs source" % i
+        binding.check(L.xsi_accessor_allele_counts(a, cnt.ctypes.data, lines[i][1]))
+        assert np.array_equal(cnt[:lines[i][1]], ecnt)
+    hits, misses = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    binding.check(L.xsi_accessor_cache_stats(a, ctypes.byref(nb), None, ctypes.byref(hits), ctypes.byref(misses)))
+    assert nb.value <= 2 and misses.value > (len(lines) + block_len - 1) // block_len
+    L.xsi_accessor_close(a)
+
+
+def _as_version4(v5):
+    """The same file as a version-4 image: u32 block index (accessor_internals_new.hpp:849-869)."""
+    io, so = struct.unpack_from("<QQ", v5, 72)
+    idx = np.frombuffer(v5, dtype="<u8", count=(so - io) // 8, offset=io)
+    assert int(idx.max()) < 2 ** 32
+    body = bytearray(v5[:io]) + idx.astype("<u4").tobytes()
+    new_so = len(body)
+    body += v5[so:]
+    struct.pack_into("<I", body, 8, 4)
+    struct.pack_into("<Q", body, 80, new_so)
+    return bytes(body)
+
+
+def test_version4_image_decodes(tmp_path):
+    """v4 files carry a u32 index; everything else on this path is the v5 layout."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    n_haps, n_lines, block_len = 1000, 700, 128
+    bits = synth.synth_bits(3, 0, n_lines, n_haps)
+    stride = synth.row_stride_bytes(n_haps)
+    packed = synth.pack_rows(bits, stride)
+    p = G.params(n_haps // 2, block_len, 1)
+    v4 = _as_version4(G.oracle_file_from_bits(bits, p))
+    assert struct.unpack_from("<I", v4, 8)[0] == 4
+    out, counts = G.decode_packed(v4, n_haps, stride, n_blocks=(n_lines + block_len - 1) // block_len, max_rows=n_lines)
+    assert np.array_equal(out, packed)
+    out2, _ = G.decode_packed(v4, n_haps, stride, first_block=3, n_blocks=2, max_rows=2 * block_len)
+    assert np.array_equal(out2, packed[3 * block_len:5 * block_len])
+    # and through the file-level accessor
+    path = tmp_path / "v4.xsi"
+    path.write_bytes(v4)
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
+    gt_all = synth.bits_to_gt(bits, 1)
+    buf = np.zeros(n_haps, dtype=np.int32)
+    for line in (0, 127, 128, 400, 699, 5):
+        bm = ((line // block_len) << 15) | (line % block_len)
+        assert L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, 2, bm) == n_haps
+        assert np.array_equal(buf, gt_all[line])
+    L.xsi_accessor_close(a)

@@ -1301,19 +1301,15 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
 //           long; otherwise the element-major kernels of xsi_rank.hip, which split a block over workgroups.
 // XSI_RANKENC_MIN_N / XSI_PAIR_MIN_N_DEC override the size rule (testing: force a kernel for every N).
 static bool use_rank_encode(uint32_t N, uint32_t n_blocks) {
-    static const int env = [] {
-        const char* e = getenv("XSI_RANKENC_MIN_N");
-        return e ? atoi(e) : -1;
-    }();
+    const char* ev = getenv("XSI_RANKENC_MIN_N");  // read per call: the tests switch kernels inside one process
+    const int env = ev ? atoi(ev) : -1;
     if (!chain_rank_enc_supported(N)) return false;
     if (env >= 0) return N >= (uint32_t)env;
     return N >= 20480u || (N >= 12288u && n_blocks >= 192u);
 }
 static bool use_pair_decode(uint32_t N, uint32_t n_blocks) {
-    static const int env = [] {
-        const char* e = getenv("XSI_PAIR_MIN_N_DEC");
-        return e ? atoi(e) : -1;
-    }();
+    const char* ev = getenv("XSI_PAIR_MIN_N_DEC");
+    const int env = ev ? atoi(ev) : -1;
     if (!chain_pair_supported(N)) return false;
     if (env >= 0) return N >= (uint32_t)env;
     return N >= 40960u && n_blocks >= 192u;
