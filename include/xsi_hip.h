@@ -202,6 +202,23 @@ int xsi_hip_debug_chain_encode(xsi_hip_ctx* ctx, const xsi_encode_params* p, con
                                uint32_t row_stride_bytes, void* d_yrows, uint32_t y_stride_bytes,
                                uint32_t* d_line_kind, uint64_t* h_n_wah);
 
+/* ---- host-only helpers of the fill loops either side of the block path (no device work) ---- */
+/* MINOR_ALLELE_COUNT_THRESHOLD = (size_t)((double)(n_samples * PLOIDY) * MAF), include/gt_compressor_new.hpp:96-99;
+ * PLOIDY = ploidy of the first record.  This is xsi_encode_params.mac_threshold. */
+uint32_t xsi_mac_threshold(uint32_t n_samples, uint32_t ploidy, double maf);
+/* seek_default_phased (xcf.cpp:811-836) on the first records of the input (the reference passes 3): rows in
+ * htslib encoding, h_ngt[r] values each.  Returns 0/1 = xsi_encode_params.default_phased, <0 on error. */
+int32_t xsi_default_phased(const int32_t* const* h_gt_rows, const uint32_t* h_ngt, uint32_t n_rows, uint32_t n_samples);
+/* The BM value of every record of the variant-only BCF (replace_samples_by_pos_in_binary_matrix,
+ * xcf.cpp:641-714, BM at :685-703): block << 15 | offset, the block advancing every block_len BCF lines and
+ * the offset counting binary lines (n_allele - 1 per record) inside the block.  Call xsi_bm_next once per
+ * record, in file order; it returns the record's BM (>= 0 as the reference's int32) or XSI_ERR_FORMAT when
+ * the offset no longer fits 15 bits ("Offset cannot be represented on 15 bits !", :692-695).
+ * The inverse, Accessor::position_from_bm_entry (accessor.hpp:37-46), is the value itself. */
+typedef struct xsi_bm_state { uint64_t line, block, offset; } xsi_bm_state;
+void xsi_bm_init(xsi_bm_state* st);
+int64_t xsi_bm_next(xsi_bm_state* st, uint32_t block_len, uint32_t n_allele);
+
 /* ---- host-side writer / accessor (file level), mirroring XsiFactoryInterface and Accessor ---- */
 typedef struct xsi_writer xsi_writer;
 typedef struct xsi_accessor xsi_accessor;
@@ -238,6 +255,15 @@ int xsi_accessor_set_cache_bytes(xsi_accessor* a, uint64_t bytes);
 /* Any of the outputs may be NULL. */
 int xsi_accessor_cache_stats(const xsi_accessor* a, uint64_t* blocks, uint64_t* bytes, uint64_t* hits,
                              uint64_t* misses);
+/* Sample selection on decode (NewDecompressor::fill_selected_genotypes, include/gt_decompressor_new.hpp:209-238):
+ * after set_sample_subset(idx, n) (indices into the file's sample list, any order, repeats allowed; n = 0
+ * clears), fill_selected_genotypes composes the line on the device, gathers the listed samples there and
+ * copies only those values to h_gt (1 or 2 per sample by the line's ploidy).  Returns AN = n * line ploidy;
+ * h_ac (optional, n_alleles - 1 ints) receives the selection's count of every ALT allele, the AC the
+ * reference rewrites (:251-254). */
+int xsi_accessor_set_sample_subset(xsi_accessor* a, const uint32_t* sample_idx, uint32_t n);
+int64_t xsi_accessor_fill_selected_genotypes(xsi_accessor* a, int32_t* h_gt, uint64_t gt_size, uint32_t n_alleles,
+                                             uint64_t position, int32_t* h_ac);
 /* Accessor::fill_allele_counts(n_alleles, position) (accessor.hpp:52-54): counts only, no genotype
  * expansion; like the reference, counts[0] = line values - sum of ALT counts (missing / end-of-vector
  * are not subtracted, accessor_internals_new.hpp:437). */

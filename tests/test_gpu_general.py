@@ -425,3 +425,58 @@ def test_phenotype_dot_products_on_decoded_planes():
     o2 = torch.zeros((400, 1), dtype=torch.float64, device="cuda")
     rc = L.xsi_hip_decode_dot(G.ctx().handle, d_file2.data_ptr(), len(ref2), 0, 2, y2.data_ptr(), 1, o2.data_ptr(), 400, None)
     assert rc == -5  # XSI_ERR_UNSUPPORTED
+
+
+def test_accessor_sample_subset(tmp_path):
+    """fill_selected_genotypes == the reference's fill_selected_genotypes (gt_decompressor_new.hpp:209-238):
+    the listed samples' values in list order, 1 or 2 per sample by the line's ploidy, AN and the AC of
+    every ALT allele over the selection."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    rng = np.random.default_rng(77)
+    n, block_len = 333, 40
+    lines = []
+    for b in range(3):
+        for i in range(block_len):
+            if b == 1 and i % 4 == 2:  # fully haploid lines, kept apart from the multi-allelic ones (SURVEY 9.6.2)
+                al = (rng.random(n) < 0.3).astype(np.int32)
+                lines.append((((al + 1) << 1).astype(np.int32), 2))
+            else:
+                lines.extend(_random_lines(rng, n, 1, multi=(b != 1), missing=True, eov=(i % 2 == 0), phase=True))
+    dp = oracle.default_phased_of(lines, n)
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=1, default_phased=dp)
+    path = tmp_path / "sub.xsi"
+    path.write_bytes(ref)
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
+    buf = np.zeros(2 * n, dtype=np.int32)
+    ac = np.zeros(8, dtype=np.int32)
+    assert L.xsi_accessor_fill_selected_genotypes(a, buf.ctypes.data, buf.size, 2, 0, None) == binding.XSI_ERR_ARG
+    bad = np.array([n], dtype=np.uint32)
+    assert L.xsi_accessor_set_sample_subset(a, bad.ctypes.data, 1) == binding.XSI_ERR_ARG
+    bms = []
+    block = off = 0
+    for i, (_, na) in enumerate(lines):
+        if i and i % block_len == 0:
+            block, off = block + 1, 0
+        bms.append((block << 15) | off)
+        off += na - 1
+    for sel in (np.array([5, 0, 332, 5, 17], dtype=np.uint32), rng.permutation(n)[:120].astype(np.uint32)):
+        binding.check(L.xsi_accessor_set_sample_subset(a, sel.ctypes.data, len(sel)))
+        for i in [int(x) for x in rng.integers(0, len(lines), 40)]:
+            gt, na = lines[i]
+            ploidy = len(gt) // n
+            exp = gt.reshape(n, ploidy)[sel].reshape(-1)
+            an = L.xsi_accessor_fill_selected_genotypes(a, buf.ctypes.data, buf.size, na, bms[i], ac.ctypes.data)
+            assert an == len(sel) * ploidy, L.xsi_hip_last_error()
+            assert np.array_equal(buf[:an], exp), "line %d" % i
+            alleles = (exp >> 1) - 1
+            for k in range(1, na):
+                assert ac[k - 1] == int(np.sum(alleles == k)), "AC of allele %d on line %d" % (k, i)
+        # the unselected path still works next to it
+        full = L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, lines[3][1], bms[3])
+        assert full == len(lines[3][0]) and np.array_equal(buf[:full], lines[3][0])
+    binding.check(L.xsi_accessor_set_sample_subset(a, None, 0))
+    assert L.xsi_accessor_fill_selected_genotypes(a, buf.ctypes.data, buf.size, 2, 0, None) == binding.XSI_ERR_ARG
+    L.xsi_accessor_close(a)

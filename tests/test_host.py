@@ -57,6 +57,55 @@ def test_make_header_matches_oracle():
     assert bytes(h) == ref[:256]
 
 
+def test_fill_loop_helpers_match_the_reference_rules(golden_dir):
+    """The parameter derivation of the compressor's fill loop, in the library instead of test code:
+    MAC threshold (gt_compressor_new.hpp:96-99), default phase (xcf.cpp:811-836) and the BM values of
+    the variant BCF (xcf.cpp:685-703), against the oracle's restatement and the micro fixtures."""
+    from oracle import oracle
+    from xsqueezeit_amd import vcf_lite
+    from test_oracle import _random_lines, ANCHORS
+    L = binding.lib()
+    for n, pl, maf in ((2504, 2, 0.001), (10, 2, 0.002), (64976 // 2, 2, 0.001), (250000, 2, 0.001), (7, 1, 0.3), (5, 2, 0.0)):
+        assert L.xsi_mac_threshold(n, pl, maf) == int(float(n * pl) * maf)
+    rng = np.random.default_rng(3)
+    cases = []
+    for kw in (dict(), dict(phase=True), dict(missing=True, eov=True, phase=True, multi=True)):
+        cases.append((_random_lines(rng, 37, 9, **kw), 37))
+    unphased = [((np.full(20, 2, np.int32)), 2)] * 3
+    cases.append((unphased, 10))
+    hap = [(np.full(10, 2, np.int32), 2)] + unphased
+    cases.append((hap, 10))
+    for name in sorted(ANCHORS):
+        samples, recs = vcf_lite.read_vcf(os.path.join(golden_dir, name + ".vcf"))
+        cases.append(([(r["gt"], r["n_allele"]) for r in recs], len(samples)))
+    for lines, n in cases:
+        rows = [np.ascontiguousarray(gt, dtype=np.int32) for gt, _ in lines[:3]]
+        ptrs = (ctypes.c_void_p * len(rows))(*[r.ctypes.data for r in rows])
+        ngt = (ctypes.c_uint32 * len(rows))(*[r.size for r in rows])
+        assert L.xsi_default_phased(ptrs, ngt, len(rows), n) == oracle.default_phased_of(lines, n)
+    # BM: block advances every block_len BCF lines, the offset counts binary lines inside the block
+    st = binding.BmState()
+    L.xsi_bm_init(ctypes.byref(st))
+    nal = [2, 3, 2, 2, 4, 2, 2, 2, 3, 2, 2]
+    block = off = 0
+    for i, na in enumerate(nal):
+        if i and i % 4 == 0:
+            block, off = block + 1, 0
+        assert L.xsi_bm_next(ctypes.byref(st), 4, na) == (block << 15) | off
+        off += na - 1
+    # 32768 binary lines in one block cannot be addressed: the reference throws (xcf.cpp:692-695)
+    L.xsi_bm_init(ctypes.byref(st))
+    for i in range(8192):
+        assert L.xsi_bm_next(ctypes.byref(st), 8192, 5) == 4 * i
+    L.xsi_bm_init(ctypes.byref(st))
+    for i in range(8191):
+        assert L.xsi_bm_next(ctypes.byref(st), 8192, 6) == 5 * i if 5 * i < 32768 else True
+        if 5 * (i + 1) >= 32768:
+            break
+    assert L.xsi_bm_next(ctypes.byref(st), 8192, 6) == binding.XSI_ERR_FORMAT
+    assert b"cannot be represented" in L.xsi_hip_last_error()
+
+
 def test_encode_bound_covers_oracle_output():
     from oracle import oracle
     for n_haps, n_lines, bl, thr, seed in ((200, 300, 64, 0, 1), (5008, 600, 256, 5, 2), (5008, 300, 64, 2000, 3)):

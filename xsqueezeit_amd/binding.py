@@ -50,8 +50,14 @@ SYMBOLS = [
     "xsi_accessor_get_genotypes", "xsi_accessor_allele_counts", "xsi_accessor_hap_samples",
     "xsi_accessor_num_samples", "xsi_accessor_sample_name", "xsi_accessor_close",
     "xsi_accessor_set_cache_bytes", "xsi_accessor_cache_stats", "xsi_file_num_samples", "xsi_hip_decode_dot",
-    "xsi_hip_ctx_set_workspace_budget", "xsi_hip_chain_kernel",
+    "xsi_hip_ctx_set_workspace_budget", "xsi_hip_chain_kernel", "xsi_mac_threshold", "xsi_default_phased",
+    "xsi_bm_init", "xsi_bm_next", "xsi_accessor_set_sample_subset", "xsi_accessor_fill_selected_genotypes",
 ]
+
+
+class BmState(ctypes.Structure):
+    _fields_ = [("line", ctypes.c_uint64), ("block", ctypes.c_uint64), ("offset", ctypes.c_uint64)]
+
 
 _LIB = None
 
@@ -64,6 +70,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # The torch wheel carries its own HIP runtime.  With torch in the process (it provides the device
+    # buffers and streams of this harness) that runtime has to be mapped before libxsi_hip.so pulls in the
+    # system one, or no device is found.  A C / C++ caller has no torch and nothing to order.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     c = ctypes
     vp, u64, u32, i32 = c.c_void_p, c.c_uint64, c.c_uint32, c.c_int32
@@ -87,6 +100,18 @@ def lib():
     L.xsi_hip_ctx_set_workspace_budget.argtypes = [vp, u64]
     L.xsi_hip_chain_kernel.restype = c.c_char_p
     L.xsi_hip_chain_kernel.argtypes = [u32, u64, c.c_int]
+    L.xsi_mac_threshold.restype = u32
+    L.xsi_mac_threshold.argtypes = [u32, u32, c.c_double]
+    L.xsi_default_phased.restype = i32
+    L.xsi_default_phased.argtypes = [c.POINTER(vp), c.POINTER(u32), u32, u32]
+    L.xsi_bm_init.restype = None
+    L.xsi_bm_init.argtypes = [c.POINTER(BmState)]
+    L.xsi_bm_next.restype = c.c_int64
+    L.xsi_bm_next.argtypes = [c.POINTER(BmState), u32, u32]
+    L.xsi_accessor_set_sample_subset.restype = c.c_int
+    L.xsi_accessor_set_sample_subset.argtypes = [vp, vp, u32]
+    L.xsi_accessor_fill_selected_genotypes.restype = c.c_int64
+    L.xsi_accessor_fill_selected_genotypes.argtypes = [vp, vp, u64, u32, u64, vp]
     L.xsi_hip_encode_bound.restype = u64
     L.xsi_hip_encode_bound.argtypes = [c.POINTER(EncodeParams), u64, u64]
     L.xsi_hip_encode_gt_bound.restype = u64

@@ -807,6 +807,43 @@ int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D,
     return XSI_OK;
 }
 
+// Sample subsetting of composed lines (NewDecompressor::fill_selected_genotypes,
+// gt_decompressor_new.hpp:209-238): out row r = the listed samples' values of composed row r, in list
+// order, 1 or 2 values per sample by the line's ploidy (line_ngt / n_samples); ac[r][k-1] = selected values
+// whose allele is k (the AC the reference recomputes for bcftools-style "-s").  One workgroup per line.
+__global__ void __launch_bounds__(256) k_select_samples(const int32_t* __restrict__ rows, uint64_t row_stride,
+                                                        const uint32_t* __restrict__ line_ngt, uint32_t n_samples,
+                                                        const uint32_t* __restrict__ sel, uint32_t n_sel,
+                                                        int32_t* __restrict__ out, uint64_t out_stride,
+                                                        uint32_t* __restrict__ ac, uint32_t n_alt) {
+    const uint32_t r = blockIdx.x;
+    const uint32_t ploidy = line_ngt[r] / n_samples;  // 1 or 2
+    const int32_t* in = rows + (size_t)r * row_stride;
+    int32_t* o = out + (size_t)r * out_stride;
+    __shared__ uint32_t s_ac[32];
+    if (threadIdx.x < 32u) s_ac[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_sel * ploidy; i += blockDim.x) {
+        const uint32_t smp = sel[i / ploidy], k = i - (i / ploidy) * ploidy;
+        const int32_t v = in[(size_t)smp * ploidy + k];
+        o[i] = v;
+        const int32_t allele = (v >> 1) - 1;  // bcf_gt_allele
+        if (allele >= 1 && (uint32_t)allele <= n_alt && n_alt <= 32u) atomicAdd(&s_ac[allele - 1], 1u);
+    }
+    __syncthreads();
+    if (ac && threadIdx.x < n_alt && n_alt <= 32u) ac[(size_t)r * n_alt + threadIdx.x] = s_ac[threadIdx.x];
+}
+
+int select_samples(xsi_hip_ctx* ctx, const int32_t* d_rows, uint64_t row_stride, const uint32_t* d_line_ngt,
+                   uint32_t n_lines, uint32_t n_samples, const uint32_t* d_sel, uint32_t n_sel, int32_t* d_out,
+                   uint64_t out_stride, uint32_t* d_ac, uint32_t n_alt) {
+    if (!n_lines) return XSI_OK;
+    k_select_samples<<<dim3(n_lines), dim3(256), 0, ctx->stream>>>(d_rows, row_stride, d_line_ngt, n_samples, d_sel, n_sel,
+                                                                  d_out, out_stride, d_ac, n_alt);
+    HIP_TRY(hipGetLastError());
+    return XSI_OK;
+}
+
 }  // namespace xsi
 
 extern "C" {

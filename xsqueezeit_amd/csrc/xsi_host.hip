@@ -340,6 +340,12 @@ struct xsi_accessor {
     int64_t win_block = -1;
     uint32_t counts_cap = 0;
     std::vector<uint64_t> last_counts;
+    // sample selection (NewDecompressor --samples, gt_decompressor_new.hpp:209-238)
+    uint32_t n_sel = 0;
+    uint32_t* d_sel = nullptr;
+    int32_t* d_sel_row = nullptr;
+    int32_t* h_sel_row = nullptr;  // pinned, 2 * n_sel values
+    uint32_t* h_sel_ac = nullptr;  // pinned, 32 counters (device-written)
 };
 
 // Device image + block number to hand the decoder for file block `block` (set_block_ptr,
@@ -533,6 +539,45 @@ static int accessor_compose(xsi_accessor* a, uint32_t first, uint32_t n, uint32_
 }
 
 extern "C" {
+
+uint32_t xsi_mac_threshold(uint32_t n_samples, uint32_t ploidy, double maf) {
+    // gt_compressor_new.hpp:98-99: N_HAPS = n_samples * PLOIDY; (size_t)((double)N_HAPS * MAF)
+    const double v = (double)((uint64_t)n_samples * ploidy) * maf;
+    return v <= 0.0 ? 0u : (v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v);
+}
+
+int32_t xsi_default_phased(const int32_t* const* h_gt_rows, const uint32_t* h_ngt, uint32_t n_rows, uint32_t n_samples) {
+    // seek_default_phased, xcf.cpp:811-836: over the first records (the reference looks at 3), count the
+    // phase bit of every sample's SECOND allele; a haploid record decides "unphased" at once; ties are phased
+    if (!h_gt_rows || !h_ngt || !n_samples) return set_error(XSI_ERR_ARG, "default_phased: null argument");
+    uint64_t counts[2] = {0, 0};
+    for (uint32_t r = 0; r < n_rows; ++r) {
+        const uint32_t ploidy = h_ngt[r] / n_samples;
+        if (ploidy == 1) return 0;
+        if (!h_gt_rows[r] || ploidy < 1) return set_error(XSI_ERR_ARG, "default_phased: bad row %u", r);
+        for (uint32_t i = 0; i < n_samples; ++i) counts[h_gt_rows[r][(size_t)i * ploidy + 1] & 1]++;  // bcf_gt_is_phased
+    }
+    return counts[0] > counts[1] ? 0 : 1;
+}
+
+void xsi_bm_init(xsi_bm_state* st) {
+    if (st) st->line = st->block = st->offset = 0;
+}
+
+int64_t xsi_bm_next(xsi_bm_state* st, uint32_t block_len, uint32_t n_allele) {
+    // replace_samples_by_pos_in_binary_matrix, xcf.cpp:685-703 (new_version: blocks count BCF lines)
+    if (!st || !block_len) return set_error(XSI_ERR_ARG, "bm_next: null state / zero block length");
+    if (st->line && (st->line % block_len) == 0) {
+        st->block++;
+        st->offset = 0;
+    }
+    if (st->offset >> BM_BLOCK_BITS)
+        return set_error(XSI_ERR_FORMAT, "Offset cannot be represented on %u bits !", BM_BLOCK_BITS);
+    const int64_t bm = (int64_t)(int32_t)((uint32_t)st->block << BM_BLOCK_BITS | (uint32_t)st->offset);
+    if (n_allele) st->offset += n_allele - 1;
+    st->line++;
+    return bm;
+}
 
 int64_t xsi_file_num_samples(const char* path) {
     if (!path) return set_error(XSI_ERR_ARG, "file_num_samples: null path");
@@ -735,6 +780,72 @@ int64_t xsi_accessor_get_genotypes(xsi_accessor* a, uint32_t n_alleles, uint64_t
     return xsi_accessor_fill_genotype_array(a, (int32_t*)*h_gt, ngt, n_alleles, position);
 }
 
+int xsi_accessor_set_sample_subset(xsi_accessor* a, const uint32_t* sample_idx, uint32_t n) {
+    if (!a || (n && !sample_idx)) return set_error(XSI_ERR_ARG, "set_sample_subset: null argument");
+    const uint64_t ns = a->num_samples ? a->num_samples : a->hap_samples / (a->ploidy ? a->ploidy : 1);
+    for (uint32_t i = 0; i < n; ++i)
+        if (sample_idx[i] >= ns) return set_error(XSI_ERR_ARG, "set_sample_subset: sample %u of %llu", sample_idx[i], (unsigned long long)ns);
+    HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    if (a->d_sel) (void)hipFree(a->d_sel);
+    if (a->d_sel_row) (void)hipFree(a->d_sel_row);
+    if (a->h_sel_row) (void)hipHostFree(a->h_sel_row);
+    a->d_sel = nullptr;
+    a->d_sel_row = nullptr;
+    a->h_sel_row = nullptr;
+    a->n_sel = n;
+    if (!n) return XSI_OK;
+    HIP_TRY(hipMalloc((void**)&a->d_sel, 4ull * n));
+    HIP_TRY(hipMalloc((void**)&a->d_sel_row, 8ull * n));
+    HIP_TRY(hipHostMalloc((void**)&a->h_sel_row, 8ull * n, hipHostMallocDefault));
+    if (!a->h_sel_ac) HIP_TRY(hipHostMalloc((void**)&a->h_sel_ac, 4ull * 32, hipHostMallocDefault));
+    HIP_TRY(hipMemcpy(a->d_sel, sample_idx, 4ull * n, hipMemcpyHostToDevice));
+    return XSI_OK;
+}
+
+int64_t xsi_accessor_fill_selected_genotypes(xsi_accessor* a, int32_t* h_gt, uint64_t gt_size, uint32_t n_alleles,
+                                             uint64_t position, int32_t* h_ac) {
+    if (!a || !h_gt) return set_error(XSI_ERR_ARG, "fill_selected_genotypes: null argument");
+    if (!a->n_sel) return set_error(XSI_ERR_ARG, "fill_selected_genotypes: no sample subset set");
+    if (n_alleles < 2 || n_alleles > 33) return set_error(XSI_ERR_ARG, "fill_selected_genotypes: n_alleles %u not in 2..33", n_alleles);
+    const uint64_t block = (position & 0xFFFFFFFFull) >> BM_BLOCK_BITS;
+    const uint32_t offset = (uint32_t)(position & ((1u << BM_BLOCK_BITS) - 1u));
+    if (a->cur_block < 0 || (uint64_t)a->cur_block != block) {
+        int rc = accessor_load_block(a, block);
+        if (rc) return rc;
+    }
+    if (offset + (n_alleles - 1) > a->P.n_bin)
+        return set_error(XSI_ERR_ARG, "position offset %u (+%u alleles) beyond the %u binary lines of block %llu", offset,
+                         n_alleles - 1, a->P.n_bin, (unsigned long long)block);
+    hipStream_t s = a->ctx->stream;
+    // compose the full line on the device (no copy to the host), gather the selected samples there
+    if ((uint64_t)n_alleles > a->counts_cap) {
+        if (a->h_counts) (void)hipHostFree(a->h_counts);
+        a->h_counts = nullptr;
+        a->counts_cap = n_alleles + 64;
+        HIP_TRY(hipHostMalloc((void**)&a->h_counts, 8ull * a->counts_cap, hipHostMallocDefault));
+    }
+    a->h_meta[0] = offset;
+    a->h_meta[a->win_rows] = n_alleles;
+    a->win_n = 0;
+    const uint32_t N = a->P.L.N;
+    int rc = compose_lines(a->ctx, a->P, a->D, a->h_meta, a->h_meta + a->win_rows, 1, a->d_rows, N,
+                           a->h_meta + 2ull * a->win_rows, a->h_counts, n_alleles);
+    if (rc) return rc;
+    rc = select_samples(a->ctx, a->d_rows, N, a->h_meta + 2ull * a->win_rows, 1, a->P.L.n_samples, a->d_sel, a->n_sel,
+                        a->d_sel_row, 2ull * a->n_sel, a->h_sel_ac, n_alleles - 1);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(a->h_sel_row, a->d_sel_row, 8ull * a->n_sel, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t ploidy = a->h_meta[2ull * a->win_rows] / a->P.L.n_samples;
+    const uint64_t an = (uint64_t)a->n_sel * ploidy;
+    if (gt_size < an) return set_error(XSI_ERR_CAPACITY, "gt array holds %llu values, selection has %llu", (unsigned long long)gt_size,
+                                       (unsigned long long)an);
+    memcpy(h_gt, a->h_sel_row, an * sizeof(int32_t));
+    if (h_ac)
+        for (uint32_t k = 0; k + 1 < n_alleles; ++k) h_ac[k] = (int32_t)a->h_sel_ac[k];
+    return (int64_t)an;
+}
+
 int xsi_accessor_fill_allele_counts(xsi_accessor* a, uint32_t n_alleles, uint64_t position) {
     if (!a) return set_error(XSI_ERR_ARG, "fill_allele_counts: null accessor");
     if (n_alleles < 2) return set_error(XSI_ERR_ARG, "fill_allele_counts: n_alleles < 2");
@@ -801,6 +912,10 @@ void xsi_accessor_close(xsi_accessor* a) {
     if (a->h_rows) (void)hipHostFree(a->h_rows);
     if (a->h_counts) (void)hipHostFree(a->h_counts);
     if (a->h_meta) (void)hipHostFree(a->h_meta);
+    if (a->d_sel) (void)hipFree(a->d_sel);
+    if (a->d_sel_row) (void)hipFree(a->d_sel_row);
+    if (a->h_sel_row) (void)hipHostFree(a->h_sel_row);
+    if (a->h_sel_ac) (void)hipHostFree(a->h_sel_ac);
     if (a->ctx) xsi_hip_ctx_destroy(a->ctx);
     delete a;
 }
