@@ -63,25 +63,47 @@ const ZstdApi& zstd_api() {
 
 // ------------------------------------------------------------------------------------------
 // writer
+//
+// XsiFactoryExt::append flushes a block every block_len BCF lines (xsi_factory.hpp:527-539) and
+// encodes one line per call on the CPU.  Here lines are staged in pinned chunks, shipped to one of
+// two device batches on a copy stream, and a batch of up to K whole blocks is encoded by ONE
+// xsi_hip_encode_gt call on a worker thread (so the PBWT chain runs one workgroup per block of the
+// batch, not one workgroup in total) while append() already fills the other batch.  The bytes
+// written are those of block-by-block flushing: blocks are independent.
 // ------------------------------------------------------------------------------------------
+#include <thread>
+
 struct xsi_writer {
     xsi_hip_ctx* ctx = nullptr;
     xsi_encode_params p{};
     FILE* f = nullptr;
     std::vector<std::string> names;
     uint64_t N = 0;
-    // current block
-    int32_t* d_rows = nullptr;   // [block_len][N]
-    int32_t* h_chunk = nullptr;  // pinned staging chunk being filled
-    int32_t* h_chunks[2] = {nullptr, nullptr};  // two chunks: one fills while the other is on its way to HBM
+    // two device batches of up to batch_blocks blocks of int32 rows
+    uint32_t batch_blocks = 1;
+    int32_t* d_rows[2] = {nullptr, nullptr};
+    std::vector<uint32_t> ngt[2], n_allele[2];
+    int cur = 0;                    // batch being filled
+    uint64_t lines_in_batch = 0, lines_on_device = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t batch_copied = nullptr;
+    // pinned staging chunks: one fills while the other is on its way to HBM
+    int32_t* h_chunk = nullptr;
+    int32_t* h_chunks[2] = {nullptr, nullptr};
     hipEvent_t chunk_done[2] = {nullptr, nullptr};
     int cur_chunk = 0;
     uint32_t chunk_rows = 0, chunk_fill = 0;
-    uint32_t lines_in_block = 0, lines_on_device = 0;
-    std::vector<uint32_t> ngt, n_allele;
+    // worker that encodes and writes the batch that is not being filled
+    std::thread worker;
+    bool worker_active = false;
+    int worker_rc = XSI_OK;
+    std::string worker_err;
     uint8_t* d_out = nullptr;
     uint64_t out_cap = 0;
+    uint64_t* d_offs = nullptr;
+    uint64_t offs_cap = 0;
     std::vector<uint8_t> h_out;
+    std::vector<uint64_t> h_offs;
     std::vector<uint64_t> indices;
     uint64_t entry_counter = 0, variant_counter = 0;
     uint32_t max_ploidy_seen = 0;
@@ -90,9 +112,9 @@ struct xsi_writer {
 
 static int writer_ship_chunk(xsi_writer* w) {
     if (!w->chunk_fill) return XSI_OK;
-    HIP_TRY(hipMemcpyAsync(w->d_rows + (size_t)w->lines_on_device * w->N, w->h_chunk,
-                           (size_t)w->chunk_fill * w->N * sizeof(int32_t), hipMemcpyHostToDevice, w->ctx->stream));
-    HIP_TRY(hipEventRecord(w->chunk_done[w->cur_chunk], w->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(w->d_rows[w->cur] + (size_t)w->lines_on_device * w->N, w->h_chunk,
+                           (size_t)w->chunk_fill * w->N * sizeof(int32_t), hipMemcpyHostToDevice, w->copy_stream));
+    HIP_TRY(hipEventRecord(w->chunk_done[w->cur_chunk], w->copy_stream));
     w->lines_on_device += w->chunk_fill;
     w->chunk_fill = 0;
     // keep filling the other chunk while this one is copied; wait only if that one is still in flight
@@ -102,49 +124,110 @@ static int writer_ship_chunk(xsi_writer* w) {
     return XSI_OK;
 }
 
-static int writer_flush_block(xsi_writer* w) {
-    if (!w->lines_in_block) return XSI_OK;
-    int rc = writer_ship_chunk(w);
-    if (rc) return rc;
+// Worker: encode batch `b` (its rows are on the device once batch_copied has fired) and append the
+// blocks to the file.  Runs on its own thread; errors are parked in the writer.
+static int writer_encode_batch(xsi_writer* w, int b, uint64_t n_lines) {
+    HIP_TRY(hipSetDevice(w->ctx->device));
+    HIP_TRY(hipStreamWaitEvent(w->ctx->stream, w->batch_copied, 0));
     uint64_t n_bin = 0;
-    for (uint32_t a : w->n_allele) n_bin += a - 1;
-    const uint64_t need = xsi_hip_encode_gt_bound(&w->p, w->lines_in_block, n_bin);
+    for (uint32_t a : w->n_allele[b]) n_bin += a - 1;
+    const uint64_t n_blocks = (n_lines + w->p.block_len - 1) / w->p.block_len;
+    const uint64_t need = xsi_hip_encode_gt_bound(&w->p, n_lines, n_bin);
     if (need > w->out_cap) {
         if (w->d_out) (void)hipFree(w->d_out);
         w->d_out = nullptr;
         HIP_TRY(hipMalloc((void**)&w->d_out, need));
         w->out_cap = need;
     }
+    if (n_blocks > w->offs_cap) {
+        if (w->d_offs) (void)hipFree(w->d_offs);
+        w->d_offs = nullptr;
+        HIP_TRY(hipMalloc((void**)&w->d_offs, 8ull * n_blocks));
+        w->offs_cap = n_blocks;
+    }
     xsi_encode_result res{};
-    rc = xsi_hip_encode_gt(w->ctx, &w->p, w->d_rows, w->N, w->lines_in_block, w->ngt.data(), w->n_allele.data(), w->d_out,
-                           w->out_cap, nullptr, &res);
+    int rc = xsi_hip_encode_gt(w->ctx, &w->p, w->d_rows[b], w->N, n_lines, w->ngt[b].data(), w->n_allele[b].data(), w->d_out,
+                               w->out_cap, w->d_offs, &res);
     if (rc) return rc;
     w->h_out.resize(res.blocks_bytes);
+    w->h_offs.resize(n_blocks + 1);
     HIP_TRY(hipMemcpy(w->h_out.data(), w->d_out, res.blocks_bytes, hipMemcpyDeviceToHost));
-    w->indices.push_back(w->file_pos);  // xsi_factory.hpp:533
-    if (w->p.zstd_level) {
-        // compress_and_write, interfaces.hpp:291-314: u64 compressed size, u64 original size, frame; pad to 4
-        const ZstdApi& z = zstd_api();
-        const uint64_t usize = res.last_block_bytes;  // the block as streamed, before its pad
-        std::vector<uint8_t> frame((size_t)usize * 2 + 64);
-        const size_t csize = z.compress(frame.data(), frame.size(), w->h_out.data(), (size_t)usize, (int)w->p.zstd_level);
-        if (z.is_error(csize)) return set_error(XSI_ERR_IO, "Failed to compress block: %s", z.error_name ? z.error_name(csize) : "zstd");
-        const uint64_t c64 = csize;
-        if (fwrite(&c64, 8, 1, w->f) != 1 || fwrite(&usize, 8, 1, w->f) != 1 || fwrite(frame.data(), 1, csize, w->f) != csize)
-            return set_error(XSI_ERR_IO, "short write");
-        w->file_pos += 16 + csize;
-        while (w->file_pos % 4) {
-            if (fputc(0, w->f) == EOF) return set_error(XSI_ERR_IO, "short write");
-            w->file_pos++;
-        }
-    } else {
+    HIP_TRY(hipMemcpy(w->h_offs.data(), w->d_offs, 8ull * n_blocks, hipMemcpyDeviceToHost));
+    w->h_offs[n_blocks] = 256 + res.blocks_bytes;
+    if (!w->p.zstd_level) {
+        for (uint64_t k = 0; k < n_blocks; ++k) w->indices.push_back(w->file_pos + (w->h_offs[k] - 256));  // xsi_factory.hpp:533
         if (fwrite(w->h_out.data(), 1, w->h_out.size(), w->f) != w->h_out.size()) return set_error(XSI_ERR_IO, "short write");
         w->file_pos += w->h_out.size();
+        return XSI_OK;
     }
-    w->lines_in_block = w->lines_on_device = 0;
-    w->ngt.clear();
-    w->n_allele.clear();
+    // compress_and_write, interfaces.hpp:291-314: u64 compressed size, u64 original size, frame; pad to 4.
+    // The reference compresses the block as streamed, before its pad; only the last block of a call comes
+    // with that length, so --zstd batches hold one block (the host-side compression is the bound anyway).
+    if (n_blocks != 1) return set_error(XSI_ERR_ARG, "zstd batches hold one block");
+    const ZstdApi& z = zstd_api();
+    const uint64_t usize = res.last_block_bytes;
+    std::vector<uint8_t> frame((size_t)usize * 2 + 64);
+    const size_t csize = z.compress(frame.data(), frame.size(), w->h_out.data(), (size_t)usize, (int)w->p.zstd_level);
+    if (z.is_error(csize)) return set_error(XSI_ERR_IO, "Failed to compress block: %s", z.error_name ? z.error_name(csize) : "zstd");
+    w->indices.push_back(w->file_pos);
+    const uint64_t c64 = csize;
+    if (fwrite(&c64, 8, 1, w->f) != 1 || fwrite(&usize, 8, 1, w->f) != 1 || fwrite(frame.data(), 1, csize, w->f) != csize)
+        return set_error(XSI_ERR_IO, "short write");
+    w->file_pos += 16 + csize;
+    while (w->file_pos % 4) {
+        if (fputc(0, w->f) == EOF) return set_error(XSI_ERR_IO, "short write");
+        w->file_pos++;
+    }
     return XSI_OK;
+}
+
+static int writer_join(xsi_writer* w) {
+    if (w->worker_active) {
+        w->worker.join();
+        w->worker_active = false;
+    }
+    if (w->worker_rc) return set_error(w->worker_rc, "%s", w->worker_err.c_str());
+    return XSI_OK;
+}
+
+// hand the batch being filled to the worker and start filling the other one
+static int writer_flush_batch(xsi_writer* w) {
+    if (!w->lines_in_batch) return writer_join(w);
+    int rc = writer_ship_chunk(w);
+    if (rc) return rc;
+    rc = writer_join(w);  // the previous batch must be done: its device rows and the output buffers are reused
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(w->batch_copied, w->copy_stream));
+    const int b = w->cur;
+    const uint64_t n_lines = w->lines_in_batch;
+    w->worker_active = true;
+    w->worker = std::thread([w, b, n_lines] {
+        const int r = writer_encode_batch(w, b, n_lines);
+        if (r) {
+            w->worker_rc = r;
+            w->worker_err = xsi_hip_last_error();
+        }
+    });
+    w->cur ^= 1;
+    w->lines_in_batch = w->lines_on_device = 0;
+    w->ngt[w->cur].clear();
+    w->n_allele[w->cur].clear();
+    return XSI_OK;
+}
+
+static void writer_free(xsi_writer* w) {
+    if (w->worker_active) w->worker.join();
+    if (w->f) fclose(w->f);
+    for (int i = 0; i < 2; ++i) {
+        if (w->d_rows[i]) (void)hipFree(w->d_rows[i]);
+        if (w->h_chunks[i]) (void)hipHostFree(w->h_chunks[i]);
+        if (w->chunk_done[i]) (void)hipEventDestroy(w->chunk_done[i]);
+    }
+    if (w->d_out) (void)hipFree(w->d_out);
+    if (w->d_offs) (void)hipFree(w->d_offs);
+    if (w->batch_copied) (void)hipEventDestroy(w->batch_copied);
+    if (w->copy_stream) (void)hipStreamDestroy(w->copy_stream);
+    delete w;
 }
 
 extern "C" {
@@ -185,15 +268,28 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
     }
     // provisional header, rewritten by finalize (xsi_factory.hpp:468-511)
     uint8_t zero[256] = {0};
-    fwrite(zero, 1, 256, w->f);
+    if (fwrite(zero, 1, 256, w->f) != 256) {
+        writer_free(w);
+        return set_error(XSI_ERR_IO, "short write");
+    }
     w->file_pos = 256;
     const size_t row_bytes = (size_t)w->N * sizeof(int32_t);
-    hipError_t e = hipMalloc((void**)&w->d_rows, row_bytes * p->block_len);
-    if (e != hipSuccess) {
-        fclose(w->f);
-        delete w;
-        return set_error(XSI_ERR_HIP, "hipMalloc block rows: %s", hipGetErrorString(e));
+    const size_t block_bytes = row_bytes * p->block_len;
+    // blocks per batch: enough to give the chain a workgroup per CU where memory allows (two row
+    // batches + the encoder's planes and workspace, about 4x the rows); XSI_WRITER_BATCH_BLOCKS overrides
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        uint64_t k = free_b / 4 / (block_bytes ? block_bytes : 1) / 2;
+        if (k > 64) k = 64;
+        if (const char* e = getenv("XSI_WRITER_BATCH_BLOCKS")) k = strtoull(e, nullptr, 10);
+        if (k < 1 || p->zstd_level) k = 1;
+        w->batch_blocks = (uint32_t)k;
     }
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&w->d_rows[i], block_bytes * w->batch_blocks);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&w->batch_copied, hipEventDisableTiming);
     size_t chunk_bytes = 64ull << 20;
     w->chunk_rows = (uint32_t)(chunk_bytes / row_bytes);
     if (w->chunk_rows < 1) w->chunk_rows = 1;
@@ -201,18 +297,12 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipHostMalloc((void**)&w->h_chunks[i], row_bytes * w->chunk_rows, hipHostMallocDefault);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&w->chunk_done[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(w->chunk_done[i], w->ctx->stream);  // "free" from the start
+        if (e == hipSuccess) e = hipEventRecord(w->chunk_done[i], w->copy_stream);  // "free" from the start
     }
     w->h_chunk = w->h_chunks[0];
     if (e != hipSuccess) {
-        for (int i = 0; i < 2; ++i) {
-            if (w->h_chunks[i]) (void)hipHostFree(w->h_chunks[i]);
-            if (w->chunk_done[i]) (void)hipEventDestroy(w->chunk_done[i]);
-        }
-        (void)hipFree(w->d_rows);
-        fclose(w->f);
-        delete w;
-        return set_error(XSI_ERR_HIP, "hipHostMalloc staging: %s", hipGetErrorString(e));
+        writer_free(w);
+        return set_error(XSI_ERR_HIP, "writer buffers: %s", hipGetErrorString(e));
     }
     *out = w;
     return XSI_OK;
@@ -223,17 +313,17 @@ int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t
     if (ngt != w->p.n_samples && ngt != 2u * w->p.n_samples)
         return set_error(XSI_ERR_ARG, "PLOIDY ERROR: %u values for %u samples", ngt, w->p.n_samples);
     if (n_allele < 2) return set_error(XSI_ERR_UNSUPPORTED, "lines without an ALT allele are rejected (see xsi_hip_encode_gt)");
-    // check_flush_block, xsi_factory.hpp:527-539
-    if (w->lines_in_block == w->p.block_len) {
-        int rc = writer_flush_block(w);
+    // check_flush_block, xsi_factory.hpp:527-539, K blocks at a time
+    if (w->lines_in_batch == (uint64_t)w->p.block_len * w->batch_blocks) {
+        int rc = writer_flush_batch(w);
         if (rc) return rc;
     }
     int32_t* dst = w->h_chunk + (size_t)w->chunk_fill * w->N;
     memcpy(dst, h_gt, (size_t)ngt * sizeof(int32_t));
     w->chunk_fill++;
-    w->lines_in_block++;
-    w->ngt.push_back(ngt);
-    w->n_allele.push_back(n_allele);
+    w->lines_in_batch++;
+    w->ngt[w->cur].push_back(ngt);
+    w->n_allele[w->cur].push_back(n_allele);
     const uint32_t pl = ngt / w->p.n_samples;
     if (pl > w->max_ploidy_seen) w->max_ploidy_seen = pl;
     w->variant_counter += n_allele - 1;
@@ -244,7 +334,9 @@ int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t
 
 int xsi_writer_finalize(xsi_writer* w, uint32_t max_ploidy) {
     if (!w || !w->f) return set_error(XSI_ERR_ARG, "writer_finalize: null / closed writer");
-    int rc = writer_flush_block(w);
+    int rc = writer_flush_batch(w);
+    if (rc) return rc;
+    rc = writer_join(w);
     if (rc) return rc;
     // xsi_factory.hpp:558-605
     while (w->file_pos % 8) {
@@ -279,14 +371,7 @@ int xsi_writer_finalize(xsi_writer* w, uint32_t max_ploidy) {
 
 void xsi_writer_close(xsi_writer* w) {
     if (!w) return;
-    if (w->f) fclose(w->f);
-    if (w->d_rows) (void)hipFree(w->d_rows);
-    if (w->d_out) (void)hipFree(w->d_out);
-    for (int i = 0; i < 2; ++i) {
-        if (w->h_chunks[i]) (void)hipHostFree(w->h_chunks[i]);
-        if (w->chunk_done[i]) (void)hipEventDestroy(w->chunk_done[i]);
-    }
-    delete w;
+    writer_free(w);
 }
 
 }  // extern "C"
