@@ -85,6 +85,10 @@ def main():
     if distributed:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # --force-dist without a launcher
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:

@@ -166,7 +166,7 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, n_haps, n_lines, bl, thr, q):
+def _rank_main(rank, world, port, n_haps, n_lines, bl, thr, q, path):
     import torch
     import torch.distributed as tdist
     from oracle import oracle
@@ -189,8 +189,19 @@ def _rank_main(rank, world, port, n_haps, n_lines, bl, thr, q):
     n_real = int(offs[-1]) + _block_len(data, 256 + int(offs[-1]))
     region = region[:n_real]
     got = xdist.gather_block_streams(torch.from_numpy(region.copy()), torch.from_numpy(offs.copy()), tdist)
+    # the alternative exchange: sizes only, every rank writes its own byte range of the file
+    my_start, total = xdist.exchange_region_offsets(len(region), tdist)
     if rank == 0:
-        q.put((got[0].numpy().tobytes(), got[1].numpy().tolist()))
+        with open(path, "wb") as f:
+            f.truncate(256 + total)
+    tdist.barrier()
+    xdist.write_own_range(path, region.tobytes(), my_start)
+    tdist.barrier()
+    if rank == 0:
+        with open(path, "rb") as f:
+            f.seek(256)
+            pwritten = f.read()
+        q.put((got[0].numpy().tobytes(), got[1].numpy().tolist(), pwritten))
     tdist.barrier()
     tdist.destroy_process_group()
 
@@ -219,17 +230,19 @@ def _wah_bits(data, off, n):
     return oracle.wah_extract(words, n)[0]
 
 
-def test_two_rank_gather_reproduces_single_process_file():
+def test_two_rank_gather_reproduces_single_process_file(tmp_path):
     import torch.multiprocessing as mp
     from oracle import oracle
     n_haps, n_lines, bl, thr = 200, 1000, 128, 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, n_haps, n_lines, bl, thr, q)) for r in range(2)]
+    path = str(tmp_path / "shared.xsi")
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, n_haps, n_lines, bl, thr, q, path)) for r in range(2)]
     for p in procs:
         p.start()
-    region, offs = q.get(timeout=120)
+    region, offs, pwritten = q.get(timeout=120)
+    assert pwritten == region  # every rank wrote its own range: same bytes as the gathered stream
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

@@ -3,7 +3,9 @@
 Every 8192-line block is independent (fresh PBWT prefix array per block), so contiguous block
 ranges go to ranks with no data-path collective during encode or decode.  The one exchange step
 is the gather of the compressed block streams to the writer rank: sizes first (tiny all-gather),
-then the variable-length streams, padded to the longest, in one RCCL all-gather-style gather.
+then point-to-point sends of exactly each rank's bytes (RCCL grouped send/recv over xGMI).  The cheaper
+alternative, exchanging only the sizes and letting every rank pwrite its own byte range, is
+exchange_region_offsets + write_own_range.
 Works on any torch.distributed backend (RCCL on the GPUs, gloo in the CPU tests).
 """
 import numpy as np
@@ -38,14 +40,14 @@ _RECV_CACHE = {}
 def gather_block_streams_async(backing, nbytes, block_offsets, dist, device=None, dst=0):
     """Start the gather of this rank's blocks region to rank `dst` and return a handle.
 
-    backing: 1-D uint8 tensor whose first `nbytes` bytes are this rank's blocks region and whose
-    capacity is at least the longest region of any rank (the encode output buffer: the send is padded
-    to the longest region by sending that many bytes of it, so no staging copy is made);
-    block_offsets: 1-D int64 tensor, offsets relative to the region start.
+    backing: 1-D uint8 tensor whose first `nbytes` bytes are this rank's blocks region (the encode output
+    buffer: it is sent from in place, no staging copy); block_offsets: 1-D int64 tensor, offsets relative
+    to the region start.
     handle.wait() returns on `dst` (parts, offsets): per-rank uint8 views in rank order (= file order)
     and per-rank int64 offsets relative to the start of the concatenated region; None elsewhere.
-    The receive buffers are reused across calls.  One size all-gather + two gathers, issued
-    asynchronously so the caller can overlap them with work that only reads `backing`."""
+    One size all-gather, then point-to-point sends of exactly the bytes each rank has (no padding to the
+    longest region), issued asynchronously so the caller can overlap them with work that only reads
+    `backing`.  The receive buffers are reused across calls."""
     import torch
     world = dist.get_world_size()
     rank = dist.get_rank()
@@ -55,37 +57,74 @@ def gather_block_streams_async(backing, nbytes, block_offsets, dist, device=None
     dist.all_gather(metas, meta)
     sizes = [int(m[0]) for m in metas]
     nblk = [int(m[1]) for m in metas]
-    max_sz = max(max(sizes), 1)
-    max_nb = max(max(nblk), 1)
-    if backing.numel() < max_sz:
-        raise ValueError("backing buffer (%d bytes) shorter than the longest region (%d)" % (backing.numel(), max_sz))
-    send = backing[:max_sz]
-    offp = torch.zeros(max_nb, dtype=torch.int64, device=device)
-    offp[:block_offsets.numel()] = block_offsets
+    if backing.numel() < sizes[rank]:
+        raise ValueError("backing buffer (%d bytes) shorter than its region (%d)" % (backing.numel(), sizes[rank]))
+    send = backing[:max(sizes[rank], 1)]
+    offs = block_offsets.to(torch.int64).contiguous() if block_offsets.numel() else torch.zeros(1, dtype=torch.int64, device=device)
     bufs = obufs = None
+    ops = []
     if rank == dst:
         key = (str(device), world)
         cached = _RECV_CACHE.get(key)
-        if cached is None or cached[0][0].numel() < max_sz or cached[1][0].numel() < max_nb:
-            cached = ([torch.empty(max_sz, dtype=torch.uint8, device=device) for _ in range(world)],
-                      [torch.empty(max_nb, dtype=torch.int64, device=device) for _ in range(world)])
+        if cached is None or any(cached[0][r].numel() < max(sizes[r], 1) or cached[1][r].numel() < max(nblk[r], 1)
+                                 for r in range(world)):
+            cached = ([torch.empty(max(sizes[r], 1), dtype=torch.uint8, device=device) for r in range(world)],
+                      [torch.empty(max(nblk[r], 1), dtype=torch.int64, device=device) for r in range(world)])
             _RECV_CACHE[key] = cached
-        bufs = [b[:max_sz] for b in cached[0]]
-        obufs = [b[:max_nb] for b in cached[1]]
-    works = [dist.gather(send, bufs, dst=dst, async_op=True), dist.gather(offp, obufs, dst=dst, async_op=True)]
+        bufs = [cached[0][r][:max(sizes[r], 1)] for r in range(world)]
+        obufs = [cached[1][r][:max(nblk[r], 1)] for r in range(world)]
+        for r in range(world):
+            if r == dst:
+                continue
+            ops.append(dist.P2POp(dist.irecv, bufs[r], r))
+            ops.append(dist.P2POp(dist.irecv, obufs[r], r))
+    else:
+        ops.append(dist.P2POp(dist.isend, send, dst))
+        ops.append(dist.P2POp(dist.isend, offs, dst))
+    works = dist.batch_isend_irecv(ops) if ops else []
 
     def finish():
         if rank != dst:
             return None
-        parts, offs = [], []
+        parts, out_offs = [], []
         base = 0
         for r in range(world):
-            parts.append(bufs[r][:sizes[r]])
-            offs.append(obufs[r][:nblk[r]] + base)
+            part = send[:sizes[r]] if r == dst else bufs[r][:sizes[r]]
+            o = offs[:nblk[r]] if r == dst else obufs[r][:nblk[r]]
+            parts.append(part)
+            out_offs.append(o + base)
             base += sizes[r]
-        return parts, offs
+        return parts, out_offs
 
-    return _GatherHandle(works, (send, offp, bufs, obufs), finish)
+    return _GatherHandle(works, (send, offs, bufs, obufs), finish)
+
+
+def exchange_region_offsets(nbytes, dist, device=None):
+    """The cheaper alternative to the gather: exchange only the region SIZES; every rank
+    then writes its own byte range of the output file itself.  Returns (my_start, total) in bytes of the
+    concatenated blocks region (file offset = 256 + my_start)."""
+    import torch
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    meta = torch.tensor([int(nbytes)], dtype=torch.int64, device=device)
+    metas = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    sizes = [int(m[0]) for m in metas]
+    return sum(sizes[:rank]), sum(sizes)
+
+
+def write_own_range(path, region_bytes, my_start):
+    """pwrite this rank's blocks region at its place in the shared output file (created by the writer rank
+    with the header; ranges of different ranks do not overlap, so no ordering between ranks is needed)."""
+    import os
+    fd = os.open(path, os.O_WRONLY)
+    try:
+        view = memoryview(region_bytes)
+        done = 0
+        while done < len(view):
+            done += os.pwrite(fd, view[done:], 256 + my_start + done)
+    finally:
+        os.close(fd)
 
 
 def gather_block_streams(region, block_offsets, dist, device=None, dst=0):
@@ -93,15 +132,8 @@ def gather_block_streams(region, block_offsets, dist, device=None, dst=0):
     (region_all uint8 tensor, offsets_all int64 tensor relative to the start of the concatenated
     region); None elsewhere."""
     import torch
-    world = dist.get_world_size()
     device = device if device is not None else region.device
-    # every rank needs a send buffer as long as the longest region: learn it, then pad
-    meta = torch.tensor([region.numel()], dtype=torch.int64, device=device)
-    metas = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    max_sz = max(max(int(m[0]) for m in metas), 1)
-    backing = torch.zeros(max_sz, dtype=torch.uint8, device=device)
-    backing[:region.numel()] = region
+    backing = region if region.numel() else torch.zeros(1, dtype=torch.uint8, device=device)
     out = gather_block_streams_async(backing, region.numel(), block_offsets, dist, device, dst).wait()
     if out is None:
         return None
