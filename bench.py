@@ -39,7 +39,7 @@ CONFIGS = {
 # one wave64 instruction per SIMD per 4 cycles; VALU instructions per 64-haplotype chunk per WAH line as
 # counted by SQ_INSTS_VALU (profiles/r02_pmc_sq_chains.txt).
 SIMDS, MODEL_CLOCK_HZ, CYCLES_PER_VALU = 256 * 4, 2.4e9, 4
-VALU_PER_CHUNK_LINE = {"k_chain_rank_enc": 9.8, "k_chain_pair_dec": 9.0, "k_chain_lds": 27.0,
+VALU_PER_CHUNK_LINE = {"k_chain_rank_enc": 9.8, "k_chain_decode_rank_wg": 11.0, "k_chain_lds": 27.0,
                        "k_chain_decode_rank": 14.0, "k_chain_decode_rank_big": 14.0, "k_chain_stream": 40.0}
 
 

@@ -62,7 +62,7 @@ def test_full_depth_block_against_oracle(n_haps, n_lines, thr, kernels):
 
 
 @pytest.mark.parametrize("n_haps,n_blocks,block_len,thr,force", [
-    (64976, 3, 700, 64, dict(XSI_PAIR_MIN_N_DEC="2")),   # packed-pair decode chain at depth (it needs >= 192 blocks by default)
+    (64976, 3, 700, 64, dict(XSI_RANK_WG_MIN_BLOCKS="1")),   # one-workgroup-per-block decode chain at depth (>= 192 blocks by default)
     (24576, 3, 900, 24, dict()),                          # rank-tracking encode below 64 chunks per wave
     (12300, 2, 1200, 12, dict(XSI_RANKENC_MIN_N="2")),
 ])
@@ -73,8 +73,8 @@ def test_chain_kernel_variants_at_depth(n_haps, n_blocks, block_len, thr, force,
     L = binding.lib()
     for k, v in force.items():
         monkeypatch.setenv(k, v)
-    if "XSI_PAIR_MIN_N_DEC" in force:
-        assert L.xsi_hip_chain_kernel(n_haps, n_blocks, 1).decode() == "k_chain_pair_dec"
+    if "XSI_RANK_WG_MIN_BLOCKS" in force:
+        assert L.xsi_hip_chain_kernel(n_haps, n_blocks, 1).decode() == "k_chain_decode_rank_wg"
     assert L.xsi_hip_chain_kernel(n_haps, n_blocks, 0).decode() == "k_chain_rank_enc"
     n_lines = n_blocks * block_len
     bits, packed, stride = _device_synth(n_haps, n_lines, 7)

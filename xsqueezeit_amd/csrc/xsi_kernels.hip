@@ -1145,7 +1145,7 @@ static const int k_chain_E[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 
 
 ChainGeom chain_geometry(uint32_t N, bool decode) {
     ChainGeom g{};
-    // N <= 65536: prefix array in LDS (k_chain_pair for the bulk, k_chain_lds for small N and for blocks
+    // N <= 65536: rank tracking (k_chain_rank_enc) for the bulk; prefix array in LDS (k_chain_lds) for small N and for blocks
     // with fully haploid lines); beyond that it streams through HBM/L2 (k_chain_stream / k_chain_global).
     (void)decode;
     g.in_lds = N <= 65536u;
@@ -1296,30 +1296,19 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
 
 // Which kernel takes the blocks without fully haploid lines (measured on MI355X, profiles/r02_chain_sweep.txt):
 //   encode  rank tracking (xsi_rankenc.hip) from ~20k haplotypes on, and from ~12k when there are enough
-//           blocks that k_chain_lds could not cut them into line segments anyway;
-//   decode  packed-pair position-major (xsi_pair.hip) when every CU gets a block of its own and the rows are
-//           long; otherwise the element-major kernels of xsi_rank.hip, which split a block over workgroups.
-// XSI_RANKENC_MIN_N / XSI_PAIR_MIN_N_DEC override the size rule (testing: force a kernel for every N).
+//           blocks that k_chain_lds could not cut them into line segments anyway; k_chain_lds below that;
+//   decode  always the element-major kernels of xsi_rank.hip (launch_rank_decode picks the geometry).
+// XSI_RANKENC_MIN_N overrides the size rule (testing: force the kernel for every N); read per call.
 static bool use_rank_encode(uint32_t N, uint32_t n_blocks) {
-    const char* ev = getenv("XSI_RANKENC_MIN_N");  // read per call: the tests switch kernels inside one process
+    const char* ev = getenv("XSI_RANKENC_MIN_N");
     const int env = ev ? atoi(ev) : -1;
     if (!chain_rank_enc_supported(N)) return false;
     if (env >= 0) return N >= (uint32_t)env;
     return N >= 20480u || (N >= 12288u && n_blocks >= 192u);
 }
-static bool use_pair_decode(uint32_t N, uint32_t n_blocks) {
-    const char* ev = getenv("XSI_PAIR_MIN_N_DEC");
-    const int env = ev ? atoi(ev) : -1;
-    if (!chain_pair_supported(N)) return false;
-    if (env >= 0) return N >= (uint32_t)env;
-    return N >= 40960u && n_blocks >= 192u;
-}
 
 const char* chain_kernel_name(uint32_t N, uint32_t n_blocks, bool decode) {
-    if (decode) {
-        if (use_pair_decode(N, n_blocks)) return "k_chain_pair_dec";
-        return N >= 49152u ? "k_chain_decode_rank_big" : "k_chain_decode_rank";
-    }
+    if (decode) return rank_decode_kernel_name(N, ((N + 63u) / 64u) * 2u, n_blocks);
     if (use_rank_encode(N, n_blocks)) return "k_chain_rank_enc";
     return N <= 65536u ? "k_chain_lds" : "k_chain_stream";
 }
@@ -1350,11 +1339,8 @@ hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n
 hipError_t launch_chain_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                                uint32_t* out_rows, uint32_t out_stride_w, uint32_t* scratch_a, bool any_haploid) {
     if (!n_blocks) return hipSuccess;
-    // blocks without fully haploid lines: element-major kernels (xsi_rank.hip) at small N, where the two
-    // barriers per line of a position-major step dominate; packed-pair position-major kernel (xsi_pair.hip)
-    // at large N, where the rank-select gather does
-    hipError_t e = use_pair_decode(L.N, n_blocks) ? launch_pair_decode(s, blocks, n_blocks, L, out_rows, out_stride_w)
-                                                  : launch_rank_decode(s, blocks, n_blocks, L, out_rows, out_stride_w);
+    // blocks without fully haploid lines: element-major kernels (xsi_rank.hip)
+    hipError_t e = launch_rank_decode(s, blocks, n_blocks, L, out_rows, out_stride_w);
     if (e != hipSuccess || !any_haploid) return e;
     // position-major kernel: the blocks with fully haploid lines (it skips the others)
     ChainArgs A{};

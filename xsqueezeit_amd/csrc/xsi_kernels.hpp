@@ -133,10 +133,8 @@ hipError_t launch_sparse_fill(hipStream_t s, const uint8_t* file, const DecBlock
 hipError_t launch_line_counts(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
                               uint32_t max_wah, uint32_t max_sparse, const uint32_t* d_totals);
 
-// packed-pair position-major decode chain (xsi_pair.hip): blocks without fully haploid lines, N <= 65536
-bool chain_pair_supported(uint32_t N);
-hipError_t launch_pair_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
-                              uint32_t* out_rows, uint32_t out_stride_w);
+// name of the element-major decode kernel launch_rank_decode picks (xsi_rank.hip)
+const char* rank_decode_kernel_name(uint32_t N, uint32_t yp_stride, uint32_t n_blocks);
 
 // element-major encode chain (xsi_rankenc.hip): blocks without fully haploid lines, N <= 65536
 bool chain_rank_enc_supported(uint32_t N);

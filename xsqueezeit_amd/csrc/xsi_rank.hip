@@ -34,6 +34,8 @@ static uint32_t next_pow2_log2(uint32_t v) {
 // Blocks that contain fully haploid lines keep the position-major kernel (a haploid line orders
 // y by the even members of `a`, which needs the permutation itself).
 // ------------------------------------------------------------------------------------------
+typedef uint32_t rank_u32x2 __attribute__((ext_vector_type(2)));
+
 struct RankArgs {
     const DecBlock* blocks;
     const uint32_t* wah_lines;  // [rank] binary line
@@ -302,6 +304,122 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
     }
 }
 
+// One workgroup per block, all of a block's haplotypes in its registers (N <= 65536: 64 chunks per wave at
+// most): the geometry for batches with at least as many blocks as CUs, where splitting a block over
+// workgroups only multiplies the row staging.  The {bits, prefix} row of line j+1 is fetched into two
+// registers per thread while line j runs and parked in the other half of a double buffer: one barrier per
+// line.  Per 64 haplotypes: one ds_read_b64 gather, 11 vector instructions, no scalar work.
+template <int E>
+__global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
+    constexpr uint32_t T = 1024, W = 16;
+    constexpr int G = 8;
+    static_assert(E % G == 0 && E <= 64, "groups of 8 chunks");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DecBlock& D = A.blocks[blockIdx.x];
+    if (D.error || D.n_wah == 0 || D.off_line_haploid != VAL_UNDEFINED) return;
+    const uint32_t N = A.N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t cg0 = w * E;
+    const uint32_t wah_first = D.wah_first, n_wah = D.n_wah;
+    const uint32_t CWP = A.yp_stride;  // pairs per row, <= 2048
+    constexpr uint32_t SLOT = 16384u;  // bytes of one staged row
+    uint2* stage = reinterpret_cast<uint2*>(smem);
+    const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    uint32_t r[E];
+    static_for<0, E>([&](auto ecn) {
+        constexpr int e = decltype(ecn)::value;
+        r[e] = (cg0 + (uint32_t)e) * 64u + lane;
+        if (r[e] >= N) r[e] = 0;  // haplotypes beyond N idle on position 0; their output is masked
+    });
+    uint32_t vm_lo = 0, vm_hi = 0;  // lane e (< E) stores chunk cg0+e's word: valid bits of that chunk
+    {
+        const uint64_t base = (uint64_t)(cg0 + lane) * 64u;
+        if (lane < (uint32_t)E && base < N) {
+            const uint32_t nv = (N - base >= 64u) ? 64u : (uint32_t)(N - base);
+            const uint64_t vm = nv == 64u ? ~0ull : ((1ull << nv) - 1ull);
+            vm_lo = (uint32_t)vm;
+            vm_hi = (uint32_t)(vm >> 32);
+        }
+    }
+    const uint32_t row_chunks = A.out_stride_w / 2u;  // 8-byte words per output row (padding included)
+    const bool store_lane = lane < (uint32_t)E && cg0 + lane < row_chunks && (A.out_stride_w & 1u) == 0u;
+    const bool odd_tail = (A.out_stride_w & 1u) != 0u;  // rows of an odd number of words: rare, word stores
+
+    uint2 R[2];
+    auto load_row = [&](uint32_t j) {
+        const uint2* src = A.yp + (size_t)(wah_first + j) * CWP;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t idx = (uint32_t)q * T + tid;
+            R[q] = idx < CWP ? src[idx] : make_uint2(0, 0);
+        }
+    };
+    auto store_row = [&](uint32_t buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t idx = (uint32_t)q * T + tid;
+            if (idx < CWP) stage[buf * (SLOT / 8u) + idx] = R[q];
+        }
+    };
+    load_row(0);
+    store_row(0);
+    uint32_t line = A.wah_lines[wah_first], Z = A.wah_z[wah_first];
+    __syncthreads();
+    using LdsPair = __attribute__((address_space(3))) rank_u32x2;
+    for (uint32_t j = 0; j < n_wah; ++j) {
+        const bool more = j + 1u < n_wah;
+        uint32_t line_n = 0, Z_n = 0;
+        if (more) {
+            load_row(j + 1u);
+            line_n = A.wah_lines[wah_first + j + 1u];
+            Z_n = A.wah_z[wah_first + j + 1u];
+        }
+        const uint32_t Zs = (uint32_t)__builtin_amdgcn_readfirstlane((int)Z);  // wave-uniform: keep it scalar
+        uint32_t tbase = tab_lds + (j & 1u) * SLOT;
+        uint32_t mine_lo = 0, mine_hi = 0;
+        static_for<0, E / G>([&](auto gcn) {
+            constexpr int g0 = decltype(gcn)::value * G;
+            // The groups are straight-line code without a branch between them: left alone the compiler issues
+            // the gathers of ALL groups first (2 E registers of pairs, E ballot masks in SGPRs) and spills.
+            // Passing the table base through an asm statement per group pins each group's gathers behind the
+            // previous group's rank updates (asm volatile statements keep their order).
+            asm volatile("" : "+s"(tbase));
+            rank_u32x2 pr[G];
+            static_for<0, G>([&](auto ecn) {
+                constexpr int e = decltype(ecn)::value;
+                pr[e] = *reinterpret_cast<const LdsPair*>((uintptr_t)(((r[g0 + e] >> 2) & 0x3FF8u) + tbase));
+            });
+            static_for<0, G>([&](auto ecn) {
+                constexpr int e = decltype(ecn)::value;
+                const uint32_t rr = r[g0 + e];
+                const uint32_t bit = __builtin_amdgcn_ubfe(pr[e][0], rr, 1u);
+                const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
+                const uint64_t m = __ballot(bit != 0u);
+                r[g0 + e] = __builtin_amdgcn_inverse_ballot_w64(m) ? Zs + ob : rr - ob;
+                mine_lo = write_lane(mine_lo, (uint32_t)m, (uint32_t)(g0 + e));
+                mine_hi = write_lane(mine_hi, (uint32_t)(m >> 32), (uint32_t)(g0 + e));
+            });
+#pragma unroll
+            for (int e = 0; e < G; ++e) asm volatile("" : "+v"(r[g0 + e]));  // this group's updates end here
+        });
+        uint32_t* orow = A.out + (size_t)line * A.out_stride_w;
+        if (store_lane) reinterpret_cast<uint2*>(orow)[cg0 + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
+        if (odd_tail && lane < (uint32_t)E) {
+            const uint32_t wi = 2u * (cg0 + lane);
+            if (wi < A.out_stride_w) orow[wi] = mine_lo & vm_lo;
+            if (wi + 1u < A.out_stride_w) orow[wi + 1u] = mine_hi & vm_hi;
+        }
+        // words of the output row beyond the chunks this workgroup holds (rows padded past 16*E chunks)
+        for (uint32_t i = 2u * W * E + tid; i < A.out_stride_w; i += T) orow[i] = 0;
+        if (more) store_row((j + 1u) & 1u);
+        line = line_n;
+        Z = Z_n;
+        __syncthreads();  // the next row is staged; everyone is done with this one
+    }
+}
+
 struct RankGeom {
     int T, E;
     uint32_t splits, batch, lds_bytes, log2_cwp;
@@ -421,6 +539,18 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) 
     return hipErrorInvalidValue;
 }
 
+// one workgroup per block: batches with about as many blocks as CUs, rows that fit a 16 KiB LDS slot
+static bool use_rank_wg(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
+    const char* ev = getenv("XSI_RANK_WG_MIN_BLOCKS");  // read per call (tests switch kernels in one process)
+    const uint32_t min_blocks = ev ? (uint32_t)atoi(ev) : 192u;
+    return yp_stride <= 2048u && N >= 16384u && n_blocks >= min_blocks;
+}
+
+const char* rank_decode_kernel_name(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
+    if (use_rank_wg(N, yp_stride, n_blocks)) return "k_chain_decode_rank_wg";
+    return N >= 49152u ? "k_chain_decode_rank_big" : "k_chain_decode_rank";
+}
+
 hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                               uint32_t* out_rows, uint32_t out_stride_w) {
     if (!n_blocks) return hipSuccess;
@@ -440,6 +570,29 @@ hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_
         const char* e = getenv("XSI_BIG_RANK_MIN_N");
         return e ? (uint32_t)atoi(e) : 49152u;  // measured: 11.3 ms against 14.2 ms at 64 976 hap x 64 blocks, slower at 40 000
     }();
+    {
+        const uint32_t nch = (L.N + 63u) / 64u;
+        if (use_rank_wg(L.N, L.yp_stride, n_blocks)) {
+            const uint32_t e = ((nch + 15u) / 16u + 7u) / 8u * 8u;  // chunks per wave, multiple of 8
+            const uint32_t lds = 2u * 16384u;
+#define XSI_WG_CASE(EE)                                                                                    \
+    if (e == EE) {                                                                                          \
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank_wg<EE>),    \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        if (err != hipSuccess) return err;                                                                  \
+        k_chain_decode_rank_wg<EE><<<dim3(n_blocks), dim3(1024), lds, s>>>(R);                              \
+        return hipGetLastError();                                                                           \
+    }
+            XSI_WG_CASE(16)
+            XSI_WG_CASE(24)
+            XSI_WG_CASE(32)
+            XSI_WG_CASE(40)
+            XSI_WG_CASE(48)
+            XSI_WG_CASE(56)
+            XSI_WG_CASE(64)
+#undef XSI_WG_CASE
+        }
+    }
     if ((!g.stage || L.N >= big_min) && L.yp_stride <= 1024u * 20u && L.yp_stride * 8u <= 160u * 1024u &&
         !getenv("XSI_NO_BIG_RANK"))
         return launch_rank_big(s, n_blocks, R);
