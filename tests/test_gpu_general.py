@@ -74,7 +74,9 @@ def test_general_encode_bit_exact_and_decode(n_samples, n_lines, block_len, maf,
         assert np.array_equal(counts[i][:nal[i]], oref[i][1]), "allele counts line %d" % i
 
 
-@pytest.mark.parametrize("n,n_lines,block_len", [(60, 240, 64), (1600, 160, 64), (2504, 96, 32), (70000, 24, 8)])
+@pytest.mark.parametrize("n,n_lines,block_len", [(60, 240, 64), (1600, 160, 64), (2504, 96, 32), (70000, 24, 8),
+                                                 (12000, 40, 8),    # rank tracking + LDS kernel for the haploid blocks
+                                                 (20000, 24, 8)])   # rank tracking + global-memory kernel for them
 def test_haploid_and_mixed_lines(n, n_lines, block_len):
     """Fully haploid lines interleaved with diploid ones (mixed-ploidy chrX-like input), through the
     256-thread, the 1024-thread and the global-memory chain kernels."""

@@ -266,6 +266,7 @@ struct ChainArgs {
     uint32_t batch;              // columns per prefetch batch
     uint32_t out_row_base;       // decode: first output row of the batch (binary line numbering offset)
     uint32_t only_haploid_blocks;// decode: skip blocks the element-major kernel already handled
+    uint32_t plain_done;         // encode: blocks without fully haploid lines are already encoded (rank tracking)
     uint32_t segments;           // encode, LDS kernel: workgroups per block (line segments), >= 1
     uint32_t seg_q16[5];         // cumulative segment boundaries as fractions of n_wah (Q16), [0] = 0
 };
@@ -1141,14 +1142,15 @@ static uint32_t next_pow2_log2(uint32_t v) {
 }
 
 // E values the LDS chain kernel is instantiated for (T = 1024); N <= 1024*E
-static const int k_chain_E[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64};
+static const int k_chain_E[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32};
 
 ChainGeom chain_geometry(uint32_t N, bool decode) {
     ChainGeom g{};
-    // N <= 65536: rank tracking (k_chain_rank_enc) for the bulk; prefix array in LDS (k_chain_lds) for small N and for blocks
-    // with fully haploid lines); beyond that it streams through HBM/L2 (k_chain_stream / k_chain_global).
+    // The position-major kernels (needed for small N and for blocks with fully haploid lines; everything else
+    // is rank tracking, xsi_rankenc.hip / xsi_rank.hip): prefix array in LDS up to 32768 haplotypes (32 chunks
+    // per wave: the larger instantiations spilled), beyond that in HBM/L2 (k_chain_stream / k_chain_global).
     (void)decode;
-    g.in_lds = N <= 65536u;
+    g.in_lds = N <= 32768u;
     if (!g.in_lds) {
         const uint32_t cw = (((N + 31u) >> 5) + 1u) & ~1u;
         g.threads = 1024;
@@ -1202,8 +1204,8 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
         if (!scratch_a) return hipErrorInvalidValue;
         // encode: A.only_haploid_blocks arrives as "some block has fully haploid lines"
         const bool any_haploid = A.only_haploid_blocks != 0;
-        if (!DECODE) A.only_haploid_blocks = 0;
-        if (!DECODE && A.cw <= 1024u * STREAM_ROW_REGS && !getenv("XSI_NO_STREAM_CHAIN")) {
+        if (!DECODE) A.only_haploid_blocks = A.plain_done;  // rank tracking done: only the haploid blocks are left
+        if (!DECODE && !A.plain_done && A.cw <= 1024u * STREAM_ROW_REGS && !getenv("XSI_NO_STREAM_CHAIN")) {
             // streaming kernel for the blocks without fully haploid lines, the two-pass kernel for the rest
             const uint32_t seg = (((A.N + 15u) / 16u) + 63u) & ~63u;  // positions per wave
             const uint32_t lds = (2u * A.cw + 3u * 16u) * 4u;
@@ -1287,9 +1289,6 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
     XSI_CHAIN_CASE(1024, 20)
     XSI_CHAIN_CASE(1024, 24)
     XSI_CHAIN_CASE(1024, 32)
-    XSI_CHAIN_CASE(1024, 40)
-    XSI_CHAIN_CASE(1024, 48)
-    XSI_CHAIN_CASE(1024, 64)
 #undef XSI_CHAIN_CASE
     return hipErrorInvalidValue;
 }
@@ -1325,6 +1324,7 @@ hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n
     // LDS kernel: handles haploid lines itself.  N > 65536: the streaming kernel takes the blocks
     // without haploid lines, k_chain_global the others (only_haploid_blocks makes it skip the rest).
     A.only_haploid_blocks = (rank_done || (any_haploid && !chain_geometry(L.N, false).in_lds)) ? 1u : 0u;
+    A.plain_done = rank_done ? 1u : 0u;
     A.wah_lines = L.wah_lines;
     A.kind = L.kind;
     A.src = L.planes;
