@@ -35,11 +35,12 @@ CONFIGS = {
     2: dict(haps=64976, sites=2_000_000, seed=43, scaling="weak", name="BASELINE.json configs[2]"),
     3: dict(haps=500_000, sites=10_000_000, seed=44, scaling="strong", name="BASELINE.json configs[3]"),
 }
-# Issue-rate model of the chain kernels: the chains are bound by vector-instruction issue,
-# one wave64 instruction per SIMD per 4 cycles; VALU instructions per 64-haplotype chunk per WAH line as
-# counted by SQ_INSTS_VALU (profiles/r02_pmc_sq_chains.txt).
-SIMDS, MODEL_CLOCK_HZ, CYCLES_PER_VALU = 256 * 4, 2.4e9, 4
-VALU_PER_CHUNK_LINE = {"k_chain_rank_enc": 9.8, "k_chain_decode_rank_wg": 11.0, "k_chain_lds": 27.0,
+# Issue-rate model of the chain kernels: the chains are bound by vector-instruction issue.
+# A SIMD sustains one wave64 VALU instruction per 2.8 cycles with four waves resident (tools/microbench2.hip,
+# profiles/r02_microbench2.txt; 4 cycles for a wave alone); VALU instructions per 64-haplotype chunk per WAH
+# line as counted by SQ_INSTS_VALU (profiles/r02_pmc_sq_chains.txt; r01 for the round-1 kernels).
+SIMDS, MODEL_CLOCK_HZ, CYCLES_PER_VALU = 256 * 4, 2.4e9, 2.8
+VALU_PER_CHUNK_LINE = {"k_chain_rank_enc": 9.8, "k_chain_decode_rank_wg": 12.9, "k_chain_lds": 27.0,
                        "k_chain_decode_rank": 14.0, "k_chain_decode_rank_big": 14.0, "k_chain_stream": 40.0}
 
 

@@ -1,6 +1,6 @@
 // microbench2.hip — issue-rate calibration on MI355X for the chain kernels' instruction mix:
-// cycles per wave64 VALU / SALU instruction with 1..4 waves per SIMD, 16-bit vs 32-bit LDS stores,
-// random ds_read_b64 gathers, LDS atomics.  One workgroup per CU.  Times are per wave-instruction.
+// cycles per wave64 VALU instruction (a dependent chain of v_add_u32) with 1..4 waves per SIMD, 16-bit vs
+// 32-bit LDS stores, random LDS gathers (with the index arithmetic around them).  One workgroup per CU.  Times are per wave-instruction.
 // Build: hipcc --offload-arch=gfx950 -O3 tools/microbench2.hip -o tools/microbench2
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -11,18 +11,6 @@
 using LdsU16 = __attribute__((address_space(3))) uint16_t;
 using LdsU32 = __attribute__((address_space(3))) uint32_t;
 
-// 4 independent VALU chains, 64 instructions per iteration
-template <int T>
-__global__ void __launch_bounds__(T) k_valu(int iters, uint32_t* out) {
-    uint32_t a = threadIdx.x, b = a + 1, c = a + 2, d = a + 3;
-    for (int i = 0; i < iters; ++i) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            a = a * 5u + 1u; b = b * 5u + 1u; c = c * 5u + 1u; d = d * 5u + 1u;  // v_mad_u32_u24 / mul+add
-        }
-    }
-    if (a + b + c + d == 0x12345678u) out[0] = a;
-}
 template <int T>
 __global__ void __launch_bounds__(T) k_valu_add(int iters, uint32_t* out) {
     uint32_t a = threadIdx.x, b = a + 1, c = a + 2, d = a + 3;
@@ -34,31 +22,6 @@ __global__ void __launch_bounds__(T) k_valu_add(int iters, uint32_t* out) {
         }
     }
     if (a + b + c + d == 0x12345678u) out[0] = a;
-}
-// 32 VALU + 32 SALU interleaved per iteration
-template <int T>
-__global__ void __launch_bounds__(T) k_mix(int iters, uint32_t* out) {
-    uint32_t a = threadIdx.x, b = a + 1;
-    uint32_t s0 = blockIdx.x, s1 = 3;
-    for (int i = 0; i < iters; ++i) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            asm volatile("v_add_u32 %0, %0, %1\n s_add_u32 %2, %2, %3\n v_add_u32 %1, %1, %0\n s_add_u32 %3, %3, %2"
-                         : "+v"(a), "+v"(b), "+s"(s0), "+s"(s1));
-        }
-    }
-    if (a + b + s0 + s1 == 0x12345678u) out[0] = a;
-}
-template <int T>
-__global__ void __launch_bounds__(T) k_salu(int iters, uint32_t* out) {
-    uint32_t s0 = blockIdx.x, s1 = 3;
-    for (int i = 0; i < iters; ++i) {
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            asm volatile("s_add_u32 %0, %0, %1\n s_add_u32 %1, %1, %0" : "+s"(s0), "+s"(s1));
-        }
-    }
-    if (s0 + s1 == 0x12345678u) out[0] = s0;
 }
 // LDS stores: MODE 0 = ds_write_b32 conflict-free, 1 = ds_write_b16 to one half of consecutive dwords
 // (half-split layout), 2 = ds_write_b16 to consecutive halfwords (adjacent lanes share a dword)
@@ -137,10 +100,7 @@ int main() {
         printf("%-18s T=%4d  %8.3f ms  %6.2f ns per wave-instr per wave = %5.2f cyc@2.4GHz; per SIMD (x waves/SIMD %d): %5.2f cyc\n", \
                name, TT, ms, ns, ns * ghz, (TT / 64 + 3) / 4, ns * ghz / ((TT / 64 + 3) / 4));           \
     }
-    RUNV("valu mad x4", k_valu, 64, 128) RUNV("valu mad x4", k_valu, 256, 128) RUNV("valu mad x4", k_valu, 512, 128) RUNV("valu mad x4", k_valu, 1024, 128)
     RUNV("valu add x4", k_valu_add, 64, 64) RUNV("valu add x4", k_valu_add, 256, 64) RUNV("valu add x4", k_valu_add, 512, 64) RUNV("valu add x4", k_valu_add, 1024, 64)
-    RUNV("salu", k_salu, 64, 64) RUNV("salu", k_salu, 256, 64) RUNV("salu", k_salu, 1024, 64)
-    RUNV("valu+salu 1:1", k_mix, 64, 64) RUNV("valu+salu 1:1", k_mix, 256, 64) RUNV("valu+salu 1:1", k_mix, 512, 64) RUNV("valu+salu 1:1", k_mix, 1024, 64)
 #define RUNL(name, kern, TT, MODE, per_iter, lds)                                                         \
     {                                                                                                     \
         hipFuncSetAttribute(reinterpret_cast<const void*>(&kern<TT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
