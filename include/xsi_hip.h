@@ -124,6 +124,18 @@ int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_
                       uint64_t n_lines, const uint32_t* h_ngt, const uint32_t* h_n_allele, void* d_out,
                       uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result);
 
+/*
+ * Decode a whole file image and encode it again with other parameters (block length, MAC threshold, default
+ * phase, missing-data strategy) and, optionally, a selection of its samples, without the genotypes leaving the
+ * device: the "-Ox" path of NewDecompressor (include/gt_decompressor_new.hpp:241-273, fill_selected_genotypes
+ * :209-238 + XsiFactoryInterface::append).  h_n_allele[l] for every BCF line as for xsi_hip_decode_gt;
+ * h_sample_idx (n_sel indices into the file's samples, NULL = all); p_new->n_samples must be the number of
+ * samples written.  Output as xsi_hip_encode_gt.
+ */
+int xsi_hip_reencode(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, const uint32_t* h_n_allele, uint64_t n_lines,
+                     const xsi_encode_params* p_new, const uint32_t* h_sample_idx, uint32_t n_sel, void* d_out,
+                     uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result);
+
 /* Upper bound of the blocks region for xsi_hip_encode_gt (adds the side channels). */
 uint64_t xsi_hip_encode_gt_bound(const xsi_encode_params* p, uint64_t n_bcf_lines, uint64_t n_binary_lines);
 

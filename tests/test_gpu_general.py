@@ -482,3 +482,53 @@ def test_accessor_sample_subset(tmp_path):
     binding.check(L.xsi_accessor_set_sample_subset(a, None, 0))
     assert L.xsi_accessor_fill_selected_genotypes(a, buf.ctypes.data, buf.size, 2, 0, None) == binding.XSI_ERR_ARG
     L.xsi_accessor_close(a)
+
+
+def test_reencode_on_device(tmp_path):
+    """xsi_hip_reencode = the -Ox path (gt_decompressor_new.hpp:241-273): decode a file and encode it again
+    with other parameters, optionally for a selection of samples, genotypes staying in HBM.  The result must
+    be the file the oracle writes from the same (selected) lines with the new parameters."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    torch = G.torch_mod()
+    rng = np.random.default_rng(4242)
+    n, block_len = 260, 50
+    lines = []
+    for b in range(4):
+        for i in range(block_len):
+            if b == 2 and i % 5 == 1:
+                al = (rng.random(n) < 0.25).astype(np.int32)
+                lines.append((((al + 1) << 1).astype(np.int32), 2))
+            else:
+                lines.extend(_random_lines(rng, n, 1, multi=(b != 2), missing=(i % 3 == 0), eov=(i % 4 == 0), phase=True))
+    dp = oracle.default_phased_of(lines, n)
+    src = oracle.encode_file(lines, n, block_len=block_len, mac_thr=1, default_phased=dp)
+    d_file = G.dev_u8(np.frombuffer(src, np.uint8))
+    nal = np.asarray([na for _, na in lines], dtype=np.uint32)
+    n_bin = int((nal - 1).sum())
+    for sel in (None, np.sort(rng.permutation(n)[:97]).astype(np.uint32)):
+        n_new = n if sel is None else len(sel)
+        # the haploid lines sit in block 2 of the source; with 80-line blocks they share blocks with
+        # multi-allelic lines, so the new files are compared as bytes, not decoded (SURVEY 9.6.2)
+        p = G.params(n_new, 80, 3, dp)
+        cap = int(L.xsi_hip_encode_gt_bound(ctypes.byref(p), len(lines), n_bin))
+        d_out = G.dev_empty(cap)
+        n_blocks = (len(lines) + 79) // 80
+        d_off = torch.zeros(n_blocks, dtype=torch.int64, device="cuda")
+        res = binding.EncodeResult()
+        binding.check(L.xsi_hip_reencode(G.ctx().handle, d_file.data_ptr(), len(src), nal.ctypes.data, len(lines),
+                                         ctypes.byref(p), sel.ctypes.data if sel is not None else None, n_new,
+                                         d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)))
+        region = d_out[:res.blocks_bytes].cpu().numpy().tobytes()
+        names = ["S%d" % i for i in range(n_new)]
+        got = G.assemble_file(region, d_off.cpu().numpy().astype(np.uint64), p, len(lines), G.num_variants(lines), names, 2)
+        if sel is None:
+            new_lines = lines
+        else:
+            new_lines = [(gt.reshape(n, len(gt) // n)[sel].reshape(-1), na) for gt, na in lines]
+        ref = oracle.encode_file(new_lines, n_new, block_len=80, mac_thr=3, default_phased=dp, sample_names=names)
+        assert got == ref
+    bad = G.params(n + 1, 80, 3, dp)
+    assert L.xsi_hip_reencode(G.ctx().handle, d_file.data_ptr(), len(src), nal.ctypes.data, len(lines), ctypes.byref(bad),
+                              None, 0, d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)) == binding.XSI_ERR_ARG

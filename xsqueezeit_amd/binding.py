@@ -52,6 +52,7 @@ SYMBOLS = [
     "xsi_accessor_set_cache_bytes", "xsi_accessor_cache_stats", "xsi_file_num_samples", "xsi_hip_decode_dot",
     "xsi_hip_ctx_set_workspace_budget", "xsi_hip_chain_kernel", "xsi_mac_threshold", "xsi_default_phased",
     "xsi_bm_init", "xsi_bm_next", "xsi_accessor_set_sample_subset", "xsi_accessor_fill_selected_genotypes",
+    "xsi_hip_reencode",
 ]
 
 
@@ -100,6 +101,9 @@ def lib():
     L.xsi_hip_ctx_set_workspace_budget.argtypes = [vp, u64]
     L.xsi_hip_chain_kernel.restype = c.c_char_p
     L.xsi_hip_chain_kernel.argtypes = [u32, u64, c.c_int]
+    L.xsi_hip_reencode.restype = c.c_int
+    L.xsi_hip_reencode.argtypes = [vp, vp, u64, vp, u64, c.POINTER(EncodeParams), vp, u32, vp, u64, vp,
+                                   c.POINTER(EncodeResult)]
     L.xsi_mac_threshold.restype = u32
     L.xsi_mac_threshold.argtypes = [u32, u32, c.c_double]
     L.xsi_default_phased.restype = i32

@@ -1043,4 +1043,60 @@ int xsi_hip_decode_gt(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, u
     return XSI_OK;
 }
 
+
+int xsi_hip_reencode(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, const uint32_t* h_n_allele, uint64_t n_lines,
+                     const xsi_encode_params* p_new, const uint32_t* h_sample_idx, uint32_t n_sel, void* d_out,
+                     uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result) {
+    if (!ctx || !d_file || !h_n_allele || !p_new || !d_out) return set_error(XSI_ERR_ARG, "reencode: null argument");
+    if (file_len < 256) return set_error(XSI_ERR_FORMAT, "file image shorter than the 256-byte header");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    uint8_t h[256];
+    HIP_TRY(hipMemcpyAsync(h, d_file, 256, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    auto get = [&](size_t off, int bytes) {
+        uint64_t v = 0;
+        for (int i = 0; i < bytes; ++i) v |= (uint64_t)h[off + i] << (8 * i);
+        return v;
+    };
+    const uint64_t io = get(72, 8), so = get(80, 8);
+    const uint64_t version = get(8, 4);
+    if (so < io) return set_error(XSI_ERR_FORMAT, "index outside the file image");
+    const uint64_t n_blocks = (so - io) / (version >= 5 ? 8 : 4);
+    const uint64_t ns = get(112, 8), N = ns ? ns * 2 : get(32, 8);
+    const uint32_t n_src = (uint32_t)(N / 2);
+    const uint32_t n_dst = h_sample_idx ? n_sel : n_src;
+    if (p_new->n_samples != n_dst)
+        return set_error(XSI_ERR_ARG, "reencode: params say %u samples, the %s has %u", p_new->n_samples,
+                         h_sample_idx ? "selection" : "file", n_dst);
+    if (h_sample_idx)
+        for (uint32_t i = 0; i < n_sel; ++i)
+            if (h_sample_idx[i] >= n_src) return set_error(XSI_ERR_ARG, "reencode: sample %u of %u", h_sample_idx[i], n_src);
+    // decode every line to int32 rows in HBM, (optionally) gather the selected samples there, encode again
+    int32_t* d_rows;
+    WS(d_rows, "reenc.rows", 4ull * N * (size_t)n_lines);
+    std::vector<uint32_t> ngt(n_lines);
+    int rc = xsi_hip_decode_gt(ctx, d_file, file_len, 0, n_blocks, h_n_allele, n_lines, d_rows, N, ngt.data(), nullptr, 0);
+    if (rc) return rc;
+    const int32_t* d_enc = d_rows;
+    uint64_t stride = N;
+    if (h_sample_idx) {
+        uint32_t *d_sel, *d_ngt;
+        int32_t* d_sub;
+        WS(d_sel, "reenc.sel", 4ull * n_sel);
+        WS(d_ngt, "reenc.ngt", 4ull * n_lines);
+        WS(d_sub, "reenc.sub", 8ull * n_sel * (size_t)n_lines);
+        HIP_TRY(hipMemcpyAsync(d_sel, h_sample_idx, 4ull * n_sel, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_ngt, ngt.data(), 4ull * n_lines, hipMemcpyHostToDevice, s));
+        rc = select_samples(ctx, d_rows, N, d_ngt, (uint32_t)n_lines, n_src, d_sel, n_sel, d_sub, 2ull * n_sel, nullptr, 0);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(s));  // the host vectors above must outlive the copies
+        for (auto& v : ngt) v = v / n_src * n_sel;
+        d_enc = d_sub;
+        stride = 2ull * n_sel;
+    }
+    return xsi_hip_encode_gt(ctx, p_new, d_enc, stride, n_lines, ngt.data(), h_n_allele, d_out, out_capacity, d_block_offsets,
+                             h_result);
+}
+
 }  // extern "C"
