@@ -197,11 +197,25 @@ int xsi_hip_decode_counts(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_le
  * fixed summation order; agrees with the reference's sum (taken in PBWT order) up to rounding.
  * Works on the bit planes alone, so it covers bi-allelic, fully called lines (diploid or fully haploid);
  * blocks with multi-allelic lines or missing / end-of-vector entries return XSI_ERR_UNSUPPORTED (use
- * xsi_hip_decode_gt and contract the genotypes).
+ * xsi_hip_decode_dot_gt).
  */
 int xsi_hip_decode_dot(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block,
                        uint64_t n_blocks, const double* d_pheno, uint32_t n_pheno, double* d_out,
                        uint64_t capacity_lines, uint64_t* h_n_bin);
+
+/*
+ * The same products for ANY block: multi-allelic lines, missing and end-of-vector entries, mixed ploidy.
+ * The genotypes are composed in HBM (as xsi_hip_decode_gt does, never leaving the device) and contracted
+ * there: d_out[r * n_pheno + k] = sum of d_pheno[sample * n_pheno + k] over the haplotypes whose allele is
+ * the ALT allele of binary line r (binary lines in file order: ALT 1 .. n_allele-1 of each BCF line); missing
+ * and end-of-vector values carry no allele.  h_n_allele[n_lines] is the allele number of every BCF line of
+ * the requested blocks, as for xsi_hip_decode_gt (it lives in the variant BCF).  Blocks are walked in ranges
+ * whose int32 rows fit the workspace budget.  Same summation order as xsi_hip_decode_dot: on lines both
+ * entry points cover the results are bit-identical.
+ */
+int xsi_hip_decode_dot_gt(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block,
+                          uint64_t n_blocks, const uint32_t* h_n_allele, uint64_t n_lines, const double* d_pheno,
+                          uint32_t n_pheno, double* d_out, uint64_t capacity_lines, uint64_t* h_n_bin);
 
 /* Deterministic synthetic haplotype matrix: writes n_lines packed rows starting
  * at site index first_line.  Generator defined in DESIGN.md; mirrored in numpy for the tests. */

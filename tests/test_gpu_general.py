@@ -429,6 +429,106 @@ def test_phenotype_dot_products_on_decoded_planes():
     assert rc == -5  # XSI_ERR_UNSUPPORTED
 
 
+def _expected_dot(dec, nal, y, n):
+    """numpy contraction of oracle-decoded rows: one output row per (BCF line, ALT allele)."""
+    out = []
+    for (g, _), na in zip(dec, nal):
+        ploidy = len(g) // n
+        al = (g.astype(np.int64) >> 1) - 1          # missing -> -1, end-of-vector -> negative
+        ys = np.repeat(y, ploidy, axis=0)
+        for k in range(1, na):
+            out.append(((al == k).astype(np.float64)[:, None] * ys).sum(0))
+    return np.stack(out)
+
+
+@pytest.mark.gpu
+def test_phenotype_dot_products_on_composed_genotypes():
+    """SURVEY §8f-4 on the blocks the plane path refuses: multi-allelic lines (with a majority ALT allele, i.e.
+    negated sparse lines), missing and end-of-vector entries, non-default phase, and fully haploid lines in
+    blocks of their own.  Expected: numpy contraction of the oracle-decoded rows (rtol 1e-12: fixed but
+    different summation order).  Also: identical bits to xsi_hip_decode_dot where both apply, and the same
+    result when the workspace budget forces one block per range."""
+    import gpu_util as G
+    from oracle import oracle
+    torch = G.torch_mod()
+    L = binding.lib()
+    rng = np.random.default_rng(909)
+    n, block_len, K = 421, 48, 5
+    lines = []
+    for b in range(5):
+        for i in range(block_len if b < 4 else 17):
+            if b == 2:     # a block of fully haploid and plain diploid lines (no multi-allelic ones beside them)
+                if i % 3 == 0:
+                    al = (rng.random(n) < 0.4).astype(np.int32)
+                    lines.append((((al + 1) << 1).astype(np.int32), 2))
+                else:
+                    lines.extend(_random_lines(rng, n, 1, missing=(i % 4 == 1)))
+            else:
+                lines.extend(_random_lines(rng, n, 1, multi=True, missing=(i % 3 == 0), eov=(i % 5 == 0), phase=True))
+                if i % 7 == 0:   # make ALT 1 the majority allele: its line is stored as a negated sparse line
+                    gt, na = lines[-1]
+                    keep = (gt == oracle.INT32_VECTOR_END) | ((gt >> 1) == 0)
+                    al = (gt >> 1) - 1
+                    sw = np.where(al == 0, 1, np.where(al == 1, 0, al))
+                    g2 = (((sw + 1) << 1) | (gt & 1)).astype(np.int32)
+                    lines[-1] = (np.where(keep, gt, g2).astype(np.int32), na)
+    nal = [na for _, na in lines]
+    dp = oracle.default_phased_of(lines, n)
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=9, default_phased=dp)
+    dec = oracle.decode_file(ref, nal, block_len=block_len)
+    y = rng.normal(0.0, 10.0, size=(n, K))
+    exp = _expected_dot(dec, nal, y, n)
+    n_bin = exp.shape[0]
+    d_file = G.dev_u8(np.frombuffer(ref, dtype=np.uint8))
+    d_y = torch.from_numpy(y).cuda()
+    h_nal = np.asarray(nal, dtype=np.uint32)
+
+    def run(n_pheno_y, first=0, nb_blocks=5, nal_slice=h_nal):
+        d_out = torch.full((n_bin + 3, n_pheno_y.shape[1]), np.nan, dtype=torch.float64, device="cuda")
+        nb = ctypes.c_uint64(0)
+        binding.check(L.xsi_hip_decode_dot_gt(G.ctx().handle, d_file.data_ptr(), len(ref), first, nb_blocks,
+                                              nal_slice.ctypes.data, len(nal_slice), n_pheno_y.data_ptr(),
+                                              n_pheno_y.shape[1], d_out.data_ptr(), n_bin + 3, ctypes.byref(nb)))
+        return d_out.cpu().numpy(), nb.value
+
+    got, nb = run(d_y)
+    assert nb == n_bin
+    assert np.allclose(got[:n_bin], exp, rtol=1e-12, atol=1e-9)
+    assert np.isnan(got[n_bin:]).all()
+    # a sub-range of blocks (the haploid block and the one after it)
+    lo, hi = 2 * block_len, 4 * block_len
+    bin_lo = int(sum(a - 1 for a in nal[:lo])); bin_hi = int(sum(a - 1 for a in nal[:hi]))
+    sub, nb = run(d_y, first=2, nb_blocks=2, nal_slice=np.ascontiguousarray(h_nal[lo:hi]))
+    assert nb == bin_hi - bin_lo
+    assert np.array_equal(sub[:nb], got[bin_lo:bin_hi])
+    # one block per range (tiny workspace budget): same bits
+    binding.check(L.xsi_hip_ctx_set_workspace_budget(G.ctx().handle, 1 << 16))
+    try:
+        small, _ = run(d_y)
+    finally:
+        binding.check(L.xsi_hip_ctx_set_workspace_budget(G.ctx().handle, 0))
+    assert np.array_equal(small[:n_bin], got[:n_bin])
+    # wrong allele numbers are refused
+    bad = h_nal.copy(); bad[3] += 1
+    d_o = torch.zeros((n_bin + 8, K), dtype=torch.float64, device="cuda")
+    rc = L.xsi_hip_decode_dot_gt(G.ctx().handle, d_file.data_ptr(), len(ref), 0, 5, bad.ctypes.data, len(bad),
+                                 d_y.data_ptr(), K, d_o.data_ptr(), n_bin + 8, None)
+    assert rc == -1
+    # on a file both entry points cover the two agree bit for bit
+    lines3 = _random_lines(rng, n, 100, phase=True)
+    ref3 = oracle.encode_file(lines3, n, block_len=block_len, mac_thr=9, default_phased=oracle.default_phased_of(lines3, n))
+    d_file3 = G.dev_u8(np.frombuffer(ref3, dtype=np.uint8))
+    y3 = torch.from_numpy(rng.normal(0.0, 10.0, size=(n, 3))).cuda()
+    o_a = torch.zeros((100, 3), dtype=torch.float64, device="cuda")
+    o_b = torch.zeros((100, 3), dtype=torch.float64, device="cuda")
+    nal3 = np.full(100, 2, dtype=np.uint32)
+    binding.check(L.xsi_hip_decode_dot(G.ctx().handle, d_file3.data_ptr(), len(ref3), 0, 3, y3.data_ptr(), 3,
+                                       o_a.data_ptr(), 100, None))
+    binding.check(L.xsi_hip_decode_dot_gt(G.ctx().handle, d_file3.data_ptr(), len(ref3), 0, 3, nal3.ctypes.data, 100,
+                                          y3.data_ptr(), 3, o_b.data_ptr(), 100, None))
+    assert torch.equal(o_a, o_b)
+
+
 def test_accessor_sample_subset(tmp_path):
     """fill_selected_genotypes == the reference's fill_selected_genotypes (gt_decompressor_new.hpp:209-238):
     the listed samples' values in list order, 1 or 2 per sample by the line's ploidy, AN and the AC of

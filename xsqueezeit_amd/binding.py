@@ -49,7 +49,7 @@ SYMBOLS = [
     "xsi_writer_finalize", "xsi_writer_close", "xsi_accessor_open", "xsi_accessor_fill_genotype_array",
     "xsi_accessor_get_genotypes", "xsi_accessor_allele_counts", "xsi_accessor_hap_samples",
     "xsi_accessor_num_samples", "xsi_accessor_sample_name", "xsi_accessor_close",
-    "xsi_accessor_set_cache_bytes", "xsi_accessor_cache_stats", "xsi_file_num_samples", "xsi_hip_decode_dot",
+    "xsi_accessor_set_cache_bytes", "xsi_accessor_cache_stats", "xsi_file_num_samples", "xsi_hip_decode_dot", "xsi_hip_decode_dot_gt",
     "xsi_hip_ctx_set_workspace_budget", "xsi_hip_chain_kernel", "xsi_mac_threshold", "xsi_default_phased",
     "xsi_bm_init", "xsi_bm_next", "xsi_accessor_set_sample_subset", "xsi_accessor_fill_selected_genotypes",
     "xsi_hip_reencode",
@@ -169,6 +169,8 @@ def lib():
     L.xsi_accessor_cache_stats.argtypes = [vp, c.POINTER(u64), c.POINTER(u64), c.POINTER(u64), c.POINTER(u64)]
     L.xsi_hip_decode_dot.restype = c.c_int
     L.xsi_hip_decode_dot.argtypes = [vp, vp, u64, u64, u64, vp, u32, vp, u64, c.POINTER(u64)]
+    L.xsi_hip_decode_dot_gt.restype = c.c_int
+    L.xsi_hip_decode_dot_gt.argtypes = [vp, vp, u64, u64, u64, vp, u64, vp, u32, vp, u64, c.POINTER(u64)]
     L.xsi_file_num_samples.restype = c.c_int64
     L.xsi_file_num_samples.argtypes = [c.c_char_p]
     L.xsi_accessor_close.restype = None

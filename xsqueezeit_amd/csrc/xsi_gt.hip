@@ -3,6 +3,7 @@
 // lists) is shared with the packed path; this file only adds the conversion kernels around it.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -633,6 +634,56 @@ __global__ void __launch_bounds__(256) k_dot_planes(const uint32_t* __restrict__
     }
 }
 
+// Phenotype dot products on COMPOSED genotypes: what the bit planes alone cannot say (which ALT allele a
+// haplotype of a multi-allelic line carries once a negated sparse line, missing or end-of-vector entries are
+// involved) the int32 rows can.  One wave per binary line (parent BCF row, ALT index); a lane takes one
+// sample per step and counts its copies of that allele (missing and end-of-vector values never match).
+// float64, same fixed summation order as k_dot_planes, so both paths give identical sums on lines both cover.
+template <int KB>
+__global__ void __launch_bounds__(256) k_dot_gt(const int32_t* __restrict__ rows, uint64_t stride,
+                                                const uint32_t* __restrict__ line_ngt,
+                                                const uint32_t* __restrict__ bin_parent,
+                                                const uint32_t* __restrict__ bin_alt, uint32_t n_bin, uint32_t n_samples,
+                                                const double* __restrict__ y, uint32_t n_pheno, uint32_t k0,
+                                                double* __restrict__ out) {
+    const uint32_t l = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (l >= n_bin) return;
+    const uint32_t lane = lane_id();
+    const uint32_t parent = bin_parent[l];
+    const int32_t alt = (int32_t)bin_alt[l];
+    const bool haploid = line_ngt[parent] == n_samples;
+    const int32_t* row = rows + (size_t)parent * stride;
+    double acc[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) acc[k] = 0.0;
+    for (uint32_t s0 = 0; s0 < n_samples; s0 += 64u) {
+        const uint32_t smp = s0 + lane;
+        uint32_t dosage = 0;
+        if (smp < n_samples) {
+            if (haploid) {
+                dosage = ((row[smp] >> 1) - 1) == alt;
+            } else {
+                const int32_t a0 = row[2u * smp], a1 = row[2u * smp + 1u];
+                dosage = (uint32_t)(((a0 >> 1) - 1) == alt) + (uint32_t)(((a1 >> 1) - 1) == alt);
+            }
+        }
+        if (dosage) {
+            const double d = (double)dosage;
+            const double* yp = y + (size_t)smp * n_pheno + k0;
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (k0 + (uint32_t)k < n_pheno) acc[k] += d * yp[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        double a = acc[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+        if (lane == 0 && k0 + (uint32_t)k < n_pheno) out[(size_t)l * n_pheno + k0 + (uint32_t)k] = a;
+    }
+}
+
 // Many phenotypes: the product is a real dense contraction, [lines x N] 0/1 times [N x K] float64, and
 // goes to the float64 matrix cores.  v_mfma_f64_16x16x4_f64: lane l holds A[row l&15][k l>>4] and
 // B[k l>>4][col l&15]; result register i of lane l is C[row (l>>4) + 4i][col l&15].  Rows = lines,
@@ -1039,6 +1090,113 @@ int xsi_hip_decode_gt(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, u
     stage_mark(ctx, -1);
     if (h_line_ngt) HIP_TRY(hipMemcpyAsync(h_line_ngt, d_line_ngt, 4ull * n_bcf, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    stage_collect(ctx);
+    return XSI_OK;
+}
+
+
+// One range of blocks through the composed rows (see k_dot_gt).  h_n_allele covers exactly these blocks.
+static int dot_gt_range(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block, uint64_t n_blocks,
+                        const uint32_t* h_n_allele, uint64_t n_lines, const double* d_pheno, uint32_t n_pheno, double* d_out,
+                        uint64_t* n_bin_out) {
+    hipStream_t s = ctx->stream;
+    DecodePlan P;
+    int rc = decode_prepare(ctx, d_file, file_len, first_block, n_blocks, &P);
+    if (rc) return rc;
+    if (P.n_bcf != n_lines)
+        return set_error(XSI_ERR_ARG, "decode_dot_gt: blocks hold %u BCF lines, caller passed %llu", P.n_bcf, (unsigned long long)n_lines);
+    const uint32_t n_bcf = P.n_bcf, N = P.L.N;
+    std::vector<uint32_t> first_bin(n_bcf), parent(P.n_bin), alt(P.n_bin);
+    {
+        uint32_t l = 0;
+        for (uint32_t b = 0; b < P.n_blocks; ++b) {
+            uint32_t acc = P.blocks_h[b].first_bin;
+            const uint32_t end = acc + P.blocks_h[b].n_bin;
+            for (uint32_t i = 0; i < P.blocks_h[b].n_bcf; ++i, ++l) {
+                if (h_n_allele[l] < 2) return set_error(XSI_ERR_ARG, "decode_dot_gt: line %u has fewer than 2 alleles", l);
+                first_bin[l] = acc;
+                for (uint32_t k = 1; k < h_n_allele[l] && acc < end; ++k, ++acc) {
+                    parent[acc] = l;
+                    alt[acc] = k;
+                }
+                if (acc - first_bin[l] != h_n_allele[l] - 1) acc = end + 1;  // overran the block: caught below
+            }
+            if (acc != end)
+                return set_error(XSI_ERR_ARG, "decode_dot_gt: allele numbers of block %u do not add up to its %u binary lines", b,
+                                 P.blocks_h[b].n_bin);
+        }
+    }
+    uint32_t *d_first_bin, *d_nallele, *d_line_ngt, *d_parent, *d_alt;
+    int32_t* d_rows;
+    WS(d_first_bin, "gt.bcf_first_bin", 4ull * n_bcf);
+    WS(d_nallele, "gt.bcf_nallele", 4ull * n_bcf);
+    WS(d_line_ngt, "gt.line_ngt", 4ull * n_bcf);
+    WS(d_parent, "dot.bin_parent", 4ull * P.n_bin + 4);
+    WS(d_alt, "dot.bin_alt", 4ull * P.n_bin + 4);
+    WS(d_rows, "dot.rows", 4ull * N * (size_t)(n_bcf ? n_bcf : 1));
+    HIP_TRY(hipMemcpyAsync(d_first_bin, first_bin.data(), 4ull * n_bcf, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_nallele, h_n_allele, 4ull * n_bcf, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_parent, parent.data(), 4ull * P.n_bin, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_alt, alt.data(), 4ull * P.n_bin, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // local vectors: the copies must have left host memory
+    DecodedPlanes DPn;
+    rc = decode_all_planes(ctx, d_file, P, &DPn);
+    if (rc) return rc;
+    rc = compose_lines(ctx, P, DPn, d_first_bin, d_nallele, n_bcf, d_rows, N, d_line_ngt, nullptr, 0);
+    if (rc) return rc;
+    if (P.n_bin) {
+        const dim3 grid((P.n_bin + 3u) / 4u), block(256);
+        uint32_t k0 = 0;
+        for (; k0 + 4u <= n_pheno; k0 += 4u)
+            k_dot_gt<4><<<grid, block, 0, s>>>(d_rows, N, d_line_ngt, d_parent, d_alt, P.n_bin, P.L.n_samples, d_pheno, n_pheno, k0, d_out);
+        for (; k0 < n_pheno; ++k0)
+            k_dot_gt<1><<<grid, block, 0, s>>>(d_rows, N, d_line_ngt, d_parent, d_alt, P.n_bin, P.L.n_samples, d_pheno, n_pheno, k0, d_out);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    *n_bin_out = P.n_bin;
+    return XSI_OK;
+}
+
+int xsi_hip_decode_dot_gt(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block, uint64_t n_blocks,
+                          const uint32_t* h_n_allele, uint64_t n_lines, const double* d_pheno, uint32_t n_pheno,
+                          double* d_out, uint64_t capacity, uint64_t* h_n_bin) {
+    if (!ctx || !d_file || !h_n_allele || !d_pheno || !d_out) return set_error(XSI_ERR_ARG, "decode_dot_gt: null argument");
+    if (!n_pheno) return set_error(XSI_ERR_ARG, "decode_dot_gt: n_pheno must be > 0");
+    if (file_len < 256) return set_error(XSI_ERR_FORMAT, "file image shorter than the 256-byte header");
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint64_t n_bin_total = 0;
+    for (uint64_t l = 0; l < n_lines; ++l) {
+        if (h_n_allele[l] < 2) return set_error(XSI_ERR_ARG, "decode_dot_gt: line %llu has fewer than 2 alleles", (unsigned long long)l);
+        n_bin_total += h_n_allele[l] - 1;
+    }
+    if (n_bin_total > capacity)
+        return set_error(XSI_ERR_CAPACITY, "decode_dot_gt: %llu binary lines, capacity %llu", (unsigned long long)n_bin_total,
+                         (unsigned long long)capacity);
+    // the int32 rows of a range of blocks live in the workspace: walk the blocks in ranges that fit its budget
+    DecodePlan P;
+    int rc = decode_prepare(ctx, d_file, file_len, first_block, n_blocks, &P);
+    if (rc) return rc;
+    if (P.n_bcf != n_lines)
+        return set_error(XSI_ERR_ARG, "decode_dot_gt: blocks hold %u BCF lines, caller passed %llu", P.n_bcf, (unsigned long long)n_lines);
+    std::vector<uint32_t> block_bcf(P.n_blocks);
+    for (uint32_t b = 0; b < P.n_blocks; ++b) block_bcf[b] = P.blocks_h[b].n_bcf;
+    const uint64_t row_bytes = 4ull * P.L.N + 3ull * 4ull * P.L.y_stride64 * 2ull;  // int32 row + up to 3 planes per line
+    const uint64_t budget_lines = std::max<uint64_t>(1, ws_budget_now(ctx) / 2 / row_bytes);
+    uint64_t done_bin = 0, line0 = 0;
+    for (uint32_t b0 = 0; b0 < (uint32_t)block_bcf.size();) {
+        uint32_t b1 = b0;
+        uint64_t lines = 0;
+        while (b1 < block_bcf.size() && (b1 == b0 || lines + block_bcf[b1] <= budget_lines)) lines += block_bcf[b1++];
+        uint64_t nb = 0;
+        rc = dot_gt_range(ctx, d_file, file_len, first_block + b0, b1 - b0, h_n_allele + line0, lines, d_pheno, n_pheno,
+                          d_out + done_bin * n_pheno, &nb);
+        if (rc) return rc;
+        done_bin += nb;
+        line0 += lines;
+        b0 = b1;
+    }
+    if (h_n_bin) *h_n_bin = done_bin;
     stage_collect(ctx);
     return XSI_OK;
 }
