@@ -303,7 +303,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     // WAH16 words per line, worst case ceil(N/15) (+1 for the saturation split): encode once, then copy
     L.wah_scratch_stride = ((N + 14u) / 15u + 3u) & ~1u;  // even: rows stay 4-byte aligned for k_wah_write
     L.wah_scratch = nullptr;  // without it the lines are sized first and encoded again straight into place
-    if (use_wah_scratch) WS(L.wah_scratch, "enc.wah_scratch", 2ull * L.wah_scratch_stride * (size_t)n_bin);
+    if (use_wah_scratch && !wah_units_ok(L.y_stride64)) WS(L.wah_scratch, "enc.wah_scratch", 2ull * L.wah_scratch_stride * (size_t)n_bin);
     WS(L.flagbits, "enc.flagbits", 4ull * (MAX_BIN_PER_BLOCK / 32) * FV_COUNT * (size_t)n_blocks);
     WS(L.flagwah, "enc.flagwah", 2ull * FLAG_WORDS_MAX * FV_COUNT * (size_t)n_blocks);
     uint32_t* d_totals;

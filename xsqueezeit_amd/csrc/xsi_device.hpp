@@ -208,6 +208,49 @@ __device__ __forceinline__ void wah_encode_chunk(uint32_t val, bool valid, bool 
     c.out += total;
 }
 
+// wah_encode_chunk for lines of at most 16383 groups (245 745 bits), where no run can outgrow the counter
+// of a fill word.  The run structure of the 64 groups is worked out on the two ballots "group is all zeros" /
+// "group is all ones" with scalar 64-bit logic; the lanes only build and store their own word.
+// `le_lo/le_hi` = bits 0..lane set (per lane, computed once per line); `nvalid` = groups in this chunk.
+template <bool WRITE>
+__device__ __forceinline__ void wah_encode_chunk_short(uint32_t val, uint32_t nvalid, bool last_chunk, uint32_t next_val,
+                                                       uint32_t le_lo, uint32_t le_hi, WahCarry& c,
+                                                       uint16_t* __restrict__ dst) {
+    const uint32_t lane = lane_id();
+    const uint64_t V = nvalid >= 64u ? ~0ull : ((1ull << nvalid) - 1ull);
+    const uint64_t Z = __ballot(val == 0u) & V;
+    const uint64_t O = __ballot(val == 0x7FFFu) & V;
+    // a fill group continues a run when the group before it (the carry for lane 0) is of its type
+    const uint64_t Zs = Z & ((Z << 1) | (uint64_t)(c.type == 0u));
+    const uint64_t Os = O & ((O << 1) | (uint64_t)(c.type == 1u));
+    const uint64_t H = V & ~(Zs | Os);  // heads: literals and first groups of runs
+    const uint32_t li = nvalid - 1u;    // last valid lane
+    const uint32_t tl = ((Z >> li) & 1ull) ? 0u : (((O >> li) & 1ull) ? 1u : 2u);
+    const uint32_t nt = (next_val == 0u) ? 0u : ((next_val == 0x7FFFu) ? 1u : 2u);
+    const bool end_last = last_chunk || nt == 2u || nt != tl;
+    // a word is emitted where a run ends: the group after it is a head (a literal is a run of one)
+    const uint64_t E = ((H >> 1) | ((uint64_t)end_last << li)) & V;
+    if (WRITE) {
+        const uint32_t pos = mbcnt64(E);
+        if (__builtin_amdgcn_inverse_ballot_w64(E)) {
+            const uint32_t hl = (uint32_t)H & le_lo, hh = (uint32_t)(H >> 32) & le_hi;
+            // groups of the run that ends here: back to its head, or through the carry when it began earlier
+            const uint32_t top = hh ? 63u - (uint32_t)__clz((int)hh) : 31u - (uint32_t)__clz((int)hl);  // hl = hh = 0: unused
+            const uint32_t len = (hh | hl) ? lane - top + 1u : c.len + lane + 1u;
+            const bool fill = val == 0u || val == 0x7FFFu;
+            dst[c.out + pos] = (uint16_t)(fill ? (0x8000u | (val & 0x4000u) | len) : val);
+        }
+    }
+    if (tl < 2u) {
+        const uint64_t hb = H;  // H has no bit above li
+        c.len = hb ? li - (63u - (uint32_t)__clzll((long long)hb)) + 1u : c.len + nvalid;
+    } else {
+        c.len = 0u;
+    }
+    c.type = tl;
+    c.out += (uint32_t)__popcll(E);
+}
+
 // Encode a whole packed bit row with one wave.  Returns the number of WAH16 words.  The groups of
 // the next two chunks are loaded before the current chunk is encoded, so the serial run-merging
 // logic never waits on memory.
@@ -219,6 +262,24 @@ __device__ __forceinline__ uint32_t wave_wah_encode_row(const uint32_t* __restri
     WahCarry c{3u, 0u, 0u};
     uint32_t cur = load_group15(row, lane, nbits);
     uint32_t n1 = load_group15(row, lane + 64u, nbits);
+    if (G <= WAH_MAXC) {
+        // no run can outgrow a fill word: the lean chunk encoder, and chunks that only extend a run of zeros
+        // are skipped on a ballot
+        const uint64_t le = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
+        const uint32_t le_lo = (uint32_t)le, le_hi = (uint32_t)(le >> 32);
+        for (uint32_t g0 = 0; g0 < G; g0 += 64u) {
+            const uint32_t n2 = load_group15(row, g0 + 128u + lane, nbits);
+            const bool last = g0 + 64u >= G;
+            const uint32_t next_val = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1);
+            if (!last && c.type == 0u && next_val == 0u && __ballot(cur != 0u) == 0ull)
+                c.len += 64u;
+            else
+                wah_encode_chunk_short<WRITE>(cur, last ? G - g0 : 64u, last, next_val, le_lo, le_hi, c, dst);
+            cur = n1;
+            n1 = n2;
+        }
+        return c.out;
+    }
     for (uint32_t g0 = 0; g0 < G; g0 += 64u) {
         const uint32_t n2 = load_group15(row, g0 + 128u + lane, nbits);
         const bool last = g0 + 64u >= G;
@@ -228,6 +289,110 @@ __device__ __forceinline__ uint32_t wave_wah_encode_row(const uint32_t* __restri
         n1 = n2;
     }
     return c.out;
+}
+
+// ------------------------------------------------------------------------------------------
+// WAH16 of a row staged in LDS, lines of at most 16383 groups (no run can outgrow a fill word), without a
+// serial pass over the line.  The line is cut into UNITS of 32 groups = 480 bits = 15 words; a lane owns unit
+// r*64 + lane in round r.  Inside a unit everything is per-lane bit logic on 32-bit masks: Z / O = groups
+// that are all zeros / all ones, and a group is a HEAD (starts a word) when it is a literal or its predecessor
+// (the last group of the unit before, read directly from the row) is not a fill of its type.  The number of
+// words of a line is the number of heads; a fill word's count is the distance to the next head.  Units whose
+// lanes sit 15 words apart read LDS without bank conflicts.
+// ------------------------------------------------------------------------------------------
+using LdsCU32 = const __attribute__((address_space(3))) uint32_t;
+using LdsU32W = __attribute__((address_space(3))) uint32_t;
+constexpr int WAH_UNIT_ROUNDS = 3;  // 3 x 64 units x 32 groups = 6144 groups >= ceil(65 536 / 15)
+constexpr uint32_t WAH_UNIT_ROW_WORDS = 64u * 15u * (uint32_t)WAH_UNIT_ROUNDS;
+struct WahUnit {
+    uint32_t H, F, O;  // heads, fill groups, all-ones groups of my unit (bit k = group k of the unit)
+};
+__device__ __forceinline__ void wah_unit_classify(LdsCU32* row, uint32_t u, uint32_t G, WahUnit& m) {
+    const uint32_t gb = u * 32u;
+    uint32_t w[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) w[i] = row[u * 15u + (uint32_t)i];
+    const uint32_t prev = row[u ? u * 15u - 1u : 0u] >> 17;  // the group before the unit (u > 0)
+    uint32_t nz = 0, no = 0;  // bit k: group k is not all zeros / not all ones
+    static_for<0, 32>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int wi = (15 * k) >> 5, sh = (15 * k) & 31;
+        uint32_t val;
+        if constexpr (sh <= 17)
+            val = __builtin_amdgcn_ubfe(w[wi], (uint32_t)sh, 15u);
+        else
+            val = __builtin_amdgcn_alignbit(w[wi + 1], w[wi], (uint32_t)sh) & 0x7FFFu;
+        nz = ((val ? 1u : 0u) << k) | nz;
+        no = (((val ^ 0x7FFFu) ? 1u : 0u) << k) | no;
+    });
+    const uint32_t nv = G > gb ? G - gb : 0u;
+    const uint32_t Vm = nv >= 32u ? ~0u : ((1u << nv) - 1u);
+    const uint32_t Z = ~nz & Vm, O = ~no & Vm;
+    const uint32_t pz = (u != 0u && prev == 0u) ? 1u : 0u, po = (u != 0u && prev == 0x7FFFu) ? 1u : 0u;
+    const uint32_t Zs = Z & ((Z << 1) | pz), Os = O & ((O << 1) | po);
+    m.H = Vm & ~(Zs | Os);
+    m.F = Z | O;
+    m.O = O;
+}
+// Masks of every unit of the line (one call per wave); returns the number of WAH16 words of the line.
+__device__ __forceinline__ uint32_t wah_units_classify_line(LdsCU32* row, uint32_t G, WahUnit (&m)[WAH_UNIT_ROUNDS]) {
+    const uint32_t lane = lane_id();
+    const uint32_t rounds = (((G + 31u) >> 5) + 63u) >> 6;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int r = 0; r < WAH_UNIT_ROUNDS; ++r) {
+        m[r] = WahUnit{0u, 0u, 0u};
+        if ((uint32_t)r < rounds) {  // wave-uniform
+            wah_unit_classify(row, (uint32_t)r * 64u + lane, G, m[r]);
+            cnt += (uint32_t)__popc(m[r].H);
+        }
+    }
+    const uint32_t inc = wave_scan_incl_dpp(cnt);
+    return (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+}
+// Emit the words of the line to dst (2-byte aligned).  `fh` = LDS scratch of 64 * WAH_UNIT_ROUNDS words.
+__device__ __forceinline__ void wah_units_emit_line(LdsCU32* row, LdsU32W* fh, uint32_t G, const WahUnit (&m)[WAH_UNIT_ROUNDS],
+                                                    uint16_t* __restrict__ dst) {
+    const uint32_t lane = lane_id();
+    const uint32_t rounds = (((G + 31u) >> 5) + 63u) >> 6;
+    uint64_t B[WAH_UNIT_ROUNDS];  // units with at least one head, per round
+#pragma unroll
+    for (int r = 0; r < WAH_UNIT_ROUNDS; ++r) {
+        B[r] = __ballot(m[r].H != 0u);
+        fh[(uint32_t)r * 64u + lane] = ((uint32_t)r * 64u + lane) * 32u + (uint32_t)__builtin_ctz(m[r].H | 0x80000000u);
+    }
+    const uint64_t above = (lane == 63u) ? 0ull : (~0ull << (lane + 1u));
+    uint32_t round_off = 0;
+#pragma unroll
+    for (int r = 0; r < WAH_UNIT_ROUNDS; ++r) {
+        if ((uint32_t)r >= rounds) break;  // wave-uniform
+        const uint32_t gb = ((uint32_t)r * 64u + lane) * 32u;
+        // first head after my unit: a later lane of this round, else the first unit with a head of a later round
+        uint32_t later = ~0u;  // wave-uniform
+#pragma unroll
+        for (int q = WAH_UNIT_ROUNDS - 1; q > r; --q)
+            if (B[q]) later = (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(B[q]);
+        const uint64_t mine = B[r] & above;
+        const uint32_t tu = mine ? (uint32_t)r * 64u + (uint32_t)__builtin_ctzll(mine) : later;
+        const uint32_t nh = tu != ~0u ? fh[tu] : G;
+        const uint32_t cnt = (uint32_t)__popc(m[r].H);
+        const uint32_t inc = wave_scan_incl_dpp(cnt);
+        uint32_t idx = round_off + inc - cnt;
+        round_off += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        uint32_t Hr = m[r].H;
+        while (__any(Hr != 0u)) {
+            if (Hr) {
+                const uint32_t k = (uint32_t)__builtin_ctz(Hr);
+                Hr &= Hr - 1u;
+                const uint32_t g = gb + k;
+                const uint32_t nxt = Hr ? gb + (uint32_t)__builtin_ctz(Hr) : nh;
+                const uint32_t o = g * WAH_BITS;
+                const uint32_t lit = __builtin_amdgcn_alignbit(row[(o >> 5) + 1u], row[o >> 5], o & 31u) & 0x7FFFu;
+                const uint32_t fill = 0x8000u | (((m[r].O >> k) & 1u) << 14) | (nxt - g);
+                dst[idx++] = (uint16_t)(((m[r].F >> k) & 1u) ? fill : lit);
+            }
+        }
+    }
 }
 
 // Expand one WAH16 line into a zeroed packed row held in LDS (wah2_extract_template,

@@ -1384,9 +1384,101 @@ __global__ void __launch_bounds__(256) k_wah_sizes(EncLines L, const uint32_t* _
     }
 }
 
+// Rows of at most 8 KiB (N <= 65 536): each wave stages its line in LDS with 8-byte loads, all in flight at
+// once, fetches the next line into registers while it works on the current one, and runs the unit encoder of
+// xsi_device.hpp on it.  The sizing pass counts heads; the writing pass (after the layout is known) classifies
+// again and stores the words straight into the file image: no scratch copy of the words (10 GB at 64 976 x 2 M).
+constexpr int WAH_STAGE_Q = 16;  // 16 x 64 lanes x 8 bytes = 8 KiB
+constexpr uint32_t WAH_UNIT_WAVE_WORDS = WAH_UNIT_ROW_WORDS + 64u * (uint32_t)WAH_UNIT_ROUNDS;
+template <bool WRITE_PASS>
+__global__ void __launch_bounds__(256) k_wah_units(const EncBlock* __restrict__ blocks, EncLines L,
+                                                   const uint32_t* __restrict__ d_total_wah, uint32_t max_wah,
+                                                   uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wah_smem[];
+    if (WRITE_PASS && d_result[3]) return;  // capacity error: nothing may be written
+    const uint32_t lane = lane_id();
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t j0 = (blockIdx.x * 4u + wv) * WAH_LINES_PER_WAVE;
+    uint32_t total;
+    if (WRITE_PASS)
+        total = max_wah < (uint32_t)d_result[2] ? max_wah : (uint32_t)d_result[2];
+    else
+        total = d_total_wah[0];
+    if (j0 >= total) return;
+    const uint32_t np = L.y_stride64;  // 8-byte pairs per row, <= 64 WAH_STAGE_Q
+    typedef uint32_t wah_u32x2 __attribute__((ext_vector_type(2)));
+    using LdsU2 = __attribute__((address_space(3))) wah_u32x2;
+    LdsU32W* lrow_w = reinterpret_cast<LdsU32W*>((__attribute__((address_space(3))) unsigned char*)wah_smem) +
+                      (size_t)wv * WAH_UNIT_WAVE_WORDS;
+    LdsU2* lrow2 = reinterpret_cast<LdsU2*>(lrow_w);
+    LdsCU32* lrow = reinterpret_cast<LdsCU32*>(lrow_w);
+    LdsU32W* fh = lrow_w + WAH_UNIT_ROW_WORDS;
+    for (uint32_t i = 2u * np + lane; i < WAH_UNIT_ROW_WORDS; i += 64u) lrow_w[i] = 0;  // beyond the row: zeros
+    uint64_t m_dst = 0;
+    uint32_t m_nbits = 0;
+    if (lane < WAH_LINES_PER_WAVE && j0 + lane < total) {
+        const uint32_t l = L.wah_lines[j0 + lane];
+        m_nbits = nbits_of(L, l);
+        if (WRITE_PASS) {
+            const EncBlock& B = blocks[L.line_block[l]];
+            m_dst = reinterpret_cast<uint64_t>(out + B.out_off + 16u + B.off_wah) + 2ull * L.wah_off[j0 + lane];
+        }
+    }
+    uint2 R[WAH_STAGE_Q];
+    auto fetch = [&](uint32_t j) {
+        const uint2* src = reinterpret_cast<const uint2*>(L.yrows + (size_t)j * L.y_stride64);
+#pragma unroll
+        for (int q = 0; q < WAH_STAGE_Q; ++q) {
+            const uint32_t idx = (uint32_t)q * 64u + lane;
+            R[q] = idx < np ? src[idx] : make_uint2(0u, 0u);
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int q = 0; q < WAH_STAGE_Q; ++q) {
+            const uint32_t idx = (uint32_t)q * 64u + lane;
+            if (idx < np) lrow2[idx] = wah_u32x2{R[q].x, R[q].y};
+        }
+    };
+    fetch(j0);
+    for (uint32_t k = 0; k < WAH_LINES_PER_WAVE && j0 + k < total; ++k) {
+        const uint32_t j = j0 + k;
+        park();
+        if (k + 1u < WAH_LINES_PER_WAVE && j + 1u < total) fetch(j + 1u);
+        const uint32_t nbits = (uint32_t)__builtin_amdgcn_readlane((int)m_nbits, (int)k);
+        // bits at or beyond nbits read as zero (the reference pads the last group with zeros, wah.hpp:547-565)
+        if (lane == 0 && (nbits & 31u)) lrow_w[nbits >> 5] &= (1u << (nbits & 31u)) - 1u;
+        for (uint32_t i = ((nbits + 31u) >> 5) + lane; i < 2u * np; i += 64u) lrow_w[i] = 0;
+        const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
+        WahUnit m[WAH_UNIT_ROUNDS];
+        const uint32_t n = wah_units_classify_line(lrow, G, m);
+        if (WRITE_PASS) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m_dst, (int)k);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m_dst >> 32), (int)k);
+            wah_units_emit_line(lrow, fh, G, m, reinterpret_cast<uint16_t*>(((uint64_t)hi << 32) | lo));
+        } else {
+            if (lane == 0) L.wah_len[j] = n;
+        }
+    }
+}
+
+bool wah_units_ok(uint32_t y_stride64) {
+    static const bool off = getenv("XSI_WAH_NO_UNITS") != nullptr;
+    return !off && y_stride64 <= 64u * (uint32_t)WAH_STAGE_Q;
+}
+
 hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_total_wah, uint32_t max_wah) {
     if (!max_wah) return hipSuccess;
     const uint32_t per_wg = 4u * WAH_LINES_PER_WAVE;
+    if (wah_units_ok(L.y_stride64)) {
+        const uint32_t lds = 4u * 4u * WAH_UNIT_WAVE_WORDS;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        k_wah_units<false><<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), lds, s>>>(nullptr, L, d_total_wah, max_wah,
+                                                                                         nullptr, nullptr);
+        return hipGetLastError();
+    }
     k_wah_sizes<<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), 0, s>>>(L, d_total_wah);
     return hipGetLastError();
 }
@@ -1445,6 +1537,15 @@ hipError_t launch_wah_write(hipStream_t s, const EncBlock* blocks, const EncLine
                             uint8_t* out, const uint64_t* d_result) {
     if (!max_wah) return hipSuccess;
     const uint32_t per_wg = 4u * WAH_LINES_PER_WAVE;
+    if (!L.wah_scratch && wah_units_ok(L.y_stride64)) {  // classify again, words straight into place
+        const uint32_t lds = 4u * 4u * WAH_UNIT_WAVE_WORDS;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        k_wah_units<true><<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), lds, s>>>(blocks, L, nullptr, max_wah, out,
+                                                                                        d_result);
+        return hipGetLastError();
+    }
     k_wah_write<<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), 0, s>>>(blocks, L, max_wah, out, d_result);
     return hipGetLastError();
 }
