@@ -209,7 +209,7 @@ uint64_t ws_budget_now(const xsi_hip_ctx* c) {
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 8ull << 30;
     uint64_t held = 0;
     for (auto& kv : c->bufs) held += kv.second.cap;
-    return (uint64_t)((free_b + held) * 0.4);
+    return (uint64_t)((free_b + held) * 0.5);
 }
 
 void stage_mark(xsi_hip_ctx* c, int stage) {
@@ -299,11 +299,12 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     WS(L.wah_len, "enc.wah_len", 4ull * n_bin);
     WS(L.wah_off, "enc.wah_off", 4ull * n_bin);
     L.y_stride64 = (N + 63u) / 64u;
-    WS(L.yrows, "enc.yrows", 8ull * L.y_stride64 * (size_t)n_bin);
+    const size_t y_rows = L.y_rows ? L.y_rows : n_bin;  // one per WAH line: exact when the caller counted them
+    WS(L.yrows, "enc.yrows", 8ull * L.y_stride64 * y_rows);
     // WAH16 words per line, worst case ceil(N/15) (+1 for the saturation split): encode once, then copy
     L.wah_scratch_stride = ((N + 14u) / 15u + 3u) & ~1u;  // even: rows stay 4-byte aligned for k_wah_write
     L.wah_scratch = nullptr;  // without it the lines are sized first and encoded again straight into place
-    if (use_wah_scratch && !wah_units_ok(L.y_stride64)) WS(L.wah_scratch, "enc.wah_scratch", 2ull * L.wah_scratch_stride * (size_t)n_bin);
+    if (use_wah_scratch && !wah_units_ok(L.y_stride64)) WS(L.wah_scratch, "enc.wah_scratch", 2ull * L.wah_scratch_stride * y_rows);
     WS(L.flagbits, "enc.flagbits", 4ull * (MAX_BIN_PER_BLOCK / 32) * FV_COUNT * (size_t)n_blocks);
     WS(L.flagwah, "enc.flagwah", 2ull * FLAG_WORDS_MAX * FV_COUNT * (size_t)n_blocks);
     uint32_t* d_totals;
@@ -401,22 +402,54 @@ int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const vo
     hipStream_t s = ctx->stream;
     const uint32_t N = (uint32_t)N64;
     const uint64_t n_blocks_all = (n_lines + p->block_len - 1) / p->block_len;
-    // Per-line workspace: the permuted row y and (optionally) the WAH16 words of the line, encoded once and
-    // copied into place.  A job whose workspace exceeds the budget drops the WAH scratch first (lines are then
-    // sized and encoded twice), then runs as batches of whole blocks: blocks are independent
+    // Ones of every line first: they decide which lines are WAH lines, i.e. how many permuted rows y each block
+    // needs (the bulk of the workspace: 62.5 KB per WAH line at 500 000 haplotypes).
+    uint32_t* cnt_all;
+    uint8_t* kind_all;
+    uint32_t* d_wah_per_block;
+    WS(cnt_all, "enc.cnt", 4ull * n_lines);
+    WS(kind_all, "enc.kind", (size_t)n_lines);
+    WS(d_wah_per_block, "enc.wah_per_block", 4ull * n_blocks_all);
+    HIP_TRY(hipMemsetAsync(kind_all, 0, n_lines, s));
+    stage_mark(ctx, XSI_ST_COUNT);
+    HIP_TRY(launch_count_rows(s, reinterpret_cast<const uint32_t*>(d_bits), row_stride_bytes / 4u, N, (uint32_t)n_lines, cnt_all));
+    HIP_TRY(launch_wah_lines_per_block(s, cnt_all, n_lines, p->block_len, N, p->mac_threshold, d_wah_per_block));
+    stage_mark(ctx, -1);
+    std::vector<uint32_t> wah_per_block((size_t)n_blocks_all);
+    HIP_TRY(hipMemcpyAsync(wah_per_block.data(), d_wah_per_block, 4ull * n_blocks_all, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // Per-line workspace: the permuted row y of a WAH line and (rows above 8 KiB only) its WAH16 words, encoded
+    // once and copied into place.  A job whose workspace exceeds the budget drops the WAH scratch first (lines are
+    // then sized and encoded twice), then runs as batches of whole blocks: blocks are independent
     // (gt_block.hpp:179-180, xsi_factory.hpp:527-539), so the bytes are those of a single call.
-    const uint64_t y_line = 8ull * ((N + 63u) / 64u), scratch_line = 2ull * (((N + 14u) / 15u + 3u) & ~1u), misc_line = 40;
+    const bool units = wah_units_ok((N + 63u) / 64u);
+    const uint64_t y_line = 8ull * ((N + 63u) / 64u), scratch_line = units ? 0 : 2ull * (((N + 14u) / 15u + 3u) & ~1u), misc_line = 40;
     const uint64_t budget = ws_budget_now(ctx);
-    bool use_scratch = (y_line + scratch_line + misc_line) * n_lines <= budget;
-    const uint64_t per_block = (y_line + (use_scratch ? scratch_line : 0) + misc_line) * p->block_len;
-    uint64_t max_batch = budget / (per_block ? per_block : 1);
-    if (max_batch < 1) max_batch = 1;
-    const uint64_t n_batches = (n_blocks_all + max_batch - 1) / max_batch;
-    const uint64_t batch_blocks = (n_blocks_all + n_batches - 1) / n_batches;  // balanced
+    uint64_t wah_all = 0;
+    for (uint32_t c : wah_per_block) wah_all += c;
+    const bool use_scratch = (y_line + scratch_line) * wah_all + misc_line * n_lines <= budget;
+    const uint64_t row_bytes = y_line + (use_scratch ? scratch_line : 0);
+    auto block_need = [&](uint64_t b) {
+        const uint64_t lines = (b + 1) * p->block_len <= n_lines ? p->block_len : n_lines - b * p->block_len;
+        return row_bytes * wah_per_block[b] + misc_line * lines;
+    };
+    // batches of about equal need, none above the budget (a single block may exceed it: it runs alone)
+    uint64_t need_all = 0;
+    for (uint64_t b = 0; b < n_blocks_all; ++b) need_all += block_need(b);
+    uint64_t n_batches = (need_all + budget - 1) / (budget ? budget : 1);
+    if (n_batches < 1) n_batches = 1;
+    const uint64_t target = (need_all + n_batches - 1) / n_batches;
     xsi_encode_result total{};
     uint64_t region_off = 0;
-    for (uint64_t b0 = 0; b0 < n_blocks_all; b0 += batch_blocks) {
-        const uint64_t nb = b0 + batch_blocks <= n_blocks_all ? batch_blocks : n_blocks_all - b0;
+    for (uint64_t b0 = 0; b0 < n_blocks_all;) {
+        uint64_t nb = 0, acc = 0, rows = 0;
+        while (b0 + nb < n_blocks_all) {
+            const uint64_t nd = block_need(b0 + nb);
+            if (nb && (acc + nd > budget || acc >= target)) break;
+            acc += nd;
+            rows += wah_per_block[b0 + nb];
+            ++nb;
+        }
         const uint64_t l0 = b0 * p->block_len;
         const uint64_t nl = (l0 + nb * p->block_len <= n_lines) ? nb * p->block_len : n_lines - l0;
         const uint32_t n_bin = (uint32_t)nl;
@@ -434,11 +467,9 @@ int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const vo
         L.N = N;
         L.aet = p->n_samples <= 65535u ? 2u : 4u;  // xsi_factory.hpp:424-427
         L.thr = p->mac_threshold;
-        WS(L.cnt, "enc.cnt", 4ull * n_bin);
-        WS(L.kind, "enc.kind", (size_t)n_bin);
-        HIP_TRY(hipMemsetAsync(L.kind, 0, n_bin, s));
-        stage_mark(ctx, XSI_ST_COUNT);
-        HIP_TRY(launch_count_rows(s, L.planes, L.plane_stride_w, N, n_bin, L.cnt));
+        L.cnt = cnt_all + l0;
+        L.kind = kind_all + l0;
+        L.y_rows = rows ? (uint32_t)rows : 1u;
         EncSide S{};
         xsi_encode_result r{};
         if (region_off > out_capacity) return set_error(XSI_ERR_CAPACITY, "encode: output capacity exhausted");
@@ -451,6 +482,7 @@ int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const vo
         total.n_wah_lines += r.n_wah_lines;
         total.max_ploidy = r.max_ploidy;
         total.last_block_bytes = r.last_block_bytes;
+        b0 += nb;
     }
     total.blocks_bytes = region_off;
     if (h_result) *h_result = total;

@@ -114,6 +114,31 @@ __global__ void __launch_bounds__(256) k_count_rows_v4(const uint4* __restrict__
     }
 }
 
+__global__ void __launch_bounds__(256) k_wah_lines_per_block(const uint32_t* __restrict__ cnt, uint64_t n_lines,
+                                                             uint32_t block_len, uint32_t nbits, uint32_t thr,
+                                                             uint32_t* __restrict__ out) {
+    __shared__ uint32_t part[4];
+    const uint64_t l0 = (uint64_t)blockIdx.x * block_len;
+    uint32_t n = 0;
+    for (uint32_t i = threadIdx.x; i < block_len && l0 + i < n_lines; i += 256u) {
+        const uint32_t c = cnt[l0 + i];
+        const uint32_t minor = c < nbits - c ? c : nbits - c;
+        n += minor > thr ? 1u : 0u;  // the rule of k_classify on fully called diploid lines
+    }
+    const uint32_t inc = wave_scan_incl_dpp(n);
+    if (lane_id() == 63u) part[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+hipError_t launch_wah_lines_per_block(hipStream_t s, const uint32_t* cnt, uint64_t n_lines, uint32_t block_len, uint32_t nbits,
+                                      uint32_t thr, uint32_t* out) {
+    const uint64_t n_blocks = (n_lines + block_len - 1) / block_len;
+    if (!n_blocks) return hipSuccess;
+    k_wah_lines_per_block<<<dim3((uint32_t)n_blocks), dim3(256), 0, s>>>(cnt, n_lines, block_len, nbits, thr, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_count_rows(hipStream_t s, const uint32_t* planes, uint32_t stride_w, uint32_t nbits,
                              uint32_t n_rows, uint32_t* cnt) {
     if (!n_rows) return hipSuccess;

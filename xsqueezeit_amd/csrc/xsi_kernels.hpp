@@ -33,6 +33,7 @@ struct EncLines {
     uint32_t* wah_off;          // word offset inside the block's WAH matrix (by batch-wide rank)
     uint64_t* yrows;            // permuted bit rows, one per WAH line (by batch-wide rank)
     uint32_t y_stride64;
+    uint32_t y_rows;            // rows to provide for: the batch's WAH lines when known beforehand, else 0 (= n_bin)
     uint16_t* wah_scratch;      // [rank][wah_scratch_stride] WAH16 words of each line (encoded once, copied to place)
     uint32_t wah_scratch_stride;
     uint32_t* flagbits;         // [n_blocks][FV_COUNT][MAX_BIN_PER_BLOCK/32] packed flag vectors
@@ -61,6 +62,9 @@ struct EncSide {
     uint32_t strategy;            // WS_SPARSE or WS_WAH
 };
 
+// WAH lines (minor allele count above the threshold) of every block_len lines, from the per-line counts
+hipError_t launch_wah_lines_per_block(hipStream_t s, const uint32_t* cnt, uint64_t n_lines, uint32_t block_len, uint32_t nbits,
+                                      uint32_t thr, uint32_t* out);
 hipError_t launch_count_rows(hipStream_t s, const uint32_t* planes, uint32_t stride_w, uint32_t nbits,
                              uint32_t n_rows, uint32_t* cnt);
 hipError_t launch_classify(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, const EncLines& L);
