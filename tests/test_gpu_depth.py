@@ -36,12 +36,16 @@ def _device_synth(n_haps, n_lines, seed):
 
 @pytest.mark.parametrize("n_haps,n_lines,thr,kernels", [
     (64976, 8192, 64, ("k_chain_rank_enc", "k_chain_decode_rank_big")),   # BASELINE configs[2] shape, one whole block
-    (200000, 2048, 200, ("k_chain_stream", "k_chain_decode_rank_big")),   # configs[4] haplotype count
-    (500000, 2048, 500, ("k_chain_stream", "k_chain_decode_rank_big")),   # configs[3] haplotype count
+    (200000, 2048, 200, ("k_chain_rank_enc_multi", "k_chain_decode_rank_big")),   # configs[4] haplotype count: 4 workgroups per block
+    (500000, 2048, 500, ("k_chain_rank_enc_multi", "k_chain_decode_rank_big")),   # configs[3] haplotype count: 8 workgroups per block
+    (200000, 1024, 200, ("k_chain_stream", "k_chain_decode_rank_big")),           # the position-major streaming chain (forced)
+    (600000, 512, 600, ("k_chain_stream", "k_chain_decode_rank_big")),            # above the multi-workgroup kernel's range
 ])
-def test_full_depth_block_against_oracle(n_haps, n_lines, thr, kernels):
+def test_full_depth_block_against_oracle(n_haps, n_lines, thr, kernels, monkeypatch):
     import gpu_util as G
     L = binding.lib()
+    if kernels[0] == "k_chain_stream" and n_haps <= 524288:
+        monkeypatch.setenv("XSI_NO_RANKENC_MULTI", "1")
     assert L.xsi_hip_chain_kernel(n_haps, 1, 0).decode() == kernels[0]
     assert L.xsi_hip_chain_kernel(n_haps, 1, 1).decode() == kernels[1]
     bits, packed, stride = _device_synth(n_haps, n_lines, 43)

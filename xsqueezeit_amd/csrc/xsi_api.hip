@@ -282,6 +282,13 @@ int pinned_ensure(xsi_hip_ctx* c, size_t bytes, void** out) {
 
 // Shared tail of both encode entry points: everything after the per-line bit planes, counts
 // and kinds exist.  Lines/side describe the batch; blocks_h holds the host-filled part.
+// 8-byte words per permuted row: rows above 8 KiB start on 128-byte lines of their own (the chain over several
+// workgroups per block reads a row while the next one is being written by others)
+static uint32_t y_stride64_for(uint32_t N) {
+    const uint32_t w = (N + 63u) / 64u;
+    return N > 65536u ? (w + 15u) & ~15u : w;
+}
+
 int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide S, std::vector<EncBlock>& blocks_h,
                void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result,
                uint64_t region_offset, bool use_wah_scratch) {
@@ -298,9 +305,11 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     WS(L.wah_lines, "enc.wah_lines", 4ull * n_bin);
     WS(L.wah_len, "enc.wah_len", 4ull * n_bin);
     WS(L.wah_off, "enc.wah_off", 4ull * n_bin);
-    L.y_stride64 = (N + 63u) / 64u;
+    L.y_stride64 = y_stride64_for(N);
     const size_t y_rows = L.y_rows ? L.y_rows : n_bin;  // one per WAH line: exact when the caller counted them
     WS(L.yrows, "enc.yrows", 8ull * L.y_stride64 * y_rows);
+    L.y_rows_alloc = y_rows;
+    WS(L.chain_sync, "enc.chain_sync", 4ull * CHAIN_SYNC_WORDS);
     // WAH16 words per line, worst case ceil(N/15) (+1 for the saturation split): encode once, then copy
     L.wah_scratch_stride = ((N + 14u) / 15u + 3u) & ~1u;  // even: rows stay 4-byte aligned for k_wah_write
     L.wah_scratch = nullptr;  // without it the lines are sized first and encoded again straight into place
@@ -361,9 +370,12 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     }
     stage_mark(ctx, -1);
     uint64_t res[5];
+    uint32_t chain_abort = 0;
     HIP_TRY(hipMemcpyAsync(res, d_result, sizeof(res), hipMemcpyDeviceToHost, s));
+    if (chain_rank_enc_multi_supported(L)) HIP_TRY(hipMemcpyAsync(&chain_abort, L.chain_sync, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     stage_collect(ctx);
+    if (chain_abort) return set_error(XSI_ERR_HIP, "encode: the workgroups of a block failed to meet (chain over several workgroups)");
     if (res[3]) return set_error(XSI_ERR_CAPACITY, "encode: output needs %llu bytes, capacity is %llu",
                                  (unsigned long long)res[0], (unsigned long long)out_capacity);
     if (h_result) {
@@ -423,7 +435,7 @@ int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const vo
     // then sized and encoded twice), then runs as batches of whole blocks: blocks are independent
     // (gt_block.hpp:179-180, xsi_factory.hpp:527-539), so the bytes are those of a single call.
     const bool units = wah_units_ok((N + 63u) / 64u);
-    const uint64_t y_line = 8ull * ((N + 63u) / 64u), scratch_line = units ? 0 : 2ull * (((N + 14u) / 15u + 3u) & ~1u), misc_line = 40;
+    const uint64_t y_line = 8ull * y_stride64_for(N), scratch_line = units ? 0 : 2ull * (((N + 14u) / 15u + 3u) & ~1u), misc_line = 40;
     const uint64_t budget = ws_budget_now(ctx);
     uint64_t wah_all = 0;
     for (uint32_t c : wah_per_block) wah_all += c;

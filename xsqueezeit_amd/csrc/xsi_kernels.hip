@@ -1334,13 +1334,18 @@ static bool use_rank_encode(uint32_t N, uint32_t n_blocks) {
 const char* chain_kernel_name(uint32_t N, uint32_t n_blocks, bool decode) {
     if (decode) return rank_decode_kernel_name(N, ((N + 63u) / 64u) * 2u, n_blocks);
     if (use_rank_encode(N, n_blocks)) return "k_chain_rank_enc";
+    if (N > 65536u && N <= 524288u && !getenv("XSI_NO_RANKENC_MULTI")) return "k_chain_rank_enc_multi";
     return N <= 65536u ? "k_chain_lds" : "k_chain_stream";
 }
 
 hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
                                uint32_t* scratch_a, bool any_haploid) {
     bool rank_done = false;
-    if (use_rank_encode(L.N, n_blocks)) {
+    if (chain_rank_enc_multi_supported(L)) {
+        hipError_t e = launch_rank_encode_multi(s, blocks, n_blocks, L);
+        if (e != hipSuccess || !any_haploid) return e;
+        rank_done = true;  // k_chain_global below only takes the blocks with fully haploid lines
+    } else if (use_rank_encode(L.N, n_blocks)) {
         hipError_t e = launch_rank_encode(s, blocks, n_blocks, L);
         if (e != hipSuccess || !any_haploid) return e;
         rank_done = true;  // k_chain_lds below only takes the blocks with fully haploid lines

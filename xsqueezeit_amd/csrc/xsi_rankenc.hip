@@ -275,4 +275,248 @@ hipError_t launch_rank_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_
     return hipErrorInvalidValue;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// 65 536 < N <= 524 288 haplotypes: the same chain with S = ceil(N / 65536) workgroups per block.
+//
+// The position-major kernel for these sizes (k_chain_stream) moves the prefix array through HBM: 8 N bytes
+// of scattered traffic per line and block, one CU per block (696 ms for 153 blocks of 500 000 haplotypes,
+// at the HBM limit of that access pattern).  Element-major, a workgroup keeps 65 536 ranks in registers
+// and only the ROW is shared: the ones of the next line are deposited straight into its permuted row y in
+// HBM (agent-scope atomic OR; the rows are zeroed by the launch) - which is also where the WAH pass wants
+// it - the S workgroups of the block meet at a counter, and each of them then reads the whole row
+// (N / 8 bytes, sc1 loads: served from L2 / memory, never from this CU's L1) and builds the rank-select
+// table of all N positions in its own LDS (8 bytes per 32 positions: 128 KiB at 524 288).  One meeting per
+// line; a row is never written again once its meeting is over, and rows start on 128-byte lines of their
+// own, so no cache holds a stale part of a row that is about to be read.
+//
+// Every workgroup of the grid must be resident for the meetings to complete: the grid is at most one
+// workgroup per CU (LDS > 80 KiB keeps it at one), groups walk the blocks persistently, and a meeting that
+// does not complete within a few seconds raises the abort flag, which ends every workgroup of the launch.
+// Placement (speed only): blocks of the grid are dealt round-robin over the 8 XCDs, so the members of a
+// group are taken 8 apart and share an XCD's L2.
+// ------------------------------------------------------------------------------------------
+struct RankEncMultiArgs {
+    const uint32_t* wah_lines;
+    const uint32_t* src;
+    uint32_t src_stride_w;
+    uint32_t* dst;          // permuted rows y by rank, zeroed
+    uint32_t dst_stride_w;  // words per row, a multiple of 32
+    uint32_t N;
+    uint32_t n_blocks;
+    uint32_t S;             // workgroups per block
+    uint32_t gpx;           // groups per XCD slot: the grid is 8 * gpx * S workgroups
+    uint32_t* sync;         // [0] abort, [16 + g] arrivals of group g
+};
+
+template <int WPT>  // row words per thread when the table is built (a multiple of 4)
+__global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* __restrict__ eblocks, RankEncMultiArgs A) {
+    constexpr uint32_t T = 1024, W = 16;
+    constexpr int E = 64, G = 8;
+    constexpr uint32_t TAB_BYTES = T * (uint32_t)WPT * 8u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint2* table = reinterpret_cast<uint2*>(smem);
+    uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + TAB_BYTES);  // [16] wave totals, [16] meeting result
+    const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t N = A.N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    const uint32_t group = xcd * A.gpx + q / A.S, member = q % A.S, n_groups = 8u * A.gpx;
+    uint32_t* bar = A.sync + 16u + group;
+    uint32_t arrivals = 0;  // what the counter reads once every member has arrived at the current meeting
+
+    const uint32_t row_bytes = ((N + 63u) / 64u) * 8u;  // bytes of an input row that hold haplotypes
+    auto in_rsrc = [&](uint32_t line) -> v4u {
+        const uint64_t base = reinterpret_cast<uint64_t>(A.src + (size_t)line * A.src_stride_w);
+        v4u d;
+        d[0] = (uint32_t)base;
+        d[1] = (uint32_t)(base >> 32) & 0xFFFFu;
+        d[2] = row_bytes;
+        d[3] = 0x00020000u;
+        return d;
+    };
+    // all members of the group have made their deposits into the row: true; false = the launch is aborting
+    auto meet = [&]() -> bool {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics have been performed
+        __syncthreads();
+        arrivals += A.S;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t ok = 1u, spins = 0;
+            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals) {
+                if (++spins > (1u << 21) || ((spins & 63u) == 0u && __hip_atomic_load(A.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(A.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            wtot[16] = ok;
+        }
+        lds_barrier();
+        return wtot[16] != 0u;
+    };
+    // rank-select table of the whole row `rank` in LDS; returns the row's zeros
+    auto build_table = [&](uint32_t rank) -> uint32_t {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(A.dst + (size_t)rank * A.dst_stride_w), 0, (int)(A.dst_stride_w * 4u), 0x00020000);
+        v4u v[WPT / 4];
+#pragma unroll
+        for (int i = 0; i < WPT / 4; ++i)  // sc1: past this CU's L1; beyond the row: zeros (range check)
+            v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid * (uint32_t)WPT + 4u * (uint32_t)i) * 4u, 0, 16);
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < WPT / 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c += (uint32_t)__popc(v[i][k]);
+        const uint32_t inc = wave_scan_incl_dpp(c);
+        if (lane == 63u) wtot[w] = inc;
+        lds_barrier();  // also: every wave is done with the previous table (the meeting's barriers came first)
+        const uint32_t sc = row16_scan_incl(lane < W ? wtot[lane] : 0u);
+        const uint32_t ones = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
+        const uint32_t base = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
+        uint32_t pre = base + inc - c;
+#pragma unroll
+        for (int i = 0; i < WPT / 4; ++i) {
+            const uint32_t p0 = pre, p1 = p0 + (uint32_t)__popc(v[i][0]), p2 = p1 + (uint32_t)__popc(v[i][1]),
+                           p3 = p2 + (uint32_t)__popc(v[i][2]);
+            pre = p3 + (uint32_t)__popc(v[i][3]);
+            uint4* t4 = reinterpret_cast<uint4*>(table + (size_t)tid * WPT + 4 * i);
+            t4[0] = make_uint4(v[i][0], p0, v[i][1], p1);
+            t4[1] = make_uint4(v[i][2], p2, v[i][3], p3);
+        }
+        lds_barrier();
+        return N - ones;
+    };
+
+    const uint32_t c0 = member * 1024u + w * (uint32_t)E;  // my first chunk of the row
+    for (uint32_t blk = group; blk < A.n_blocks; blk += n_groups) {
+        const EncBlock& B = eblocks[blk];
+        if (B.has_haploid) continue;  // the position-major kernels take the blocks with fully haploid lines
+        const uint32_t wah_first = B.wah_first, n_wah = B.n_wah;
+        if (n_wah == 0) continue;
+        const ConstU32* lines = as_const(A.wah_lines) + wah_first;
+        auto deposit = [&](uint64_t xm, uint32_t rr, uint32_t* row) {
+            if (xm) {
+                if (__builtin_amdgcn_inverse_ballot_w64(xm)) {
+                    asm volatile("" : "+v"(rr));  // the address is formed here, not hoisted for all 64 chunks at once
+                    __hip_atomic_fetch_or(row + (rr >> 5), 1u << (rr & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+        // line 0: ranks are the identity, its row is the input row itself
+        {
+            const v4u rs0 = in_rsrc(lines[0]);
+            uint32_t* row0 = A.dst + (size_t)wah_first * A.dst_stride_w;
+            static_for<0, E / G>([&](auto gc) {
+                constexpr int g0 = decltype(gc)::value * G;
+                uint64_t x0[G];
+                sbuf_load_chunks<G>(rs0, c0 + (uint32_t)g0, x0);
+                static_for<0, G>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    deposit(x0[e], (c0 + (uint32_t)(g0 + e)) * 64u + lane, row0);  // bits at or beyond N are zero
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        if (!meet()) return;
+        uint32_t Z = build_table(wah_first);
+        uint32_t r[E];
+        uint32_t lane_here = lane;
+        asm volatile("" : "+v"(lane_here));  // the identity ranks are formed here, not kept across the blocks
+        static_for<0, E>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            const uint32_t h = (c0 + (uint32_t)e) * 64u + lane_here;
+            r[e] = h < N ? h : 0u;
+        });
+        auto prefetch_row = [&](uint32_t line) -> uint2 {  // my workgroup's 8 KiB of the input row, into L2
+            const uint2* rowp = reinterpret_cast<const uint2*>(A.src + (size_t)line * A.src_stride_w) + member * 1024u;
+            return (member * 1024u + tid) * 8u < row_bytes ? rowp[tid] : make_uint2(0u, 0u);
+        };
+        for (uint32_t j = 0; j < n_wah; ++j) {
+            const bool more = j + 1u < n_wah;
+            const uint2 pf = prefetch_row(lines[j + 2u < n_wah ? j + 2u : j]);
+            const v4u rsc = in_rsrc(lines[j]);
+            v4u rsn = in_rsrc(lines[more ? j + 1u : j]);
+            if (!more) rsn[2] = 0;  // nothing follows the block's last line: an empty range reads as zeros, no deposits
+            uint32_t* rown = A.dst + (size_t)(wah_first + j + 1u) * A.dst_stride_w;
+            static_for<0, E / G>([&](auto gc) {
+                constexpr int g0 = decltype(gc)::value * G;
+                uint64_t xc[G], xn[G];
+                u32x2 pr[G];
+                sbuf_load_chunks<G>(rsc, c0 + (uint32_t)g0, xc);
+                sbuf_load_chunks<G>(rsn, c0 + (uint32_t)g0, xn);
+                static_for<0, G>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    pr[e] = *reinterpret_cast<const LdsU2*>((uintptr_t)(((r[g0 + e] >> 2) & 0x1FFF8u) + tab_lds));
+                });
+                static_for<0, G>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    const uint32_t rr = r[g0 + e];
+                    const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
+                    const uint32_t rn = __builtin_amdgcn_inverse_ballot_w64(xc[e]) ? Z + ob : rr - ob;
+                    r[g0 + e] = rn;
+                    deposit(xn[e], rn, rown);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            asm volatile("" ::"v"(pf.x), "v"(pf.y));
+            if (more) {
+                if (!meet()) return;
+                Z = build_table(wah_first + j + 1u);
+            }
+        }
+        __syncthreads();  // the next block's first table must not overtake this block's last gathers
+    }
+}
+
+bool chain_rank_enc_multi_supported(const EncLines& L) {
+    const bool off = getenv("XSI_NO_RANKENC_MULTI") != nullptr;  // read per call (tests force the other kernel)
+    return !off && L.chain_sync && L.N > 65536u && L.N <= 524288u && (L.y_stride64 % 16u) == 0u && L.y_rows_alloc;
+}
+
+hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L) {
+    if (!n_blocks) return hipSuccess;
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    RankEncMultiArgs A{};
+    A.wah_lines = L.wah_lines;
+    A.src = L.planes;
+    A.src_stride_w = L.plane_stride_w;
+    A.dst = reinterpret_cast<uint32_t*>(L.yrows);
+    A.dst_stride_w = L.y_stride64 * 2u;
+    A.N = L.N;
+    A.n_blocks = n_blocks;
+    A.S = (L.N + 65535u) / 65536u;
+    A.gpx = (uint32_t)cus / 8u / A.S;
+    if (A.gpx < 1u || 8u * A.gpx > CHAIN_SYNC_WORDS - 16u) return hipErrorInvalidValue;
+    while (A.gpx > 1u && 8u * (A.gpx - 1u) >= n_blocks) --A.gpx;  // no more groups than blocks need
+    A.sync = L.chain_sync;
+    const uint32_t wpt = ((A.dst_stride_w + 1023u) / 1024u + 3u) & ~3u;  // 4, 8, 12 or 16
+    e = hipMemsetAsync(L.chain_sync, 0, 4ull * CHAIN_SYNC_WORDS, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(L.yrows, 0, 8ull * L.y_stride64 * L.y_rows_alloc, s);
+    if (e != hipSuccess) return e;
+    const dim3 grid(8u * A.gpx * A.S);
+#define XSI_REM_CASE(WW)                                                                                  \
+    if (wpt == WW) {                                                                                      \
+        const uint32_t lds = 1024u * WW * 8u + 256u;                                                      \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_rank_enc_multi<WW>),               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+        if (e != hipSuccess) return e;                                                                    \
+        k_chain_rank_enc_multi<WW><<<grid, dim3(1024), lds, s>>>(blocks, A);                              \
+        return hipGetLastError();                                                                         \
+    }
+    XSI_REM_CASE(4)
+    XSI_REM_CASE(8)
+    XSI_REM_CASE(12)
+    XSI_REM_CASE(16)
+#undef XSI_REM_CASE
+    return hipErrorInvalidValue;
+}
+
 }  // namespace xsi
