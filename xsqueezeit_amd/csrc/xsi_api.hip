@@ -282,11 +282,10 @@ int pinned_ensure(xsi_hip_ctx* c, size_t bytes, void** out) {
 
 // Shared tail of both encode entry points: everything after the per-line bit planes, counts
 // and kinds exist.  Lines/side describe the batch; blocks_h holds the host-filled part.
-// 8-byte words per permuted row: rows above 8 KiB start on 128-byte lines of their own (the chain over several
-// workgroups per block reads a row while the next one is being written by others)
+// 8-byte words per permuted row
 static uint32_t y_stride64_for(uint32_t N) {
     const uint32_t w = (N + 63u) / 64u;
-    return N > 65536u ? (w + 15u) & ~15u : w;
+    return N > 65536u ? (w + 1u) & ~1u : w;  // rows of whole 16-byte units: the chain over several workgroups stores them so
 }
 
 int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide S, std::vector<EncBlock>& blocks_h,
@@ -308,8 +307,10 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     L.y_stride64 = y_stride64_for(N);
     const size_t y_rows = L.y_rows ? L.y_rows : n_bin;  // one per WAH line: exact when the caller counted them
     WS(L.yrows, "enc.yrows", 8ull * L.y_stride64 * y_rows);
-    L.y_rows_alloc = y_rows;
-    WS(L.chain_sync, "enc.chain_sync", 4ull * CHAIN_SYNC_WORDS);
+    if (N > 65536u && N <= 524288u) {  // the chain over several workgroups per block
+        WS(L.chain_sync, "enc.chain_sync", 4ull * (CHAIN_SYNC_WORDS + CHAIN_MAX_WGS * 2u * 16u));
+        WS(L.chain_lists, "enc.chain_lists", 4ull * CHAIN_LIST_WORDS);
+    }
     // WAH16 words per line, worst case ceil(N/15) (+1 for the saturation split): encode once, then copy
     L.wah_scratch_stride = ((N + 14u) / 15u + 3u) & ~1u;  // even: rows stay 4-byte aligned for k_wah_write
     L.wah_scratch = nullptr;  // without it the lines are sized first and encoded again straight into place

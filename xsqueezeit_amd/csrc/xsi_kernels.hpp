@@ -34,10 +34,11 @@ struct EncLines {
     uint64_t* yrows;            // permuted bit rows, one per WAH line (by batch-wide rank)
     uint32_t y_stride64;
     uint32_t y_rows;            // rows to provide for: the batch's WAH lines when known beforehand, else 0 (= n_bin)
-    // chain over several workgroups per block (N > 65536): [0] abort flag, [16 + g] arrivals of group g;
-    // nullptr = not available to this call.  y_rows_alloc = rows of yrows that exist (zeroed by the launch).
+    // chain over several workgroups per block (N > 65536), nullptr = not available to this call:
+    // chain_sync  [0] abort flag, [16 + g] arrivals of group g, [CHAIN_SYNC_WORDS ..] list counts
+    // chain_lists per-wave rank lists, CHAIN_LIST_WORDS words
     uint32_t* chain_sync;
-    uint64_t y_rows_alloc;
+    uint32_t* chain_lists;
     uint16_t* wah_scratch;      // [rank][wah_scratch_stride] WAH16 words of each line (encoded once, copied to place)
     uint32_t wah_scratch_stride;
     uint32_t* flagbits;         // [n_blocks][FV_COUNT][MAX_BIN_PER_BLOCK/32] packed flag vectors
@@ -151,6 +152,8 @@ bool chain_rank_enc_supported(uint32_t N);
 hipError_t launch_rank_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L);
 // 65 536 < N <= 524 288: several workgroups per block (xsi_rankenc.hip)
 constexpr uint32_t CHAIN_SYNC_WORDS = 16u + 256u;
+constexpr uint32_t CHAIN_MAX_WGS = 256u;  // workgroups of the launch (one per CU)
+constexpr uint64_t CHAIN_LIST_WORDS = (uint64_t)CHAIN_MAX_WGS * 2u * 16u * 4096u;
 bool chain_rank_enc_multi_supported(const EncLines& L);
 hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L);
 

@@ -28,6 +28,7 @@
 // Bits at or beyond N never enter a row; lanes beyond N idle on rank 0.
 #include "xsi_kernels.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -282,31 +283,40 @@ hipError_t launch_rank_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_
 // The position-major kernel for these sizes (k_chain_stream) moves the prefix array through HBM: 8 N bytes
 // of scattered traffic per line and block, one CU per block (696 ms for 153 blocks of 500 000 haplotypes,
 // at the HBM limit of that access pattern).  Element-major, a workgroup keeps 65 536 ranks in registers
-// and only the ROW is shared: the ones of the next line are deposited straight into its permuted row y in
-// HBM (agent-scope atomic OR; the rows are zeroed by the launch) - which is also where the WAH pass wants
-// it - the S workgroups of the block meet at a counter, and each of them then reads the whole row
-// (N / 8 bytes, sc1 loads: served from L2 / memory, never from this CU's L1) and builds the rank-select
-// table of all N positions in its own LDS (8 bytes per 32 positions: 128 KiB at 524 288).  One meeting per
-// line; a row is never written again once its meeting is over, and rows start on 128-byte lines of their
-// own, so no cache holds a stale part of a row that is about to be read.
+// and holds the rank-select table of ALL N positions in its LDS (8 bytes per 32 positions: 128 KiB at
+// 524 288); what the S workgroups of a block exchange per line is only where the ONES of the next line go:
+//   M  main phase as in k_chain_rank_enc, but a lane whose next-line bit is set APPENDS its new rank to its
+//      wave's list in HBM (sc1 stores; the wave's count follows);
+//      -- the workgroups of the block meet at a counter (one meeting per line) --
+//   A  every workgroup clears the bit words of its table, reads the lists of all 16 S waves (sc1 loads) and
+//      sets the bits (LDS atomic OR): each ends up with the whole permuted row y;
+//   B  popcounts + scan over the 16 K words -> the "ones before" half of the table; workgroup m also stores
+//      its 1/S of the row to HBM for the WAH pass.
+// Depositing with agent-scope atomics straight into the row in HBM (the first version of this kernel) was
+// correct and 3.6x SLOWER than k_chain_stream: 3e10 atomics per launch at the 12 G atomics/s the memory side
+// sustains.  The lists are double-buffered by line parity (a workgroup may be one meeting ahead).
 //
 // Every workgroup of the grid must be resident for the meetings to complete: the grid is at most one
-// workgroup per CU (LDS > 80 KiB keeps it at one), groups walk the blocks persistently, and a meeting that
-// does not complete within a few seconds raises the abort flag, which ends every workgroup of the launch.
+// workgroup per CU, groups walk the blocks persistently, and a meeting that does not complete within a few
+// seconds raises the abort flag, which ends every workgroup of the launch (the call then fails).
 // Placement (speed only): blocks of the grid are dealt round-robin over the 8 XCDs, so the members of a
 // group are taken 8 apart and share an XCD's L2.
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t MULTI_LIST_CAP = 4096u;  // ranks per wave and line: every one of its 64 x 64 haplotypes
+
 struct RankEncMultiArgs {
     const uint32_t* wah_lines;
     const uint32_t* src;
     uint32_t src_stride_w;
-    uint32_t* dst;          // permuted rows y by rank, zeroed
-    uint32_t dst_stride_w;  // words per row, a multiple of 32
+    uint32_t* dst;          // permuted rows y by rank
+    uint32_t dst_stride_w;  // words per row
     uint32_t N;
     uint32_t n_blocks;
     uint32_t S;             // workgroups per block
     uint32_t gpx;           // groups per XCD slot: the grid is 8 * gpx * S workgroups
     uint32_t* sync;         // [0] abort, [16 + g] arrivals of group g
+    uint32_t* lists;        // [group][parity][S * 16 waves][MULTI_LIST_CAP] ranks, whole 64-entry stores (padding: ~0)
+    uint32_t* counts;       // [group][parity][S * 16] entries of each list
 };
 
 template <int WPT>  // row words per thread when the table is built (a multiple of 4)
@@ -317,14 +327,19 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2* table = reinterpret_cast<uint2*>(smem);
     uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + TAB_BYTES);  // [16] wave totals, [16] meeting result
+    uint32_t* ring_all = wtot + 64;                                 // [16 waves][128] ranks on their way to the lists
     const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint32_t N = A.N;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
     const uint32_t group = xcd * A.gpx + q / A.S, member = q % A.S, n_groups = 8u * A.gpx;
+    const uint32_t n_lists = A.S * W;
     uint32_t* bar = A.sync + 16u + group;
+    uint32_t* glists = A.lists + (size_t)group * 2u * n_lists * MULTI_LIST_CAP;
+    uint32_t* gcounts = A.counts + (size_t)group * 2u * n_lists;
     uint32_t arrivals = 0;  // what the counter reads once every member has arrived at the current meeting
+    uint32_t parity = 0;
 
     const uint32_t row_bytes = ((N + 63u) / 64u) * 8u;  // bytes of an input row that hold haplotypes
     auto in_rsrc = [&](uint32_t line) -> v4u {
@@ -336,9 +351,9 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
         d[3] = 0x00020000u;
         return d;
     };
-    // all members of the group have made their deposits into the row: true; false = the launch is aborting
+    // all members of the group have published their lists: true; false = the launch is aborting
     auto meet = [&]() -> bool {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics have been performed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores have left
         __syncthreads();
         arrivals += A.S;
         if (tid == 0) {
@@ -357,35 +372,94 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
         lds_barrier();
         return wtot[16] != 0u;
     };
-    // rank-select table of the whole row `rank` in LDS; returns the row's zeros
-    auto build_table = [&](uint32_t rank) -> uint32_t {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(A.dst + (size_t)rank * A.dst_stride_w), 0, (int)(A.dst_stride_w * 4u), 0x00020000);
-        v4u v[WPT / 4];
+    // phases A + B: the lists of parity `par` -> row `rank` in the table (and my share of it in HBM); returns the zeros
+    auto build_table = [&](uint32_t rank, uint32_t par) -> uint32_t {
+        // every wave is done with the previous table (the meeting's barriers came first): clear its bit words
+        // (thread t works on entries i * 1024 + t: neighbouring lanes on neighbouring entries, no bank conflicts;
+        // 16 entries in a row per thread put all 64 lanes of an access on two banks)
 #pragma unroll
-        for (int i = 0; i < WPT / 4; ++i)  // sc1: past this CU's L1; beyond the row: zeros (range check)
-            v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid * (uint32_t)WPT + 4u * (uint32_t)i) * 4u, 0, 16);
-        uint32_t c = 0;
+        for (int i = 0; i < WPT; ++i) table[(size_t)i * T + tid] = make_uint2(0u, 0u);
+        lds_barrier();
+        const uint32_t* lst = glists + (size_t)par * n_lists * MULTI_LIST_CAP;
+        // wave w applies lists w * S .. w * S + S - 1.  The loads are sc1 round trips to L2 / memory: the counts of
+        // all of them come in one load, then four 16-byte loads per lane are in flight before any is used.
+        // (Fetching the first KiB of every list blind, with the count in a header, measured no faster: 485 / 468 ms.)
+        constexpr int SMAX = 8;  // N <= 524 288
+        const uint32_t* cnts = gcounts + (size_t)par * n_lists;
+        const uint32_t cnt_l = lane < A.S ? __hip_atomic_load(cnts + w * A.S + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        uint32_t cnt[SMAX], longest = 0;
 #pragma unroll
-        for (int i = 0; i < WPT / 4; ++i)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) c += (uint32_t)__popc(v[i][k]);
-        const uint32_t inc = wave_scan_incl_dpp(c);
-        if (lane == 63u) wtot[w] = inc;
-        lds_barrier();  // also: every wave is done with the previous table (the meeting's barriers came first)
-        const uint32_t sc = row16_scan_incl(lane < W ? wtot[lane] : 0u);
-        const uint32_t ones = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
-        const uint32_t base = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
-        uint32_t pre = base + inc - c;
-#pragma unroll
-        for (int i = 0; i < WPT / 4; ++i) {
-            const uint32_t p0 = pre, p1 = p0 + (uint32_t)__popc(v[i][0]), p2 = p1 + (uint32_t)__popc(v[i][1]),
-                           p3 = p2 + (uint32_t)__popc(v[i][2]);
-            pre = p3 + (uint32_t)__popc(v[i][3]);
-            uint4* t4 = reinterpret_cast<uint4*>(table + (size_t)tid * WPT + 4 * i);
-            t4[0] = make_uint4(v[i][0], p0, v[i][1], p1);
-            t4[1] = make_uint4(v[i][2], p2, v[i][3], p3);
+        for (int k = 0; k < SMAX; ++k) {
+            cnt[k] = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, k);
+            longest = cnt[k] > longest ? cnt[k] : longest;
         }
+        for (uint32_t i0 = 0; i0 < longest; i0 += 256u) {
+#pragma unroll
+            for (int h = 0; h < SMAX; h += 4) {
+                v4u rk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // lists are whole 64-entry stores; beyond a list the range check returns 0, not used below
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(lst + (size_t)(w * A.S + (uint32_t)(h + k)) * MULTI_LIST_CAP), 0, (int)(cnt[h + k] * 4u), 0x00020000);
+                    rk[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (i0 + lane * 4u) * 4u, 0, 16);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool in = i0 + lane * 4u < cnt[h + k];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (in && rk[k][u] != ~0u) {
+                            LdsU32* p = reinterpret_cast<LdsU32*>((uintptr_t)(((rk[k][u] >> 2) & 0x1FFF8u) + tab_lds));
+                            __hip_atomic_fetch_or(p, 1u << (rk[k][u] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                }
+            }
+        }
+        lds_barrier();
+        // stripe i = entries [1024 i, 1024 i + 1024): a wave scan per stripe, then the 16 x WPT (wave, stripe) totals
+        // are scanned in row order by wave 0
+        uint32_t* tot = ring_all;  // [WPT][16]: the rings are idle between the main phases
+        {
+            uint32_t* row = A.dst + (size_t)rank * A.dst_stride_w;
+            uint32_t tid_here = tid;
+            asm volatile("" : "+v"(tid_here));  // store addresses are formed here, not kept (spilled) across the lines
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const uint32_t v = table[(size_t)i * T + tid].x;
+                // my share of the row for the WAH pass: stripes m, m + S, ... (4 KiB each, whole 256-byte stores)
+                if ((uint32_t)i % A.S == member && (uint32_t)i * T + tid_here < A.dst_stride_w) row[(uint32_t)i * T + tid_here] = v;
+                const uint32_t c = (uint32_t)__popc(v);
+                const uint32_t inc = wave_scan_incl_dpp(c);
+                table[(size_t)i * T + tid].y = inc - c;  // ones of my stripe before my entry; the stripe's base follows
+                if (lane == 63u) tot[i * (int)W + (int)w] = inc;
+            }
+        }
+        lds_barrier();
+        if (w == 0) {  // exclusive scan of the WPT * 16 totals, 4 (= WPT * 16 / 64, at most) per lane, in order
+            constexpr int PER = (WPT * (int)W + 63) / 64;
+            uint32_t a[PER], sum = 0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const uint32_t idx = lane * (uint32_t)PER + (uint32_t)k;
+                a[k] = idx < (uint32_t)WPT * W ? tot[idx] : 0u;
+                sum += a[k];
+            }
+            uint32_t run = wave_scan_incl_dpp(sum) - sum;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const uint32_t idx = lane * (uint32_t)PER + (uint32_t)k;
+                if (idx < (uint32_t)WPT * W) tot[idx] = run;
+                run += a[k];
+            }
+            if (lane == 63u) wtot[17] = run;  // ones of the row
+        }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>((uintptr_t)(tab_lds + ((uint32_t)i * T + tid) * 8u + 4u)), tot[i * (int)W + (int)w],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t ones = wtot[17];
         lds_barrier();
         return N - ones;
     };
@@ -397,31 +471,55 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
         const uint32_t wah_first = B.wah_first, n_wah = B.n_wah;
         if (n_wah == 0) continue;
         const ConstU32* lines = as_const(A.wah_lines) + wah_first;
-        auto deposit = [&](uint64_t xm, uint32_t rr, uint32_t* row) {
+        // Ranks on their way to my wave's list pass through a 128-entry ring in LDS, so that they leave as whole
+        // 256-byte stores (a store of one to three lanes per chunk is one fabric write per lane).
+        uint32_t n_app = 0, n_out = 0;  // ranks appended / already stored, for the line in the making (wave-uniform)
+        uint32_t* my_list = glists + ((size_t)parity * n_lists + member * W + w) * MULTI_LIST_CAP;
+        uint32_t* ring = ring_all + w * 128u;
+        auto flush64 = [&]() {
+            __hip_atomic_store(my_list + n_out + lane, ring[(n_out + lane) & 127u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            n_out += 64u;
+        };
+        auto append = [&](uint64_t xm, uint32_t rr) {
             if (xm) {
                 if (__builtin_amdgcn_inverse_ballot_w64(xm)) {
-                    asm volatile("" : "+v"(rr));  // the address is formed here, not hoisted for all 64 chunks at once
-                    __hip_atomic_fetch_or(row + (rr >> 5), 1u << (rr & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("" : "+v"(rr));  // the slot is formed here, not hoisted for all 64 chunks at once
+                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(xm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)xm, n_app));
+                    ring[slot & 127u] = rr;
                 }
+                n_app += (uint32_t)__popcll(xm);
+                if (n_app - n_out >= 64u) flush64();
             }
+        };
+        // the rest of the list, padded to whole 64-entry stores with entries that mean nothing (~0), and its length
+        auto publish = [&]() {
+            if (n_app != n_out) {
+                const uint32_t left = n_app - n_out;
+                __hip_atomic_store(my_list + n_out + lane, lane < left ? ring[(n_out + lane) & 127u] : ~0u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                n_out += 64u;
+            }
+            if (lane == 0)
+                __hip_atomic_store(gcounts + (size_t)parity * n_lists + member * W + w, n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         // line 0: ranks are the identity, its row is the input row itself
         {
             const v4u rs0 = in_rsrc(lines[0]);
-            uint32_t* row0 = A.dst + (size_t)wah_first * A.dst_stride_w;
             static_for<0, E / G>([&](auto gc) {
                 constexpr int g0 = decltype(gc)::value * G;
                 uint64_t x0[G];
                 sbuf_load_chunks<G>(rs0, c0 + (uint32_t)g0, x0);
                 static_for<0, G>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
-                    deposit(x0[e], (c0 + (uint32_t)(g0 + e)) * 64u + lane, row0);  // bits at or beyond N are zero
+                    append(x0[e], (c0 + (uint32_t)(g0 + e)) * 64u + lane);  // bits at or beyond N are zero
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
+            publish();
         }
         if (!meet()) return;
-        uint32_t Z = build_table(wah_first);
+        uint32_t Z = build_table(wah_first, parity);
+        parity ^= 1u;
         uint32_t r[E];
         uint32_t lane_here = lane;
         asm volatile("" : "+v"(lane_here));  // the identity ranks are formed here, not kept across the blocks
@@ -439,8 +537,10 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
             const uint2 pf = prefetch_row(lines[j + 2u < n_wah ? j + 2u : j]);
             const v4u rsc = in_rsrc(lines[j]);
             v4u rsn = in_rsrc(lines[more ? j + 1u : j]);
-            if (!more) rsn[2] = 0;  // nothing follows the block's last line: an empty range reads as zeros, no deposits
-            uint32_t* rown = A.dst + (size_t)(wah_first + j + 1u) * A.dst_stride_w;
+            if (!more) rsn[2] = 0;  // nothing follows the block's last line: an empty range reads as zeros, no appends
+            n_app = 0;
+            n_out = 0;
+            my_list = glists + ((size_t)parity * n_lists + member * W + w) * MULTI_LIST_CAP;
             static_for<0, E / G>([&](auto gc) {
                 constexpr int g0 = decltype(gc)::value * G;
                 uint64_t xc[G], xn[G];
@@ -457,14 +557,16 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                     const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
                     const uint32_t rn = __builtin_amdgcn_inverse_ballot_w64(xc[e]) ? Z + ob : rr - ob;
                     r[g0 + e] = rn;
-                    deposit(xn[e], rn, rown);
+                    append(xn[e], rn);
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
             asm volatile("" ::"v"(pf.x), "v"(pf.y));
             if (more) {
+                publish();
                 if (!meet()) return;
-                Z = build_table(wah_first + j + 1u);
+                Z = build_table(wah_first + j + 1u, parity);
+                parity ^= 1u;
             }
         }
         __syncthreads();  // the next block's first table must not overtake this block's last gathers
@@ -473,7 +575,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
 
 bool chain_rank_enc_multi_supported(const EncLines& L) {
     const bool off = getenv("XSI_NO_RANKENC_MULTI") != nullptr;  // read per call (tests force the other kernel)
-    return !off && L.chain_sync && L.N > 65536u && L.N <= 524288u && (L.y_stride64 % 16u) == 0u && L.y_rows_alloc;
+    return !off && L.chain_sync && L.chain_lists && L.N > 65536u && L.N <= 524288u && (L.y_stride64 % 2u) == 0u;
 }
 
 hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L) {
@@ -496,15 +598,16 @@ hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint3
     if (A.gpx < 1u || 8u * A.gpx > CHAIN_SYNC_WORDS - 16u) return hipErrorInvalidValue;
     while (A.gpx > 1u && 8u * (A.gpx - 1u) >= n_blocks) --A.gpx;  // no more groups than blocks need
     A.sync = L.chain_sync;
+    A.counts = L.chain_sync + CHAIN_SYNC_WORDS;
+    A.lists = L.chain_lists;
+    if (8u * A.gpx * A.S > CHAIN_MAX_WGS) return hipErrorInvalidValue;
     const uint32_t wpt = ((A.dst_stride_w + 1023u) / 1024u + 3u) & ~3u;  // 4, 8, 12 or 16
     e = hipMemsetAsync(L.chain_sync, 0, 4ull * CHAIN_SYNC_WORDS, s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(L.yrows, 0, 8ull * L.y_stride64 * L.y_rows_alloc, s);
     if (e != hipSuccess) return e;
     const dim3 grid(8u * A.gpx * A.S);
 #define XSI_REM_CASE(WW)                                                                                  \
     if (wpt == WW) {                                                                                      \
-        const uint32_t lds = 1024u * WW * 8u + 256u;                                                      \
+        const uint32_t lds = 1024u * WW * 8u + 256u + 16u * 128u * 4u;                                    \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_rank_enc_multi<WW>),               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
         if (e != hipSuccess) return e;                                                                    \
