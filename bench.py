@@ -41,7 +41,8 @@ CONFIGS = {
 # line as counted by SQ_INSTS_VALU (profiles/r02_pmc_sq_chains.txt; r01 for the round-1 kernels).
 SIMDS, MODEL_CLOCK_HZ, CYCLES_PER_VALU = 256 * 4, 2.4e9, 2.8
 VALU_PER_CHUNK_LINE = {"k_chain_rank_enc": 9.8, "k_chain_decode_rank_wg": 12.9, "k_chain_lds": 27.0,
-                       "k_chain_decode_rank": 14.0, "k_chain_decode_rank_big": 14.0, "k_chain_stream": 40.0}
+                       "k_chain_decode_rank": 14.0, "k_chain_decode_rank_big": 14.0, "k_chain_stream": 40.0,
+                       "k_chain_rank_enc_multi": 15.0}  # _multi: 9.8 of the main phase + the per-line table build
 
 
 def main():

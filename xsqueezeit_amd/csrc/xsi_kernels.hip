@@ -1494,7 +1494,9 @@ __global__ void __launch_bounds__(256) k_wah_units(const EncBlock* __restrict__ 
 
 bool wah_units_ok(uint32_t y_stride64) {
     static const bool off = getenv("XSI_WAH_NO_UNITS") != nullptr;
-    return !off && y_stride64 <= 64u * (uint32_t)WAH_STAGE_Q;
+    // below ~12 000 haplotypes a line has fewer than 26 units for 64 lanes: the serial encoder with its scratch
+    // copy is faster there (5008 hap x 1 M: sizing + writing 0.85 ms against 1.81 ms)
+    return !off && y_stride64 >= 192u && y_stride64 <= 64u * (uint32_t)WAH_STAGE_Q;
 }
 
 hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_total_wah, uint32_t max_wah) {
