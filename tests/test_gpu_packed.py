@@ -90,7 +90,8 @@ def test_chain_matches_numpy(n_haps, n_lines, block_len, thr):
     (200000, 10, 8, 200),
     (10000, 520, 260, 10),    # 10 chunks per wave, chain cut into line segments
     (140000, 260, 128, 140),  # streaming encode chain + LDS-staged long-row decode chain, long blocks
-    (530000, 24, 12, 530),    # > 16384 rank-select pairs per row: deepest prefetch variant
+    (530000, 24, 12, 530),    # > 16384 rank-select pairs per row: deepest prefetch variant; above the multi-workgroup encode
+    (140000, 390, 3, 140),    # 130 blocks over 80 groups of 3 workgroups: the groups' persistent walk over the blocks
 ])
 def test_encode_bit_exact_and_roundtrip(n_haps, n_lines, block_len, thr):
     import gpu_util as G
@@ -177,6 +178,7 @@ def test_capacity_error_is_reported():
 @pytest.mark.parametrize("n_haps,n_lines,block_len,thr", [
     (65534, 20, 8, 65),     # largest count with u16 A_T in header AND blocks (32767 samples)
     (131072, 10, 8, 131),   # 65536 samples: first size with u32 A_T everywhere
+    (524288, 16, 8, 524),   # largest size of the multi-workgroup encode chain: 8 workgroups, 16384-entry table
     (64, 200, 50, 0),       # exactly one wave chunk
     (66, 200, 50, 0),       # one sample past a chunk boundary
     (4096, 300, 128, 4),    # exact multiple of the chain capacity (no padding members)
