@@ -215,6 +215,8 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
     const uint32_t wah_first = D.wah_first, n_wah = D.n_wah;
     const uint32_t CWP = A.yp_stride;
     uint2* row = reinterpret_cast<uint2*>(smem);
+    const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    using LdsPairBig = __attribute__((address_space(3))) rank_u32x2;
 
     uint32_t r[E];
     static_for<0, E>([&](auto ecn) {
@@ -272,23 +274,30 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
             Z_n = A.wah_z[wah_first + j + 1u];
         }
         uint32_t mine_lo = 0, mine_hi = 0;
+        const uint32_t Zs = (uint32_t)__builtin_amdgcn_readfirstlane((int)Z);  // wave-uniform: keep it scalar
+        uint32_t tbase = tab_lds;
         static_for<0, E / G>([&](auto gcn) {
             constexpr int g0 = decltype(gcn)::value * G;
-            uint2 pr[G];
+            // pins this group's gathers behind the previous group's rank updates (see k_chain_decode_rank_wg):
+            // left alone the compiler issues the gathers of all groups first and spills
+            asm volatile("" : "+s"(tbase));
+            rank_u32x2 pr[G];
             static_for<0, G>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
-                pr[e] = row[r[g0 + e] >> 5];
+                pr[e] = *reinterpret_cast<const LdsPairBig*>((uintptr_t)(((r[g0 + e] >> 2) & 0x3FFF8u) + tbase));
             });
             static_for<0, G>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
                 const uint32_t rr = r[g0 + e];
-                const uint32_t bit = __builtin_amdgcn_ubfe(pr[e].x, rr, 1u);
-                const uint32_t ob = pr[e].y + (uint32_t)__popc(pr[e].x & ((1u << (rr & 31u)) - 1u));
-                r[g0 + e] = bit ? Z + ob : rr - ob;
+                const uint32_t bit = __builtin_amdgcn_ubfe(pr[e][0], rr, 1u);
+                const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
                 const uint64_t m = __ballot(bit != 0u);
+                r[g0 + e] = __builtin_amdgcn_inverse_ballot_w64(m) ? Zs + ob : rr - ob;
                 mine_lo = write_lane(mine_lo, (uint32_t)m, (uint32_t)(g0 + e));
                 mine_hi = write_lane(mine_hi, (uint32_t)(m >> 32), (uint32_t)(g0 + e));
             });
+#pragma unroll
+            for (int e = 0; e < G; ++e) asm volatile("" : "+v"(r[g0 + e]));  // this group's updates end here
         });
         if (store_lane) {
             uint2* orow = reinterpret_cast<uint2*>(A.out + (size_t)line * A.out_stride_w);
@@ -515,11 +524,16 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) 
         return e ? atoi(e) : 0;
     }();
     const uint32_t RP = A.yp_stride <= 8u * 1024u ? 8u : (A.yp_stride <= 16u * 1024u ? 16u : 20u);
-    const uint32_t e_max = RP == 8u ? 32u : 16u;
+    // every workgroup of a block stages the whole rank-select row of each line: the fewer workgroups per block
+    // (the more chunks per wave) the less of that, as long as the launch still fills the chip
+    const uint32_t e_max = RP == 20u ? 16u : (RP == 16u ? 32u : 64u);  // <64, 16> spills 60 VGPRs
     uint32_t E = 8;
-    if (e_max >= 32u && (uint64_t)n_blocks * splits_of(32) >= 256u) E = 32;
-    else if ((uint64_t)n_blocks * splits_of(16) >= 256u) E = 16;
-    if ((env_e == 8 || env_e == 16 || env_e == 32) && (uint32_t)env_e <= e_max) E = (uint32_t)env_e;
+    for (uint32_t e : {64u, 32u, 16u})
+        if (e <= e_max && (uint64_t)n_blocks * splits_of(e) >= 224u) {
+            E = e;
+            break;
+        }
+    if ((env_e == 8 || env_e == 16 || env_e == 32 || env_e == 64) && (uint32_t)env_e <= e_max) E = (uint32_t)env_e;
 #define XSI_BIG_CASE(EE, RR)                                                                                 \
     if (E == EE && RP == RR) {                                                                               \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank_big<EE, RR>),  \
@@ -531,8 +545,10 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) 
     XSI_BIG_CASE(8, 8)
     XSI_BIG_CASE(16, 8)
     XSI_BIG_CASE(32, 8)
+    XSI_BIG_CASE(64, 8)
     XSI_BIG_CASE(8, 16)
     XSI_BIG_CASE(16, 16)
+    XSI_BIG_CASE(32, 16)
     XSI_BIG_CASE(8, 20)
     XSI_BIG_CASE(16, 20)
 #undef XSI_BIG_CASE
