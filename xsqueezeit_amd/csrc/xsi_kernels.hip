@@ -2397,10 +2397,88 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
     }
 }
 
+// Rows above 16 KiB: one 1024-thread workgroup per WAH line.  The one-wave-per-line kernel above keeps the row in
+// LDS, so at 500 000 haplotypes (62.5 KB) only two of its one-wave workgroups fit a CU: 46 ms per launch.  Here
+// wave 0 expands the words into the LDS row as before, and all 16 waves turn the row into {bits, ones before}
+// pairs: thread t works on words i * 1024 + t (neighbouring lanes on neighbouring words), a wave scan per
+// stripe of 1024 words, the 16 x stripes totals scanned in row order by wave 0.
+constexpr int WAH_WIDE_STRIPES = 20;  // 20 x 1024 words: rows up to 655 360 bits
+__global__ void __launch_bounds__(1024) k_wah_expand_wide(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
+                                                          DecLines L, const uint32_t* __restrict__ d_totals) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* row = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t rw = L.y_stride64 * 2u;
+    uint32_t* tot = row + rw;  // [stripes][16] + [1]
+    const uint32_t j = blockIdx.x;
+    if (j >= d_totals[1] || d_totals[3]) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    for (uint32_t i = tid; i < rw; i += 1024u) row[i] = 0;
+    const uint32_t l = L.wah_lines[j];
+    const DecBlock& D = blocks[L.line_block[l]];
+    const uint32_t start = L.wah_start[j];
+    const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
+    __syncthreads();
+    if (w == 0) {
+        uint32_t ones;
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah) + start;
+        (void)wave_wah_expand_row(src, D.wah_words - start, nbits, row, &ones);
+        if (lane == 0) L.ones[l] = ones;
+    }
+    __syncthreads();
+    const uint32_t stripes = (L.yp_stride + 1023u) / 1024u;  // <= WAH_WIDE_STRIPES
+    uint32_t excl[WAH_WIDE_STRIPES];
+#pragma unroll
+    for (int i = 0; i < WAH_WIDE_STRIPES; ++i) {
+        excl[i] = 0;
+        if ((uint32_t)i < stripes) {  // uniform
+            const uint32_t idx = (uint32_t)i * 1024u + tid;
+            const uint32_t c = (uint32_t)__popc(idx < rw ? row[idx] : 0u);
+            const uint32_t inc = wave_scan_incl_dpp(c);
+            excl[i] = inc - c;
+            if (lane == 63u) tot[i * 16 + (int)w] = inc;
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        constexpr int PER = (WAH_WIDE_STRIPES * 16 + 63) / 64;
+        uint32_t a[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t idx = lane * (uint32_t)PER + (uint32_t)k;
+            a[k] = idx < stripes * 16u ? tot[idx] : 0u;
+            sum += a[k];
+        }
+        uint32_t run = wave_scan_incl_dpp(sum) - sum;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t idx = lane * (uint32_t)PER + (uint32_t)k;
+            if (idx < stripes * 16u) tot[idx] = run;
+            run += a[k];
+        }
+        if (lane == 63u) L.wah_z[j] = nbits - run;
+    }
+    __syncthreads();
+    uint2* dst = L.yp + (size_t)j * L.yp_stride;
+#pragma unroll
+    for (int i = 0; i < WAH_WIDE_STRIPES; ++i)
+        if ((uint32_t)i < stripes) {
+            const uint32_t idx = (uint32_t)i * 1024u + tid;
+            if (idx < L.yp_stride) dst[idx] = make_uint2(idx < rw ? row[idx] : 0u, tot[i * 16 + (int)w] + excl[i]);
+        }
+}
+
 hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
                              uint32_t max_wah, const uint32_t* d_totals) {
     if (!max_wah) return hipSuccess;
     const uint32_t lds = L.y_stride64 * 8u;
+    if (lds > 16384u && L.yp_stride <= 1024u * (uint32_t)WAH_WIDE_STRIPES && !getenv("XSI_NO_WIDE_EXPAND")) {
+        const uint32_t lds_w = lds + 4u * ((uint32_t)WAH_WIDE_STRIPES * 16u + 16u);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_expand_wide),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
+        if (e != hipSuccess) return e;
+        k_wah_expand_wide<<<dim3(max_wah), dim3(1024), lds_w, s>>>(file, blocks, L, d_totals);
+        return hipGetLastError();
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_expand),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -2462,7 +2540,9 @@ hipError_t launch_line_counts(hipStream_t s, const uint8_t* file, const DecBlock
 // accessor_internals_new.hpp:208-219, 619-637).  apply_negation: write the ALT bit row of a
 // negated bi-allelic line (complement of the listed REF positions); otherwise the raw listed
 // positions are written and KIND_NEGATED is left for the composer.
-__global__ void __launch_bounds__(64) k_sparse_fill(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
+template <int T>  // threads per line: one wave for short rows; 1024 for long ones, whose LDS copy leaves room for two
+                   // workgroups per CU only (one wave each: 100 ms per launch at 500 000 haplotypes)
+__global__ void __launch_bounds__(T) k_sparse_fill(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
                                                     DecLines L, const uint32_t* __restrict__ d_totals,
                                                     uint32_t* __restrict__ out_rows, uint32_t out_stride_w,
                                                     int apply_negation) {
@@ -2474,8 +2554,8 @@ __global__ void __launch_bounds__(64) k_sparse_fill(const uint8_t* __restrict__ 
     const DecBlock& D = blocks[L.line_block[l]];
     const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
     const uint32_t nw = (nbits + 31u) >> 5;
-    const uint32_t lane = lane_id();
-    for (uint32_t i = lane; i < out_stride_w; i += 64u) row[i] = 0;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < out_stride_w; i += (uint32_t)T) row[i] = 0;
     __syncthreads();
     const uint64_t at = D.gt_off + D.off_sparse + L.sparse_start[k];
     const uint8_t* p = file + at;
@@ -2488,13 +2568,13 @@ __global__ void __launch_bounds__(64) k_sparse_fill(const uint8_t* __restrict__ 
         const uint64_t room = in_file ? (L.file_len - at) / L.aet - 1u : 0u;
         if (num > room) num = (uint32_t)room;
     }
-    for (uint32_t i = lane; i < num; i += 64u) {
+    for (uint32_t i = lane; i < num; i += (uint32_t)T) {
         const uint32_t idx = rd_at(p + (size_t)(1u + i) * L.aet, L.aet);
         if (idx < nbits) atomicOr(&row[idx >> 5], 1u << (idx & 31u));
     }
     __syncthreads();
     uint32_t* dst = out_rows + (size_t)l * out_stride_w;
-    for (uint32_t i = lane; i < out_stride_w; i += 64u) {
+    for (uint32_t i = lane; i < out_stride_w; i += (uint32_t)T) {
         uint32_t v = row[i];
         if (neg && apply_negation) {
             v = (i < nw) ? ~v : 0u;
@@ -2513,10 +2593,18 @@ hipError_t launch_sparse_fill(hipStream_t s, const uint8_t* file, const DecBlock
                               uint32_t out_stride_w, int apply_negation) {
     if (!max_sparse) return hipSuccess;
     const uint32_t lds = out_stride_w * 4u;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sparse_fill),
+    if (lds > 16384u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sparse_fill<1024>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        k_sparse_fill<1024><<<dim3(max_sparse), dim3(1024), lds, s>>>(file, blocks, L, d_totals, out_rows, out_stride_w,
+                                                                     apply_negation);
+        return hipGetLastError();
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sparse_fill<64>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_sparse_fill<<<dim3(max_sparse), dim3(64), lds, s>>>(file, blocks, L, d_totals, out_rows, out_stride_w,
+    k_sparse_fill<64><<<dim3(max_sparse), dim3(64), lds, s>>>(file, blocks, L, d_totals, out_rows, out_stride_w,
                                                           apply_negation);
     return hipGetLastError();
 }
