@@ -229,7 +229,10 @@ def main():
         alg_bytes = (cells / 8.0 + xsi_bytes) / launches_per_step
         kern_ms = dec_ms if dom_decode else enc_ms
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in timing.items() if v[1]}
+        stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in timing.items() if v[1]}  # per launch
+        # per step: a job that runs as several batches of blocks launches a stage several times a step
+        stages_step = {k: round(v[0] / steps, 4) for k, v in timing.items() if v[1]}
+        launches = {"encode": enc_n / steps, "decode": dec_n / steps}
         # instruction-issue model of that launch: chunk-lines x VALU per chunk-line x 4 cycles / all SIMDs
         chunk_lines = float(res.n_wah_lines) * ((N + 63) // 64) / launches_per_step
         vpc = VALU_PER_CHUNK_LINE.get(kname)
@@ -275,7 +278,7 @@ def main():
                                          "achieved_over_model": (model_ms / kern_ms) if model_ms and kern_ms else None},
                          "chain_encode_ms": enc_ms, "chain_decode_ms": dec_ms,
                          "pipeline_achieved_GBps": pipeline_gbs, "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
-                         "stage_ms": stages},
+                         "stage_ms": stages, "stage_ms_per_step": stages_step, "chain_launches_per_step": launches},
             "roundtrip_equal": roundtrip_ok,
         }
         if gather_ms is not None:

@@ -296,6 +296,31 @@ int64_t xsi_accessor_fill_selected_genotypes(xsi_accessor* a, int32_t* h_gt, uin
 int xsi_accessor_fill_allele_counts(xsi_accessor* a, uint32_t n_alleles, uint64_t position);
 /* Accessor::get_allele_counts after a fill (accessor.hpp:56). */
 int xsi_accessor_allele_counts(xsi_accessor* a, uint64_t* h_counts, uint32_t n_alleles);
+/*
+ * Accessor::get_internal_access (include/accessor.hpp:69-75 -> AccessorInternalsNewTemplate::get_internal_access,
+ * include/accessor_internals_new.hpp:444-471; class InternalGtAccess, include/accessor_internals.hpp:374-397):
+ * the compressed form of a record for callers that compute on it (dot_prod/dot_prod.hpp).  For each of the
+ * n_alleles - 1 binary lines of the record at `position` (BM value): h_sparse[i] = 1 sparse list / 0 WAH16
+ * words, h_offsets[i] = byte offset of that data inside info->image, a host copy of the file (of the inflated
+ * block for zstd files) valid until the next call on this accessor.  A sparse list is {count | MSB, indices} of
+ * sparse_bytes each; WAH words are wah_bytes each.  h_a (optional, hap_samples entries, 4 bytes each whatever
+ * the file's A_T: a_bytes reports 4) receives the PBWT arrangement in force at the LAST of those lines, as the
+ * reference's `a` pointer shows it after its seeks: a[i] = haplotype at position i of the permuted rows.  It is
+ * rebuilt on the device from the block's decoded lines (the decode kernels track ranks, never `a`), one stable
+ * partition per earlier WAH line of the block: a replay, as in the reference.  Blocks with fully haploid lines:
+ * XSI_ERR_UNSUPPORTED.  default_allele as in the reference: 1 when the first line is a negated sparse line.
+ */
+typedef struct xsi_internal_access {
+    uint64_t position;
+    uint32_t n_alleles;
+    uint32_t sparse_bytes, wah_bytes, a_bytes;
+    int32_t default_allele;
+    uint32_t n_a;       /* entries of a = hap_samples */
+    const void* image;  /* base of the offsets */
+    uint64_t image_len;
+} xsi_internal_access;
+int xsi_accessor_get_internal_access(xsi_accessor* a, uint32_t n_alleles, uint64_t position, xsi_internal_access* info,
+                                     uint8_t* h_sparse, uint64_t* h_offsets, uint32_t* h_a);
 uint64_t xsi_accessor_hap_samples(const xsi_accessor* a);
 uint64_t xsi_accessor_num_samples(const xsi_accessor* a);
 /* Accessor::get_sample_list()[i] */

@@ -46,6 +46,18 @@ int main(int argc, char** argv) {
             for (int v : rows[l]) alt += ((v >> 1) - 1) == 1;
             if (a->get_allele_counts()[1] != alt) return 5;
         }
+        // InternalGtAccess of a record in the second block: one line, a pointer into the host image, `a` a permutation
+        {
+            const size_t l = block_len + block_len / 2;
+            InternalGtAccess ia = a->get_internal_access(2, ((l / block_len) << 15) | (l % block_len));
+            if (ia.n_alleles != 2 || ia.pointers.size() != 1 || ia.sparse.size() != 1 || !ia.pointers[0] || !ia.a) return 7;
+            std::vector<char> seen(2 * n_samples, 0);
+            const uint32_t* arr = (const uint32_t*)ia.a;
+            for (size_t i = 0; i < 2 * n_samples; ++i) {
+                if (arr[i] >= 2 * n_samples || seen[arr[i]]) return 8;
+                seen[arr[i]] = 1;
+            }
+        }
     } catch (const char* e) {
         std::fprintf(stderr, "exception: %s\n", e);
         return 6;

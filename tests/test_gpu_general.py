@@ -529,6 +529,100 @@ def test_phenotype_dot_products_on_composed_genotypes():
     assert torch.equal(o_a, o_b)
 
 
+def test_accessor_internal_access(tmp_path):
+    """get_internal_access (accessor_internals_new.hpp:444-471): per binary line of a record WAH-or-sparse and
+    where its data sits, plus the PBWT arrangement `a` in force at the record's last line.  Checked by
+    recomputation: WAH-or-sparse from the allele counts and the MAC threshold (gt_block.hpp:299-326), `a` by
+    numpy stable partitions over the earlier WAH lines of the block (internal_gt_record.hpp:32-59), and the
+    data itself: the WAH words at the returned offset expand (oracle wah_extract) to the line's bits gathered
+    through `a` (wah.hpp:530-537), sparse lists hold the carriers (the REF haplotypes when negated)."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    rng = np.random.default_rng(4242)
+    n, block_len, thr = 300, 60, 12
+    N = 2 * n
+    lines = []
+    for i in range(3 * block_len - 7):
+        lines.extend(_random_lines(rng, n, 1, multi=(i % 3 == 0), missing=(i % 5 == 0), phase=True))
+        if i % 11 == 0:   # ALT 1 the majority allele: a negated sparse line or a dense WAH line
+            gt, na = lines[-1]
+            al = (gt >> 1) - 1
+            sw = np.where(al == 0, 1, np.where(al == 1, 0, al))
+            keep = (gt >> 1) == 0
+            lines[-1] = (np.where(keep, gt, ((sw + 1) << 1) | (gt & 1)).astype(np.int32), na)
+    dp = oracle.default_phased_of(lines, n)
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=thr, default_phased=dp)
+    path = tmp_path / "ia.xsi"
+    path.write_bytes(ref)
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
+    # per BCF line: BM, and per binary line: allele bits, WAH or sparse
+    bms, first_bin = [], []
+    block = off = 0
+    for i, (_, na) in enumerate(lines):
+        if i and i % block_len == 0:
+            block, off = block + 1, 0
+        bms.append((block << 15) | off)
+        off += na - 1
+    def bits_of(i, k):
+        gt = lines[i][0]
+        return (((gt >> 1) - 1) == k).astype(np.uint8)
+    def is_wah(x):
+        c = int(x.sum())
+        return min(c, N - c) > thr
+    checked_wah = checked_sparse = checked_neg = 0
+    for i in [int(v) for v in rng.integers(0, len(lines), 30)] + [0, block_len, len(lines) - 1]:
+        gt, na = lines[i]
+        info = binding.InternalAccess()
+        sp = np.zeros(na - 1, dtype=np.uint8)
+        offs = np.zeros(na - 1, dtype=np.uint64)
+        arr = np.zeros(N, dtype=np.uint32)
+        binding.check(L.xsi_accessor_get_internal_access(a, na, bms[i], ctypes.byref(info), sp.ctypes.data, offs.ctypes.data,
+                                                         arr.ctypes.data))
+        assert (info.n_alleles, info.sparse_bytes, info.wah_bytes, info.a_bytes, info.n_a) == (na, 2, 2, 4, N)
+        img = np.frombuffer((ctypes.c_uint8 * info.image_len).from_address(info.image), dtype=np.uint8)
+        # arrangement at the record's last binary line: stable partitions over the block's earlier WAH lines
+        exp_a = np.arange(N, dtype=np.uint32)
+        b0 = (i // block_len) * block_len
+        for j in range(b0, i + 1):
+            for k in range(1, lines[j][1]):
+                if j == i and k == na - 1:
+                    break
+                x = bits_of(j, k)
+                if is_wah(x):
+                    y = x[exp_a]
+                    exp_a = np.concatenate([exp_a[y == 0], exp_a[y == 1]])
+        assert np.array_equal(arr, exp_a), "line %d" % i
+        for k in range(1, na):
+            x = bits_of(i, k)
+            assert sp[k - 1] == (0 if is_wah(x) else 1), "line %d allele %d" % (i, k)
+            o = int(offs[k - 1])
+            if not sp[k - 1]:
+                if k == na - 1:   # `a` is the arrangement of this line
+                    words = img[o:o + 2 * (N // 15 + 2)].view(np.uint16)
+                    y, _, _ = oracle.wah_extract(words, N)
+                    assert np.array_equal(y, x[arr]), "line %d allele %d" % (i, k)
+                    checked_wah += 1
+            else:
+                num = int(img[o:o + 2].view(np.uint16)[0])
+                neg = bool(num & 0x8000)
+                num &= 0x7FFF
+                listed = img[o + 2:o + 2 + 2 * num].view(np.uint16).astype(np.int64)
+                want = np.flatnonzero((((gt >> 1) - 1) == 0) if neg else x)
+                assert np.array_equal(listed, want), "line %d allele %d" % (i, k)
+                checked_sparse += 1
+                checked_neg += neg
+                if k == 1:
+                    assert info.default_allele == (1 if neg else 0)
+    assert checked_wah >= 5 and checked_sparse >= 5
+    # the accessor still serves genotypes afterwards
+    buf = np.zeros(N, dtype=np.int32)
+    assert L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, N, lines[7][1], bms[7]) == N
+    assert np.array_equal(buf, lines[7][0])
+    L.xsi_accessor_close(a)
+
+
 def test_accessor_sample_subset(tmp_path):
     """fill_selected_genotypes == the reference's fill_selected_genotypes (gt_decompressor_new.hpp:209-238):
     the listed samples' values in list order, 1 or 2 per sample by the line's ploidy, AN and the AC of

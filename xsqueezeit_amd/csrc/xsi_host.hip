@@ -20,6 +20,7 @@
 
 #include "../../include/xsi_hip.h"
 #include "xsi_ctx.hpp"
+#include "xsi_device.hpp"
 
 using namespace xsi;
 
@@ -971,6 +972,142 @@ int xsi_accessor_fill_allele_counts(xsi_accessor* a, uint32_t n_alleles, uint64_
         total += a->last_counts[k];
     }
     a->last_counts[0] = nl - total;  // sic: missing / end-of-vector not subtracted (:437)
+    return XSI_OK;
+}
+
+}  // extern "C"
+
+// The PBWT arrangement after the WAH lines [0, n_before) of a decoded block: a_{k+1} = zeros of line k in a_k's
+// order, then its ones (pbwt_sort, internal_gt_record.hpp:32-59).  One workgroup; thread t owns positions
+// [t K, t K + K): it counts the zeros among them, a workgroup scan places its segment, and it writes its members
+// to their new positions.  This is the replay the reference's seek does on the host; nothing on the hot path
+// holds `a` (the chains track ranks), so it is built only when get_internal_access asks for it.
+__global__ void __launch_bounds__(1024) k_arrangement_at(const uint32_t* __restrict__ planes, uint32_t stride_w,
+                                                         const uint8_t* __restrict__ kind, uint32_t n_before, uint32_t N,
+                                                         uint32_t* a0, uint32_t* a1, uint32_t* which) {
+    __shared__ uint64_t scan_lds[17];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t K = (N + 1023u) / 1024u;
+    const uint32_t lo = tid * K < N ? tid * K : N, hi = lo + K < N ? lo + K : N;
+    for (uint32_t i = lo; i < hi; ++i) a0[i] = i;
+    __syncthreads();
+    uint32_t *cur = a0, *nxt = a1;
+    for (uint32_t l = 0; l < n_before; ++l) {
+        if (!(kind[l] & KIND_WAH)) continue;  // sparse lines never touch a (gt_block.hpp:299-326)
+        const uint32_t* row = planes + (size_t)l * stride_w;
+        uint32_t zc = 0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t h = cur[i];
+            zc += 1u - ((row[h >> 5] >> (h & 31u)) & 1u);
+        }
+        uint64_t Z;
+        const uint32_t zbase = (uint32_t)block_scan_excl64(zc, scan_lds, &Z);
+        uint32_t zpos = zbase, opos = (uint32_t)Z + (lo - zbase);
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t h = cur[i];
+            if ((row[h >> 5] >> (h & 31u)) & 1u) nxt[opos++] = h;
+            else nxt[zpos++] = h;
+        }
+        __threadfence_block();
+        __syncthreads();
+        uint32_t* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    if (tid == 0) *which = cur == a0 ? 0u : 1u;
+}
+
+extern "C" {
+
+int xsi_accessor_get_internal_access(xsi_accessor* a, uint32_t n_alleles, uint64_t position, xsi_internal_access* info,
+                                     uint8_t* h_sparse, uint64_t* h_offsets, uint32_t* h_a) {
+    if (!a || !info) return set_error(XSI_ERR_ARG, "get_internal_access: null argument");
+    if (n_alleles >= 2 && (!h_sparse || !h_offsets)) return set_error(XSI_ERR_ARG, "get_internal_access: null output array");
+    const uint64_t block = (position & 0xFFFFFFFFull) >> BM_BLOCK_BITS;
+    const uint32_t offset = (uint32_t)(position & ((1u << BM_BLOCK_BITS) - 1u));
+    memset(info, 0, sizeof(*info));
+    info->position = position;
+    info->n_alleles = n_alleles;
+    info->sparse_bytes = a->aet;
+    info->wah_bytes = 2;
+    info->a_bytes = 4;
+    info->n_a = (uint32_t)a->hap_samples;
+    if (n_alleles < 2) return XSI_OK;  // the reference returns the bare header for n_alleles == 0
+    hipStream_t s = a->ctx->stream;
+    // the arrangement first: it needs the decoded lines of the block (cache or workspace)
+    if (a->cur_block < 0 || (uint64_t)a->cur_block != block) {
+        int rc = accessor_load_block(a, block);
+        if (rc) return rc;
+    }
+    const uint32_t n_lines = n_alleles - 1u;
+    if (offset + n_lines > a->P.n_bin)
+        return set_error(XSI_ERR_ARG, "position offset %u (+%u alleles) beyond the %u binary lines of block %llu", offset, n_lines,
+                         a->P.n_bin, (unsigned long long)block);
+    if (a->P.blocks_h.empty() || a->P.blocks_h[0].off_line_haploid != VAL_UNDEFINED)
+        return set_error(XSI_ERR_UNSUPPORTED, "get_internal_access: block %llu has fully haploid lines", (unsigned long long)block);
+    if (h_a) {
+        const uint32_t N = a->P.L.N;
+        uint32_t *d_a0, *d_a1, *d_which;
+        xsi_hip_ctx* ctx = a->ctx;
+        void* wp;
+        int wrc = ws_ensure(ctx, "acc.arr0", 4ull * N, &wp);
+        if (wrc) return wrc;
+        d_a0 = (uint32_t*)wp;
+        if ((wrc = ws_ensure(ctx, "acc.arr1", 4ull * N, &wp))) return wrc;
+        d_a1 = (uint32_t*)wp;
+        if ((wrc = ws_ensure(ctx, "acc.arr_which", 64, &wp))) return wrc;
+        d_which = (uint32_t*)wp;
+        k_arrangement_at<<<dim3(1), dim3(1024), 0, s>>>(a->D.planes, a->D.stride_w, a->P.L.kind, offset + n_lines - 1u, N, d_a0, d_a1,
+                                                     d_which);
+        HIP_TRY(hipGetLastError());
+        uint32_t which = 0;
+        HIP_TRY(hipMemcpyAsync(&which, d_which, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpyAsync(h_a, which ? d_a1 : d_a0, 4ull * N, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    // where the lines' words / lists sit: parse the block again (line kinds, ranks, starts); this uses the workspace
+    const uint8_t* img;
+    uint64_t len, blk;
+    if (a->cur_in_workspace) a->cur_block = -1;  // the view of the current block is about to be overwritten
+    a->cnt_block = -1;
+    a->win_n = 0;
+    int rc = accessor_block_image(a, block, &img, &len, &blk);
+    if (rc) return rc;
+    DecodePlan P;
+    rc = decode_prepare(a->ctx, img, len, blk, 1, &P);
+    if (rc) return rc;
+    rc = decode_counts_only(a->ctx, img, P);
+    if (rc) return rc;
+    std::vector<uint8_t> kind(n_lines);
+    std::vector<uint32_t> rank(n_lines), wah_start(P.n_wah ? P.n_wah : 1), sparse_start(P.n_sparse ? P.n_sparse : 1);
+    HIP_TRY(hipMemcpyAsync(kind.data(), P.L.kind + offset, n_lines, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(rank.data(), P.L.rank + offset, 4ull * n_lines, hipMemcpyDeviceToHost, s));
+    if (P.n_wah) HIP_TRY(hipMemcpyAsync(wah_start.data(), P.L.wah_start, 4ull * P.n_wah, hipMemcpyDeviceToHost, s));
+    if (P.n_sparse) HIP_TRY(hipMemcpyAsync(sparse_start.data(), P.L.sparse_start, 4ull * P.n_sparse, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    stage_collect(a->ctx);
+    const DecBlock& D = P.blocks_h[0];
+    const std::vector<uint8_t>& himg = a->zstd ? a->mini : a->file;
+    info->image = himg.data();
+    info->image_len = himg.size();
+    for (uint32_t i = 0; i < n_lines; ++i) {
+        const bool is_wah = (kind[i] & KIND_WAH) != 0u;
+        h_sparse[i] = is_wah ? 0 : 1;
+        if (is_wah) {
+            if (rank[i] >= P.n_wah) return set_error(XSI_ERR_FORMAT, "get_internal_access: WAH rank out of range");
+            h_offsets[i] = D.gt_off + D.off_wah + 2ull * wah_start[D.wah_first + rank[i]];
+        } else {
+            if (rank[i] >= P.n_sparse) return set_error(XSI_ERR_FORMAT, "get_internal_access: sparse rank out of range");
+            h_offsets[i] = D.gt_off + D.off_sparse + sparse_start[D.sparse_first + rank[i]];
+        }
+        if (h_offsets[i] + a->aet > himg.size()) return set_error(XSI_ERR_FORMAT, "get_internal_access: line data outside the image");
+    }
+    if (h_sparse[0]) {  // REF listed (MSB of the count set): ALT 1 is the default allele (accessor_internals_new.hpp:458-460)
+        uint64_t num = 0;
+        for (uint32_t b = 0; b < a->aet; ++b) num |= (uint64_t)himg[h_offsets[0] + b] << (8 * b);
+        info->default_allele = (num >> (8 * a->aet - 1)) & 1ull ? 1 : 0;
+    }
     return XSI_OK;
 }
 
