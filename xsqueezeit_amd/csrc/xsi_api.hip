@@ -86,6 +86,11 @@ void xsi_hip_ctx_destroy(xsi_hip_ctx* c) {
         (void)hipStreamSynchronize(c->side);
         (void)hipStreamDestroy(c->side);
     }
+    if (c->side2) {
+        (void)hipStreamSynchronize(c->side2);
+        (void)hipStreamDestroy(c->side2);
+    }
+    for (auto e : c->ev_phase) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto& kv : c->bufs)
@@ -829,10 +834,66 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
     HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
     stage_mark(ctx, XSI_ST_DEC_BOUND);
     HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
-    stage_mark(ctx, XSI_ST_DEC_EXPAND);
-    HIP_TRY(launch_wah_expand(s, f, P.d_blocks, L, P.n_wah, P.d_totals));
-    stage_mark(ctx, XSI_ST_CHAIN_DEC);
-    HIP_TRY(launch_chain_decode(s, P.d_blocks, P.n_blocks, L, out, stride_w, scratch_a, any_haploid));
+    // Phased: the chain needs line j of every block at its step j, so the WAH lines of every block are cut into K
+    // ranges; the expansion of range p+1 (side stream) runs underneath the chain of range p, which parks its
+    // ranks in HBM between the launches (64 MB at 245 blocks of 64 976 haplotypes).  A whole second expansion
+    // next to the chain costs the chain 1 ms of its 23.4 (measured): the expansion is almost free this way.
+    const uint32_t n_phases = [] {  // read per call (tests switch it); 12: 74.6 -> 71.0 ms per step at configs[2] (4: 72.2)
+        const char* e = getenv("XSI_DEC_PHASES");
+        const int v = e ? atoi(e) : 12;
+        return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
+    }();
+    if (n_phases > 1u && !any_haploid && P.n_wah >= 64u * P.n_blocks && rank_decode_phased_ok(L.N, L.yp_stride, P.n_blocks)) {
+        const uint32_t K = n_phases, nb = P.n_blocks;
+        // per phase and block: first WAH line (batch-wide rank), lines, and the running number of 4-line groups
+        P.phase_tab.assign((size_t)K * (3u * nb + 1u), 0u);
+        for (uint32_t p = 0; p < K; ++p) {
+            uint32_t* start = P.phase_tab.data() + (size_t)p * (3u * nb + 1u);
+            uint32_t *cnt = start + nb, *gpre = cnt + nb;
+            uint32_t g = 0;
+            for (uint32_t b = 0; b < nb; ++b) {
+                const DecBlock& D = P.blocks_h[b];
+                const uint32_t n = D.error ? 0u : D.n_wah;
+                const uint32_t lo = (uint32_t)((uint64_t)n * p / K), hi = (uint32_t)((uint64_t)n * (p + 1u) / K);
+                start[b] = D.wah_first + lo;
+                cnt[b] = hi - lo;
+                gpre[b] = g;
+                g += (hi - lo + WAH_EXPAND_LINES_PER_WAVE - 1u) / WAH_EXPAND_LINES_PER_WAVE;
+            }
+            gpre[nb] = g;
+        }
+        uint32_t *d_tab, *d_state;
+        WS(d_tab, "dec.phase_tab", 4ull * P.phase_tab.size());
+        WS(d_state, "dec.rank_state", 4ull * 65536ull * nb);
+        HIP_TRY(hipMemcpyAsync(d_tab, P.phase_tab.data(), 4ull * P.phase_tab.size(), hipMemcpyHostToDevice, s));
+        if (!ctx->side2) HIP_TRY(hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
+        while (ctx->ev_phase.size() < (size_t)K + 1u) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->ev_phase.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(ctx->ev_phase[K], s));  // boundaries done, table uploaded
+        HIP_TRY(hipStreamWaitEvent(ctx->side2, ctx->ev_phase[K], 0));
+        for (uint32_t p = 0; p < K; ++p) {
+            const uint32_t* tab = d_tab + (size_t)p * (3u * nb + 1u);
+            const uint32_t groups = P.phase_tab[(size_t)p * (3u * nb + 1u) + 3u * nb];
+            HIP_TRY(launch_wah_expand_phase(ctx->side2, f, P.d_blocks, L, P.d_totals, tab, tab + nb, tab + 2u * nb, nb, groups));
+            HIP_TRY(hipEventRecord(ctx->ev_phase[p], ctx->side2));
+        }
+        stage_mark(ctx, XSI_ST_DEC_EXPAND);  // what shows of the expansion: the wait for its first range
+        HIP_TRY(hipStreamWaitEvent(s, ctx->ev_phase[0], 0));
+        stage_mark(ctx, XSI_ST_CHAIN_DEC);
+        for (uint32_t p = 0; p < K; ++p) {
+            const uint32_t* tab = d_tab + (size_t)p * (3u * nb + 1u);
+            if (p) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_phase[p], 0));
+            HIP_TRY(launch_rank_decode_phase(s, P.d_blocks, nb, L, out, stride_w, tab, tab + nb, d_state, p == 0u, p + 1u == K));
+        }
+    } else {
+        stage_mark(ctx, XSI_ST_DEC_EXPAND);
+        HIP_TRY(launch_wah_expand(s, f, P.d_blocks, L, P.n_wah, P.d_totals));
+        stage_mark(ctx, XSI_ST_CHAIN_DEC);
+        HIP_TRY(launch_chain_decode(s, P.d_blocks, P.n_blocks, L, out, stride_w, scratch_a, any_haploid));
+    }
     stage_mark(ctx, XSI_ST_DEC_SPARSE);  // what is left of the sparse work after the chain
     HIP_TRY(hipStreamWaitEvent(s, ctx->ev_join, 0));
     stage_mark(ctx, -1);

@@ -35,6 +35,10 @@ struct xsi_hip_ctx {
     // joined back into `stream` with the two events, so callers still see one in-order stream
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // second side stream + events of the phased decode: the WAH expansion of the next range of lines runs
+    // underneath the chain of the current one (created on first use)
+    hipStream_t side2 = nullptr;
+    std::vector<hipEvent_t> ev_phase;
     struct Buf {
         void* p = nullptr;
         size_t cap = 0;
@@ -76,6 +80,7 @@ struct DecodePlan {
     uint32_t* d_totals = nullptr;
     std::vector<DecBlock> blocks_h;
     DecLines L{};
+    std::vector<uint32_t> phase_tab;  // host copy of the phase table (outlives its async upload)
 };
 
 struct DecodedPlanes {

@@ -2327,11 +2327,29 @@ hipError_t launch_sparse_walk(hipStream_t s, const uint8_t* file, const DecBlock
 // expand every WAH line into its permuted bit row (wah2_extract_count_ones, wah.hpp:232-235).
 // One wave per line, row built in LDS then streamed out.
 __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
-                                                   DecLines L, const uint32_t* __restrict__ d_totals) {
+                                                   DecLines L, const uint32_t* __restrict__ d_totals,
+                                                   const uint32_t* __restrict__ ph_start, const uint32_t* __restrict__ ph_cnt,
+                                                   const uint32_t* __restrict__ ph_gpre, uint32_t n_blocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* row = reinterpret_cast<uint32_t*>(smem);
-    const uint32_t j0 = blockIdx.x * WAH_LINES_PER_WAVE;
-    const uint32_t total = d_totals[1];
+    uint32_t j0 = blockIdx.x * WAH_LINES_PER_WAVE;
+    uint32_t total = d_totals[1];
+    if (ph_start) {
+        // one range of every block's lines (phased decode): group g of the launch -> block b with
+        // ph_gpre[b] <= g < ph_gpre[b + 1] (blocks without lines in the range repeat their successor's value)
+        const uint32_t g = blockIdx.x;
+        uint32_t lo = 0, hi = n_blocks;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ph_gpre[mid] <= g) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t first = (g - ph_gpre[lo]) * WAH_LINES_PER_WAVE;
+        if (first >= ph_cnt[lo]) return;
+        j0 = ph_start[lo] + first;
+        const uint32_t end = ph_start[lo] + ph_cnt[lo];
+        total = end < total ? end : total;
+    }
     if (j0 >= total || d_totals[3]) return;
     const uint32_t lane = lane_id();
     const uint32_t rw = L.y_stride64 * 2u;
@@ -2482,8 +2500,21 @@ hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock*
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_expand),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_wah_expand<<<dim3((max_wah + WAH_LINES_PER_WAVE - 1u) / WAH_LINES_PER_WAVE), dim3(64), lds, s>>>(file, blocks, L,
-                                                                                                  d_totals);
+    k_wah_expand<<<dim3((max_wah + WAH_LINES_PER_WAVE - 1u) / WAH_LINES_PER_WAVE), dim3(64), lds, s>>>(
+        file, blocks, L, d_totals, nullptr, nullptr, nullptr, 0u);
+    return hipGetLastError();
+}
+
+static_assert(WAH_EXPAND_LINES_PER_WAVE == WAH_LINES_PER_WAVE, "the phase table counts groups of this many lines");
+hipError_t launch_wah_expand_phase(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
+                                   const uint32_t* d_totals, const uint32_t* ph_start, const uint32_t* ph_cnt,
+                                   const uint32_t* ph_gpre, uint32_t n_blocks, uint32_t n_groups) {
+    if (!n_groups) return hipSuccess;
+    const uint32_t lds = L.y_stride64 * 8u;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_expand),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    k_wah_expand<<<dim3(n_groups), dim3(64), lds, s>>>(file, blocks, L, d_totals, ph_start, ph_cnt, ph_gpre, n_blocks);
     return hipGetLastError();
 }
 

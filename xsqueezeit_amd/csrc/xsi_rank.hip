@@ -47,6 +47,12 @@ struct RankArgs {
     uint32_t N;
     uint32_t batch;             // lines staged per LDS batch
     uint32_t log2_cwp;
+    // phased decode (k_chain_decode_rank_wg): this launch runs ph_cnt[b] lines of block b from batch-wide
+    // rank ph_start[b]; ranks come from / go to `state` unless it is the first / last range.  nullptr: all lines.
+    const uint32_t* ph_start;
+    const uint32_t* ph_cnt;
+    uint32_t* state;            // [block][chunk of the wave][1024 threads]
+    uint32_t ph_first, ph_last;
 };
 
 constexpr int RANK_RP = 6;  // {bits, prefix} pairs a thread carries while a batch is in flight
@@ -330,18 +336,28 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t cg0 = w * E;
-    const uint32_t wah_first = D.wah_first, n_wah = D.n_wah;
+    const uint32_t wah_first = A.ph_start ? A.ph_start[blockIdx.x] : D.wah_first;
+    const uint32_t n_wah = A.ph_start ? A.ph_cnt[blockIdx.x] : D.n_wah;
+    if (n_wah == 0) return;  // no line of this block in this range: its ranks stay parked
     const uint32_t CWP = A.yp_stride;  // pairs per row, <= 2048
     constexpr uint32_t SLOT = 16384u;  // bytes of one staged row
     uint2* stage = reinterpret_cast<uint2*>(smem);
     const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     uint32_t r[E];
-    static_for<0, E>([&](auto ecn) {
-        constexpr int e = decltype(ecn)::value;
-        r[e] = (cg0 + (uint32_t)e) * 64u + lane;
-        if (r[e] >= N) r[e] = 0;  // haplotypes beyond N idle on position 0; their output is masked
-    });
+    uint32_t* park = A.state + ((size_t)blockIdx.x * (uint32_t)E) * T + tid;  // chunk e of my wave: park[e * T]
+    if (!A.ph_start || A.ph_first) {
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            r[e] = (cg0 + (uint32_t)e) * 64u + lane;
+            if (r[e] >= N) r[e] = 0;  // haplotypes beyond N idle on position 0; their output is masked
+        });
+    } else {
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            r[e] = park[(size_t)e * T];
+        });
+    }
     uint32_t vm_lo = 0, vm_hi = 0;  // lane e (< E) stores chunk cg0+e's word: valid bits of that chunk
     {
         const uint64_t base = (uint64_t)(cg0 + lane) * 64u;
@@ -426,6 +442,12 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
         line = line_n;
         Z = Z_n;
         __syncthreads();  // the next row is staged; everyone is done with this one
+    }
+    if (A.ph_start && !A.ph_last) {
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            park[(size_t)e * T] = r[e];
+        });
     }
 }
 
@@ -567,6 +589,52 @@ const char* rank_decode_kernel_name(uint32_t N, uint32_t yp_stride, uint32_t n_b
     return N >= 49152u ? "k_chain_decode_rank_big" : "k_chain_decode_rank";
 }
 
+static hipError_t launch_rank_wg(hipStream_t s, uint32_t n_blocks, const RankArgs& R) {
+    const uint32_t nch = (R.N + 63u) / 64u;
+    const uint32_t e = ((nch + 15u) / 16u + 7u) / 8u * 8u;  // chunks per wave, multiple of 8
+    const uint32_t lds = 2u * 16384u;
+#define XSI_WG_CASE(EE)                                                                                    \
+    if (e == EE) {                                                                                          \
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank_wg<EE>),    \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        if (err != hipSuccess) return err;                                                                  \
+        k_chain_decode_rank_wg<EE><<<dim3(n_blocks), dim3(1024), lds, s>>>(R);                              \
+        return hipGetLastError();                                                                           \
+    }
+    XSI_WG_CASE(16)
+    XSI_WG_CASE(24)
+    XSI_WG_CASE(32)
+    XSI_WG_CASE(40)
+    XSI_WG_CASE(48)
+    XSI_WG_CASE(56)
+    XSI_WG_CASE(64)
+#undef XSI_WG_CASE
+    return hipErrorInvalidValue;
+}
+
+bool rank_decode_phased_ok(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) { return use_rank_wg(N, yp_stride, n_blocks); }
+
+hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
+                                    uint32_t* out_rows, uint32_t out_stride_w, const uint32_t* ph_start,
+                                    const uint32_t* ph_cnt, uint32_t* state, bool first, bool last) {
+    if (!n_blocks) return hipSuccess;
+    RankArgs R{};
+    R.blocks = blocks;
+    R.wah_lines = L.wah_lines;
+    R.yp = L.yp;
+    R.yp_stride = L.yp_stride;
+    R.wah_z = L.wah_z;
+    R.out = out_rows;
+    R.out_stride_w = out_stride_w;
+    R.N = L.N;
+    R.ph_start = ph_start;
+    R.ph_cnt = ph_cnt;
+    R.state = state;
+    R.ph_first = first ? 1u : 0u;
+    R.ph_last = last ? 1u : 0u;
+    return launch_rank_wg(s, n_blocks, R);
+}
+
 hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                               uint32_t* out_rows, uint32_t out_stride_w) {
     if (!n_blocks) return hipSuccess;
@@ -586,29 +654,7 @@ hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_
         const char* e = getenv("XSI_BIG_RANK_MIN_N");
         return e ? (uint32_t)atoi(e) : 49152u;  // measured: 11.3 ms against 14.2 ms at 64 976 hap x 64 blocks, slower at 40 000
     }();
-    {
-        const uint32_t nch = (L.N + 63u) / 64u;
-        if (use_rank_wg(L.N, L.yp_stride, n_blocks)) {
-            const uint32_t e = ((nch + 15u) / 16u + 7u) / 8u * 8u;  // chunks per wave, multiple of 8
-            const uint32_t lds = 2u * 16384u;
-#define XSI_WG_CASE(EE)                                                                                    \
-    if (e == EE) {                                                                                          \
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank_wg<EE>),    \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-        if (err != hipSuccess) return err;                                                                  \
-        k_chain_decode_rank_wg<EE><<<dim3(n_blocks), dim3(1024), lds, s>>>(R);                              \
-        return hipGetLastError();                                                                           \
-    }
-            XSI_WG_CASE(16)
-            XSI_WG_CASE(24)
-            XSI_WG_CASE(32)
-            XSI_WG_CASE(40)
-            XSI_WG_CASE(48)
-            XSI_WG_CASE(56)
-            XSI_WG_CASE(64)
-#undef XSI_WG_CASE
-        }
-    }
+    if (use_rank_wg(L.N, L.yp_stride, n_blocks)) return launch_rank_wg(s, n_blocks, R);
     if ((!g.stage || L.N >= big_min) && L.yp_stride <= 1024u * 20u && L.yp_stride * 8u <= 160u * 1024u &&
         !getenv("XSI_NO_BIG_RANK"))
         return launch_rank_big(s, n_blocks, R);
