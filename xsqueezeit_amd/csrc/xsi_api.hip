@@ -836,7 +836,7 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
     HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
     // Phased: the chain needs line j of every block at its step j, so the WAH lines of every block are cut into K
     // ranges; the expansion of range p+1 (side stream) runs underneath the chain of range p, which parks its
-    // ranks in HBM between the launches (64 MB at 245 blocks of 64 976 haplotypes).  A whole second expansion
+    // ranks in HBM between the launches (4 N bytes per block: 64 MB at 245 blocks of 64 976 haplotypes).  A whole second expansion
     // next to the chain costs the chain 1 ms of its 23.4 (measured): the expansion is almost free this way.
     const uint32_t n_phases = [] {  // read per call (tests switch it); 12: 74.6 -> 71.0 ms per step at configs[2] (4: 72.2)
         const char* e = getenv("XSI_DEC_PHASES");
@@ -844,7 +844,7 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
         return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
     }();
     if (n_phases > 1u && !any_haploid && P.n_wah >= 64u * P.n_blocks && rank_decode_phased_ok(L.N, L.yp_stride, P.n_blocks)) {
-        const uint32_t K = n_phases, nb = P.n_blocks;
+        const uint32_t K = n_phases, nb = P.n_blocks, lpg = wah_expand_lines_per_group(L);
         // per phase and block: first WAH line (batch-wide rank), lines, and the running number of 4-line groups
         P.phase_tab.assign((size_t)K * (3u * nb + 1u), 0u);
         for (uint32_t p = 0; p < K; ++p) {
@@ -858,13 +858,13 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
                 start[b] = D.wah_first + lo;
                 cnt[b] = hi - lo;
                 gpre[b] = g;
-                g += (hi - lo + WAH_EXPAND_LINES_PER_WAVE - 1u) / WAH_EXPAND_LINES_PER_WAVE;
+                g += (hi - lo + lpg - 1u) / lpg;
             }
             gpre[nb] = g;
         }
         uint32_t *d_tab, *d_state;
         WS(d_tab, "dec.phase_tab", 4ull * P.phase_tab.size());
-        WS(d_state, "dec.rank_state", 4ull * 65536ull * nb);
+        WS(d_state, "dec.rank_state", 4ull * rank_decode_state_words(L.N, nb));
         HIP_TRY(hipMemcpyAsync(d_tab, P.phase_tab.data(), 4ull * P.phase_tab.size(), hipMemcpyHostToDevice, s));
         if (!ctx->side2) HIP_TRY(hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
         while (ctx->ev_phase.size() < (size_t)K + 1u) {

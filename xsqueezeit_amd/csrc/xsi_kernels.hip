@@ -2422,12 +2422,23 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
 // stripe of 1024 words, the 16 x stripes totals scanned in row order by wave 0.
 constexpr int WAH_WIDE_STRIPES = 20;  // 20 x 1024 words: rows up to 655 360 bits
 __global__ void __launch_bounds__(1024) k_wah_expand_wide(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
-                                                          DecLines L, const uint32_t* __restrict__ d_totals) {
+                                                          DecLines L, const uint32_t* __restrict__ d_totals,
+                                                          const uint32_t* __restrict__ ph_start,
+                                                          const uint32_t* __restrict__ ph_gpre, uint32_t n_blocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* row = reinterpret_cast<uint32_t*>(smem);
     const uint32_t rw = L.y_stride64 * 2u;
     uint32_t* tot = row + rw;  // [stripes][16] + [1]
-    const uint32_t j = blockIdx.x;
+    uint32_t j = blockIdx.x;
+    if (ph_start) {  // one range of every block's lines (phased decode), one line per group: see k_wah_expand
+        uint32_t lo = 0, hi = n_blocks;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ph_gpre[mid] <= j) lo = mid;
+            else hi = mid;
+        }
+        j = ph_start[lo] + (j - ph_gpre[lo]);
+    }
     if (j >= d_totals[1] || d_totals[3]) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     for (uint32_t i = tid; i < rw; i += 1024u) row[i] = 0;
@@ -2485,37 +2496,45 @@ __global__ void __launch_bounds__(1024) k_wah_expand_wide(const uint8_t* __restr
         }
 }
 
-hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
-                             uint32_t max_wah, const uint32_t* d_totals) {
-    if (!max_wah) return hipSuccess;
+static bool wah_expand_is_wide(const DecLines& L) {
+    return L.y_stride64 * 8u > 16384u && L.yp_stride <= 1024u * (uint32_t)WAH_WIDE_STRIPES && !getenv("XSI_NO_WIDE_EXPAND");
+}
+
+uint32_t wah_expand_lines_per_group(const DecLines& L) { return wah_expand_is_wide(L) ? 1u : WAH_LINES_PER_WAVE; }
+
+// ph_start == nullptr: all WAH lines of the batch (n_groups ignored); else one range of every block's lines
+static hipError_t launch_wah_expand_any(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
+                                        uint32_t max_wah, const uint32_t* d_totals, const uint32_t* ph_start,
+                                        const uint32_t* ph_cnt, const uint32_t* ph_gpre, uint32_t n_blocks, uint32_t n_groups) {
     const uint32_t lds = L.y_stride64 * 8u;
-    if (lds > 16384u && L.yp_stride <= 1024u * (uint32_t)WAH_WIDE_STRIPES && !getenv("XSI_NO_WIDE_EXPAND")) {
+    if (wah_expand_is_wide(L)) {
         const uint32_t lds_w = lds + 4u * ((uint32_t)WAH_WIDE_STRIPES * 16u + 16u);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_expand_wide),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
         if (e != hipSuccess) return e;
-        k_wah_expand_wide<<<dim3(max_wah), dim3(1024), lds_w, s>>>(file, blocks, L, d_totals);
+        k_wah_expand_wide<<<dim3(ph_start ? n_groups : max_wah), dim3(1024), lds_w, s>>>(file, blocks, L, d_totals, ph_start, ph_gpre,
+                                                                                       n_blocks);
         return hipGetLastError();
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_expand),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_wah_expand<<<dim3((max_wah + WAH_LINES_PER_WAVE - 1u) / WAH_LINES_PER_WAVE), dim3(64), lds, s>>>(
-        file, blocks, L, d_totals, nullptr, nullptr, nullptr, 0u);
+    const uint32_t grid = ph_start ? n_groups : (max_wah + WAH_LINES_PER_WAVE - 1u) / WAH_LINES_PER_WAVE;
+    k_wah_expand<<<dim3(grid), dim3(64), lds, s>>>(file, blocks, L, d_totals, ph_start, ph_cnt, ph_gpre, n_blocks);
     return hipGetLastError();
 }
 
-static_assert(WAH_EXPAND_LINES_PER_WAVE == WAH_LINES_PER_WAVE, "the phase table counts groups of this many lines");
+hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
+                             uint32_t max_wah, const uint32_t* d_totals) {
+    if (!max_wah) return hipSuccess;
+    return launch_wah_expand_any(s, file, blocks, L, max_wah, d_totals, nullptr, nullptr, nullptr, 0u, 0u);
+}
+
 hipError_t launch_wah_expand_phase(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
                                    const uint32_t* d_totals, const uint32_t* ph_start, const uint32_t* ph_cnt,
                                    const uint32_t* ph_gpre, uint32_t n_blocks, uint32_t n_groups) {
     if (!n_groups) return hipSuccess;
-    const uint32_t lds = L.y_stride64 * 8u;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_expand),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    k_wah_expand<<<dim3(n_groups), dim3(64), lds, s>>>(file, blocks, L, d_totals, ph_start, ph_cnt, ph_gpre, n_blocks);
-    return hipGetLastError();
+    return launch_wah_expand_any(s, file, blocks, L, 0u, d_totals, ph_start, ph_cnt, ph_gpre, n_blocks, n_groups);
 }
 
 // allele counts without expansion (fill_allele_counts_advance, accessor_internals_new.hpp:407-438):

@@ -133,13 +133,14 @@ hipError_t launch_sparse_walk(hipStream_t s, const uint8_t* file, const DecBlock
 hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
                              uint32_t max_wah, const uint32_t* d_totals);
 // one range of every block's WAH lines: ph_start[b] first line (batch-wide rank), ph_cnt[b] lines,
-// ph_gpre[b] groups of WAH_EXPAND_LINES_PER_WAVE lines before block b (ph_gpre[n_blocks] = n_groups)
-constexpr uint32_t WAH_EXPAND_LINES_PER_WAVE = 4;
+// ph_gpre[b] groups of wah_expand_lines_per_group(L) lines before block b (ph_gpre[n_blocks] = n_groups)
+uint32_t wah_expand_lines_per_group(const DecLines& L);
 hipError_t launch_wah_expand_phase(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
                                    const uint32_t* d_totals, const uint32_t* ph_start, const uint32_t* ph_cnt,
                                    const uint32_t* ph_gpre, uint32_t n_blocks, uint32_t n_groups);
 // the one-workgroup-per-block decode chain over one range of lines; ranks parked in `state` between the launches
 bool rank_decode_phased_ok(uint32_t N, uint32_t yp_stride, uint32_t n_blocks);
+uint64_t rank_decode_state_words(uint32_t N, uint32_t n_blocks);
 hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                                     uint32_t* out_rows, uint32_t out_stride_w, const uint32_t* ph_start,
                                     const uint32_t* ph_cnt, uint32_t* state, bool first, bool last);

@@ -218,18 +218,28 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t cg0 = (blockIdx.x * W + w) * E;  // first chunk of my wave
-    const uint32_t wah_first = D.wah_first, n_wah = D.n_wah;
+    const uint32_t wah_first = A.ph_start ? A.ph_start[blockIdx.y] : D.wah_first;
+    const uint32_t n_wah = A.ph_start ? A.ph_cnt[blockIdx.y] : D.n_wah;
+    if (n_wah == 0) return;  // no line of this block in this range: its ranks stay parked
     const uint32_t CWP = A.yp_stride;
     uint2* row = reinterpret_cast<uint2*>(smem);
     const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     using LdsPairBig = __attribute__((address_space(3))) rank_u32x2;
 
     uint32_t r[E];
-    static_for<0, E>([&](auto ecn) {
-        constexpr int e = decltype(ecn)::value;
-        r[e] = (cg0 + (uint32_t)e) * 64u + lane;
-        if (r[e] >= N) r[e] = 0;
-    });
+    uint32_t* park = A.state + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (uint32_t)E) * T + tid;  // chunk e: park[e * T]
+    if (!A.ph_start || A.ph_first) {
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            r[e] = (cg0 + (uint32_t)e) * 64u + lane;
+            if (r[e] >= N) r[e] = 0;
+        });
+    } else {
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            r[e] = park[(size_t)e * T];
+        });
+    }
     uint32_t vm_lo = 0, vm_hi = 0;
     {
         const uint64_t base = (uint64_t)(cg0 + lane) * 64u;
@@ -316,6 +326,12 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
         line = line_n;
         Z = Z_n;
         __syncthreads();
+    }
+    if (A.ph_start && !A.ph_last) {
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            park[(size_t)e * T] = r[e];
+        });
     }
 }
 
@@ -612,7 +628,24 @@ static hipError_t launch_rank_wg(hipStream_t s, uint32_t n_blocks, const RankArg
     return hipErrorInvalidValue;
 }
 
-bool rank_decode_phased_ok(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) { return use_rank_wg(N, yp_stride, n_blocks); }
+// which family launch_rank_decode picks: 1 one workgroup per block, 2 long rows (haplotype splits, row staged whole),
+// 0 the batch-staged kernels.  The first two can run a block's lines in ranges (ranks parked between launches).
+static int rank_decode_family(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
+    if (use_rank_wg(N, yp_stride, n_blocks)) return 1;
+    static const uint32_t big_min = [] {
+        const char* e = getenv("XSI_BIG_RANK_MIN_N");
+        return e ? (uint32_t)atoi(e) : 49152u;  // measured: 11.3 ms against 14.2 ms at 64 976 hap x 64 blocks, slower at 40 000
+    }();
+    const bool stage = N <= 65536u;
+    if ((!stage || N >= big_min) && yp_stride <= 1024u * 20u && yp_stride * 8u <= 160u * 1024u && !getenv("XSI_NO_BIG_RANK")) return 2;
+    return 0;
+}
+
+bool rank_decode_phased_ok(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) { return rank_decode_family(N, yp_stride, n_blocks) != 0; }
+
+uint64_t rank_decode_state_words(uint32_t N, uint32_t n_blocks) {  // ranks of every workgroup: whole 16 384-haplotype units
+    return (uint64_t)n_blocks * (((uint64_t)N + 65535u) / 65536u) * 65536u;
+}
 
 hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                                     uint32_t* out_rows, uint32_t out_stride_w, const uint32_t* ph_start,
@@ -632,7 +665,7 @@ hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint3
     R.state = state;
     R.ph_first = first ? 1u : 0u;
     R.ph_last = last ? 1u : 0u;
-    return launch_rank_wg(s, n_blocks, R);
+    return rank_decode_family(L.N, L.yp_stride, n_blocks) == 1 ? launch_rank_wg(s, n_blocks, R) : launch_rank_big(s, n_blocks, R);
 }
 
 hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
@@ -650,14 +683,9 @@ hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_
     const RankGeom g = rank_geometry(L.N, L.yp_stride, n_blocks);
     R.batch = g.batch;
     R.log2_cwp = g.log2_cwp;
-    static const uint32_t big_min = [] {
-        const char* e = getenv("XSI_BIG_RANK_MIN_N");
-        return e ? (uint32_t)atoi(e) : 49152u;  // measured: 11.3 ms against 14.2 ms at 64 976 hap x 64 blocks, slower at 40 000
-    }();
-    if (use_rank_wg(L.N, L.yp_stride, n_blocks)) return launch_rank_wg(s, n_blocks, R);
-    if ((!g.stage || L.N >= big_min) && L.yp_stride <= 1024u * 20u && L.yp_stride * 8u <= 160u * 1024u &&
-        !getenv("XSI_NO_BIG_RANK"))
-        return launch_rank_big(s, n_blocks, R);
+    const int fam = rank_decode_family(L.N, L.yp_stride, n_blocks);
+    if (fam == 1) return launch_rank_wg(s, n_blocks, R);
+    if (fam == 2) return launch_rank_big(s, n_blocks, R);
     return g.stage ? launch_rank<true>(s, g, n_blocks, R) : launch_rank<false>(s, g, n_blocks, R);
 }
 
