@@ -355,6 +355,11 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
     auto meet = [&]() -> bool {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores have left
         __syncthreads();
+        // every wave is done with the table of the line before: its bit words are cleared here, while lane 0 waits
+        // for the other workgroups (thread t works on entries i * 1024 + t: neighbouring lanes on neighbouring
+        // entries, no bank conflicts; 16 entries in a row per thread put all 64 lanes of an access on two banks)
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) table[(size_t)i * T + tid] = make_uint2(0u, 0u);
         arrivals += A.S;
         if (tid == 0) {
             __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -374,12 +379,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
     };
     // phases A + B: the lists of parity `par` -> row `rank` in the table (and my share of it in HBM); returns the zeros
     auto build_table = [&](uint32_t rank, uint32_t par) -> uint32_t {
-        // every wave is done with the previous table (the meeting's barriers came first): clear its bit words
-        // (thread t works on entries i * 1024 + t: neighbouring lanes on neighbouring entries, no bank conflicts;
-        // 16 entries in a row per thread put all 64 lanes of an access on two banks)
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) table[(size_t)i * T + tid] = make_uint2(0u, 0u);
-        lds_barrier();
+        // (the meeting cleared the table's bit words and ended with a barrier)
         const uint32_t* lst = glists + (size_t)par * n_lists * MULTI_LIST_CAP;
         // wave w applies lists w * S .. w * S + S - 1.  The loads are sc1 round trips to L2 / memory: the counts of
         // all of them come in one load, then four 16-byte loads per lane are in flight before any is used.
