@@ -208,49 +208,6 @@ __device__ __forceinline__ void wah_encode_chunk(uint32_t val, bool valid, bool 
     c.out += total;
 }
 
-// wah_encode_chunk for lines of at most 16383 groups (245 745 bits), where no run can outgrow the counter
-// of a fill word.  The run structure of the 64 groups is worked out on the two ballots "group is all zeros" /
-// "group is all ones" with scalar 64-bit logic; the lanes only build and store their own word.
-// `le_lo/le_hi` = bits 0..lane set (per lane, computed once per line); `nvalid` = groups in this chunk.
-template <bool WRITE>
-__device__ __forceinline__ void wah_encode_chunk_short(uint32_t val, uint32_t nvalid, bool last_chunk, uint32_t next_val,
-                                                       uint32_t le_lo, uint32_t le_hi, WahCarry& c,
-                                                       uint16_t* __restrict__ dst) {
-    const uint32_t lane = lane_id();
-    const uint64_t V = nvalid >= 64u ? ~0ull : ((1ull << nvalid) - 1ull);
-    const uint64_t Z = __ballot(val == 0u) & V;
-    const uint64_t O = __ballot(val == 0x7FFFu) & V;
-    // a fill group continues a run when the group before it (the carry for lane 0) is of its type
-    const uint64_t Zs = Z & ((Z << 1) | (uint64_t)(c.type == 0u));
-    const uint64_t Os = O & ((O << 1) | (uint64_t)(c.type == 1u));
-    const uint64_t H = V & ~(Zs | Os);  // heads: literals and first groups of runs
-    const uint32_t li = nvalid - 1u;    // last valid lane
-    const uint32_t tl = ((Z >> li) & 1ull) ? 0u : (((O >> li) & 1ull) ? 1u : 2u);
-    const uint32_t nt = (next_val == 0u) ? 0u : ((next_val == 0x7FFFu) ? 1u : 2u);
-    const bool end_last = last_chunk || nt == 2u || nt != tl;
-    // a word is emitted where a run ends: the group after it is a head (a literal is a run of one)
-    const uint64_t E = ((H >> 1) | ((uint64_t)end_last << li)) & V;
-    if (WRITE) {
-        const uint32_t pos = mbcnt64(E);
-        if (__builtin_amdgcn_inverse_ballot_w64(E)) {
-            const uint32_t hl = (uint32_t)H & le_lo, hh = (uint32_t)(H >> 32) & le_hi;
-            // groups of the run that ends here: back to its head, or through the carry when it began earlier
-            const uint32_t top = hh ? 63u - (uint32_t)__clz((int)hh) : 31u - (uint32_t)__clz((int)hl);  // hl = hh = 0: unused
-            const uint32_t len = (hh | hl) ? lane - top + 1u : c.len + lane + 1u;
-            const bool fill = val == 0u || val == 0x7FFFu;
-            dst[c.out + pos] = (uint16_t)(fill ? (0x8000u | (val & 0x4000u) | len) : val);
-        }
-    }
-    if (tl < 2u) {
-        const uint64_t hb = H;  // H has no bit above li
-        c.len = hb ? li - (63u - (uint32_t)__clzll((long long)hb)) + 1u : c.len + nvalid;
-    } else {
-        c.len = 0u;
-    }
-    c.type = tl;
-    c.out += (uint32_t)__popcll(E);
-}
-
 // Encode a whole packed bit row with one wave.  Returns the number of WAH16 words.  The groups of
 // the next two chunks are loaded before the current chunk is encoded, so the serial run-merging
 // logic never waits on memory.
@@ -262,24 +219,6 @@ __device__ __forceinline__ uint32_t wave_wah_encode_row(const uint32_t* __restri
     WahCarry c{3u, 0u, 0u};
     uint32_t cur = load_group15(row, lane, nbits);
     uint32_t n1 = load_group15(row, lane + 64u, nbits);
-    if (G <= WAH_MAXC) {
-        // no run can outgrow a fill word: the lean chunk encoder, and chunks that only extend a run of zeros
-        // are skipped on a ballot
-        const uint64_t le = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
-        const uint32_t le_lo = (uint32_t)le, le_hi = (uint32_t)(le >> 32);
-        for (uint32_t g0 = 0; g0 < G; g0 += 64u) {
-            const uint32_t n2 = load_group15(row, g0 + 128u + lane, nbits);
-            const bool last = g0 + 64u >= G;
-            const uint32_t next_val = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1);
-            if (!last && c.type == 0u && next_val == 0u && __ballot(cur != 0u) == 0ull)
-                c.len += 64u;
-            else
-                wah_encode_chunk_short<WRITE>(cur, last ? G - g0 : 64u, last, next_val, le_lo, le_hi, c, dst);
-            cur = n1;
-            n1 = n2;
-        }
-        return c.out;
-    }
     for (uint32_t g0 = 0; g0 < G; g0 += 64u) {
         const uint32_t n2 = load_group15(row, g0 + 128u + lane, nbits);
         const bool last = g0 + 64u >= G;
