@@ -502,6 +502,8 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
             if (lane == 0)
                 __hip_atomic_store(gcounts + (size_t)parity * n_lists + member * W + w, n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
+        uint32_t lane_here = lane;
+        asm volatile("" : "+v"(lane_here));  // the identity ranks are formed in this block's code, not kept across the blocks
         // line 0: ranks are the identity, its row is the input row itself
         {
             const v4u rs0 = in_rsrc(lines[0]);
@@ -511,7 +513,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                 sbuf_load_chunks<G>(rs0, c0 + (uint32_t)g0, x0);
                 static_for<0, G>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
-                    append(x0[e], (c0 + (uint32_t)(g0 + e)) * 64u + lane);  // bits at or beyond N are zero
+                    append(x0[e], (c0 + (uint32_t)(g0 + e)) * 64u + lane_here);  // bits at or beyond N are zero
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -521,8 +523,6 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
         uint32_t Z = build_table(wah_first, parity);
         parity ^= 1u;
         uint32_t r[E];
-        uint32_t lane_here = lane;
-        asm volatile("" : "+v"(lane_here));  // the identity ranks are formed here, not kept across the blocks
         static_for<0, E>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
             const uint32_t h = (c0 + (uint32_t)e) * 64u + lane_here;
