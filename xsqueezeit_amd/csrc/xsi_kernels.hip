@@ -2447,11 +2447,69 @@ __global__ void __launch_bounds__(1024) k_wah_expand_wide(const uint8_t* __restr
     const uint32_t start = L.wah_start[j];
     const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
     __syncthreads();
-    if (w == 0) {
-        uint32_t ones;
+    {
+        // all 16 waves expand the line's words, 1024 at a time (wave_wah_expand_row's logic with the first group of
+        // a word taken from a workgroup scan): a line of 500 000 bits has some 2500 words
         const uint16_t* src = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah) + start;
-        (void)wave_wah_expand_row(src, D.wah_words - start, nbits, row, &ones);
-        if (lane == 0) L.ones[l] = ones;
+        const uint32_t max_words = D.wah_words - start;
+        const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
+        const uint32_t row_bits = ((nbits + 31u) >> 5) << 5;
+        uint32_t gbase = 0, cnt1 = 0;
+        for (uint32_t wbase = 0; wbase < max_words && gbase < G; wbase += 1024u) {
+            const uint32_t wi = wbase + tid;
+            const bool have = wi < max_words;
+            const uint32_t word = have ? (uint32_t)src[wi] : 0u;
+            const bool fill = (word & 0x8000u) != 0u;
+            const uint32_t ng = have ? (fill ? (word & WAH_MAXC) : 1u) : 0u;
+            const uint32_t inc = wave_scan_incl_dpp(ng);
+            if (lane == 63u) tot[w] = inc;
+            __syncthreads();
+            const uint32_t sc = row16_scan_incl(lane < 16u ? tot[lane] : 0u);
+            const uint32_t wave_base = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
+            const uint32_t chunk_groups = (uint32_t)__builtin_amdgcn_readlane((int)sc, 15);
+            const uint32_t sg = gbase + wave_base + inc - ng;  // first group covered by this word
+            const bool active = have && sg < G;
+            if (active) {
+                if (!fill) {
+                    const uint32_t o = sg * WAH_BITS;
+                    const uint32_t v = word & 0x7FFFu;
+                    cnt1 += (uint32_t)__popc(v);
+                    if (v && o < row_bits) {
+                        atomicOr(&row[o >> 5], v << (o & 31u));
+                        if ((o & 31u) > 17u && (o >> 5) + 1u < (row_bits >> 5)) atomicOr(&row[(o >> 5) + 1u], v >> (32u - (o & 31u)));
+                    }
+                } else if (word & 0x4000u) {
+                    cnt1 += ng * WAH_BITS;
+                }
+            }
+            uint64_t F = __ballot(active && fill && (word & 0x4000u) && ng);  // ones-fills: the wave paints each run
+            while (F) {
+                const int f = __ffsll((long long)F) - 1;
+                F &= F - 1ull;
+                const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)sg, f);
+                const uint32_t fn = (uint32_t)__builtin_amdgcn_readlane((int)ng, f);
+                uint32_t b0 = fs * WAH_BITS, b1 = b0 + fn * WAH_BITS;
+                if (b1 > row_bits) b1 = row_bits;
+                if (b0 >= b1) continue;
+                const uint32_t w0 = b0 >> 5, w1 = (b1 - 1u) >> 5;
+                for (uint32_t x = w0 + lane; x <= w1; x += 64u) {
+                    uint32_t m = 0xFFFFFFFFu;
+                    if (x == w0) m &= 0xFFFFFFFFu << (b0 & 31u);
+                    if (x == w1 && (b1 & 31u)) m &= (1u << (b1 & 31u)) - 1u;
+                    atomicOr(&row[x], m);
+                }
+            }
+            gbase += chunk_groups;
+            __syncthreads();  // tot[] is reused by the next round (and by the scan below)
+        }
+        const uint32_t wsum = wave_sum(cnt1);
+        if (lane == 0) tot[16 + w] = wsum;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t ones = 0;
+            for (int i = 0; i < 16; ++i) ones += tot[16 + i];
+            L.ones[l] = ones;
+        }
     }
     __syncthreads();
     const uint32_t stripes = (L.yp_stride + 1023u) / 1024u;  // <= WAH_WIDE_STRIPES
