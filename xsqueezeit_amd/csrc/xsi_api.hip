@@ -319,7 +319,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     // WAH16 words per line, worst case ceil(N/15) (+1 for the saturation split): encode once, then copy
     L.wah_scratch_stride = ((N + 14u) / 15u + 3u) & ~1u;  // even: rows stay 4-byte aligned for k_wah_write
     L.wah_scratch = nullptr;  // without it the lines are sized first and encoded again straight into place
-    if (use_wah_scratch && !wah_units_ok(L.y_stride64)) WS(L.wah_scratch, "enc.wah_scratch", 2ull * L.wah_scratch_stride * y_rows);
+    if (use_wah_scratch && !wah_units_any(L.y_stride64)) WS(L.wah_scratch, "enc.wah_scratch", 2ull * L.wah_scratch_stride * y_rows);
     WS(L.flagbits, "enc.flagbits", 4ull * (MAX_BIN_PER_BLOCK / 32) * FV_COUNT * (size_t)n_blocks);
     WS(L.flagwah, "enc.flagwah", 2ull * FLAG_WORDS_MAX * FV_COUNT * (size_t)n_blocks);
     uint32_t* d_totals;
@@ -440,7 +440,7 @@ int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const vo
     // once and copied into place.  A job whose workspace exceeds the budget drops the WAH scratch first (lines are
     // then sized and encoded twice), then runs as batches of whole blocks: blocks are independent
     // (gt_block.hpp:179-180, xsi_factory.hpp:527-539), so the bytes are those of a single call.
-    const bool units = wah_units_ok((N + 63u) / 64u);
+    const bool units = wah_units_any(y_stride64_for(N));
     const uint64_t y_line = 8ull * y_stride64_for(N), scratch_line = units ? 0 : 2ull * (((N + 14u) / 15u + 3u) & ~1u), misc_line = 40;
     const uint64_t budget = ws_budget_now(ctx);
     uint64_t wah_all = 0;

@@ -1492,6 +1492,157 @@ __global__ void __launch_bounds__(256) k_wah_units(const EncBlock* __restrict__ 
     }
 }
 
+// Rows above 8 KiB: the unit encoder with one 1024-thread workgroup per line (the serial encoder walks a line
+// of 500 000 bits in 521 chunks: 28 + 38 ms for the two passes of the configs[3] shard).  Thread t owns unit
+// r * 1024 + t in round r (at most two rounds: 65 536 groups); heads as in wah_unit_classify; the first head
+// after a unit comes from the waves' "unit has a head" ballots kept in LDS.  Lines this long can hold a run
+// that outgrows a fill word (16 383 groups): only the LAST head of a unit can start one, it then takes
+// ceil(len / 16383) words (counts of 16383, then the rest - as the serial encoder does it).
+constexpr int WAH_WIDE_ROUNDS = 2;
+constexpr uint32_t WAH_WIDE_UNITS = 1024u * (uint32_t)WAH_WIDE_ROUNDS;
+template <bool WRITE_PASS>
+__global__ void __launch_bounds__(1024) k_wah_units_wide(const EncBlock* __restrict__ blocks, EncLines L,
+                                                         const uint32_t* __restrict__ d_total_wah, uint32_t max_wah,
+                                                         uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result,
+                                                         uint32_t row_words_lds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wah_smem[];
+    if (WRITE_PASS && d_result[3]) return;  // capacity error: nothing may be written
+    const uint32_t j = blockIdx.x;
+    const uint32_t total = WRITE_PASS ? (max_wah < (uint32_t)d_result[2] ? max_wah : (uint32_t)d_result[2]) : d_total_wah[0];
+    if (j >= total) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    LdsU32W* lrow_w = reinterpret_cast<LdsU32W*>((__attribute__((address_space(3))) unsigned char*)wah_smem);
+    LdsCU32* lrow = reinterpret_cast<LdsCU32*>(lrow_w);
+    LdsU32W* fh = lrow_w + row_words_lds;           // [WAH_WIDE_UNITS] first head of the unit (group index)
+    LdsU32W* hb = fh + WAH_WIDE_UNITS;              // [2 * 16 * WAH_WIDE_ROUNDS] ballots "unit has a head", lo / hi words
+    LdsU32W* sc = hb + 2u * 16u * WAH_WIDE_ROUNDS;  // [16 * WAH_WIDE_ROUNDS + 2] wave totals of the word counts
+    const uint32_t l = L.wah_lines[j];
+    const uint32_t nbits = nbits_of(L, l);
+    const uint32_t rw = L.y_stride64 * 2u;
+    {  // stage the row (16-byte loads; rows are 16-byte multiples: y_stride64 is even above 8 KiB), zeros behind it
+        const uint4* src = reinterpret_cast<const uint4*>(L.yrows + (size_t)j * L.y_stride64);
+        typedef uint32_t wah_u32x4 __attribute__((ext_vector_type(4)));
+        using LdsU4 = __attribute__((address_space(3))) wah_u32x4;
+        LdsU4* l4 = reinterpret_cast<LdsU4*>(lrow_w);
+        for (uint32_t i = tid; i < rw / 4u; i += 1024u) {
+            const uint4 v = src[i];
+            l4[i] = wah_u32x4{v.x, v.y, v.z, v.w};
+        }
+        for (uint32_t i = rw + tid; i < row_words_lds; i += 1024u) lrow_w[i] = 0;
+    }
+    __syncthreads();
+    // bits at or beyond nbits read as zero (the reference pads the last group with zeros, wah.hpp:547-565)
+    if (tid == 0 && (nbits & 31u)) lrow_w[nbits >> 5] &= (1u << (nbits & 31u)) - 1u;
+    for (uint32_t i = ((nbits + 31u) >> 5) + tid; i < rw; i += 1024u) lrow_w[i] = 0;
+    __syncthreads();
+    const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
+    const uint32_t units = (G + 31u) >> 5;
+    WahUnit m[WAH_WIDE_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < WAH_WIDE_ROUNDS; ++r) {
+        const uint32_t u = (uint32_t)r * 1024u + tid;
+        m[r] = WahUnit{0u, 0u, 0u};
+        if (u < units) wah_unit_classify(lrow, u, G, m[r]);
+        const uint64_t B = __ballot(m[r].H != 0u);
+        if (lane == 0) {
+            hb[2u * ((uint32_t)r * 16u + w)] = (uint32_t)B;
+            hb[2u * ((uint32_t)r * 16u + w) + 1u] = (uint32_t)(B >> 32);
+        }
+        fh[u] = u * 32u + (uint32_t)__builtin_ctz(m[r].H | 0x80000000u);
+    }
+    __syncthreads();
+    // per unit: first head after it, words it emits (one per head; the last head's run may need more), their prefix
+    uint32_t nh[WAH_WIDE_ROUNDS], nw[WAH_WIDE_ROUNDS], base[WAH_WIDE_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < WAH_WIDE_ROUNDS; ++r) {
+        const uint32_t slot = (uint32_t)r * 16u + w;  // my wave's ballot
+        uint32_t tu = ~0u;
+        {
+            uint64_t mine = ((uint64_t)hb[2u * slot + 1u] << 32) | hb[2u * slot];
+            mine = lane == 63u ? 0ull : (mine & (~0ull << (lane + 1u)));
+            if (mine) tu = slot * 64u + (uint32_t)__builtin_ctzll(mine);
+            for (uint32_t q = slot + 1u; tu == ~0u && q < 16u * (uint32_t)WAH_WIDE_ROUNDS; ++q) {
+                const uint64_t b = ((uint64_t)hb[2u * q + 1u] << 32) | hb[2u * q];
+                if (b) tu = q * 64u + (uint32_t)__builtin_ctzll(b);
+            }
+        }
+        nh[r] = tu != ~0u ? fh[tu] : G;
+        uint32_t n = (uint32_t)__popc(m[r].H);
+        if (m[r].H) {
+            const uint32_t k = 31u - (uint32_t)__builtin_clz(m[r].H);  // the unit's last head
+            if ((m[r].F >> k) & 1u) {
+                const uint32_t len = nh[r] - (((uint32_t)r * 1024u + tid) * 32u + k);
+                n += (len + WAH_MAXC - 1u) / WAH_MAXC - 1u;
+            }
+        }
+        nw[r] = n;
+        const uint32_t inc = wave_scan_incl_dpp(n);
+        base[r] = inc - n;
+        if (lane == 63u) sc[slot] = inc;
+    }
+    __syncthreads();
+    if (w == 0) {  // 32 wave totals, in unit order
+        const uint32_t v = lane < 16u * (uint32_t)WAH_WIDE_ROUNDS ? sc[lane] : 0u;
+        const uint32_t inc = wave_scan_incl_dpp(v);
+        if (lane < 16u * (uint32_t)WAH_WIDE_ROUNDS) sc[lane] = inc - v;
+        if (lane == 63u) sc[16u * (uint32_t)WAH_WIDE_ROUNDS] = inc;
+    }
+    __syncthreads();
+    if (!WRITE_PASS) {
+        if (tid == 0) L.wah_len[j] = sc[16u * (uint32_t)WAH_WIDE_ROUNDS];
+        return;
+    }
+    const EncBlock& Bk = blocks[L.line_block[l]];
+    uint16_t* dst = reinterpret_cast<uint16_t*>(out + Bk.out_off + 16u + Bk.off_wah) + L.wah_off[j];
+#pragma unroll
+    for (int r = 0; r < WAH_WIDE_ROUNDS; ++r) {
+        const uint32_t gb = ((uint32_t)r * 1024u + tid) * 32u;
+        uint32_t idx = sc[(uint32_t)r * 16u + w] + base[r];
+        uint32_t Hr = m[r].H;
+        while (__any(Hr != 0u)) {
+            if (Hr) {
+                const uint32_t k = (uint32_t)__builtin_ctz(Hr);
+                Hr &= Hr - 1u;
+                const uint32_t g = gb + k;
+                const uint32_t nxt = Hr ? gb + (uint32_t)__builtin_ctz(Hr) : nh[r];
+                if ((m[r].F >> k) & 1u) {
+                    const uint32_t tag = 0x8000u | (((m[r].O >> k) & 1u) << 14);
+                    uint32_t len = nxt - g;
+                    while (len > WAH_MAXC) {  // a run that outgrows the counter: only ever the unit's last head
+                        dst[idx++] = (uint16_t)(tag | WAH_MAXC);
+                        len -= WAH_MAXC;
+                    }
+                    dst[idx++] = (uint16_t)(tag | len);
+                } else {
+                    const uint32_t o = g * WAH_BITS;
+                    dst[idx++] = (uint16_t)(__builtin_amdgcn_alignbit(lrow[(o >> 5) + 1u], lrow[o >> 5], o & 31u) & 0x7FFFu);
+                }
+            }
+        }
+    }
+}
+
+static bool wah_units_wide_ok(uint32_t y_stride64) {
+    const bool off = getenv("XSI_WAH_NO_UNITS") != nullptr;
+    // rows of whole 16-byte units (y_stride64 even) of at most 65 536 groups
+    return !off && y_stride64 > 64u * (uint32_t)WAH_STAGE_Q && (y_stride64 % 2u) == 0u &&
+           (uint64_t)y_stride64 * 64u <= (uint64_t)WAH_WIDE_UNITS * 32u * WAH_BITS;
+}
+
+template <bool WRITE_PASS>
+static hipError_t launch_wah_units_wide(hipStream_t s, const EncBlock* blocks, const EncLines& L, const uint32_t* d_total_wah,
+                                        uint32_t max_wah, uint8_t* out, const uint64_t* d_result) {
+    const uint32_t rw = L.y_stride64 * 2u;
+    const uint32_t units = ((rw * 32u + WAH_BITS - 1u) / WAH_BITS + 31u) / 32u;
+    const uint32_t row_words = ((units * 15u + 1u) > rw ? (units * 15u + 1u) : rw) + 3u & ~3u;  // every unit's 15 words (+ the literal read)
+    const uint32_t lds = 4u * (row_words + WAH_WIDE_UNITS + 2u * 16u * WAH_WIDE_ROUNDS + 16u * WAH_WIDE_ROUNDS + 2u);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units_wide<WRITE_PASS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    k_wah_units_wide<WRITE_PASS><<<dim3(max_wah), dim3(1024), lds, s>>>(blocks, L, d_total_wah, max_wah, out, d_result, row_words);
+    return hipGetLastError();
+}
+
 bool wah_units_ok(uint32_t y_stride64) {
     static const bool off = getenv("XSI_WAH_NO_UNITS") != nullptr;
     // below ~12 000 haplotypes a line has fewer than 26 units for 64 lanes: the serial encoder with its scratch
@@ -1499,9 +1650,12 @@ bool wah_units_ok(uint32_t y_stride64) {
     return !off && y_stride64 >= 192u && y_stride64 <= 64u * (uint32_t)WAH_STAGE_Q;
 }
 
+bool wah_units_any(uint32_t y_stride64) { return wah_units_ok(y_stride64) || wah_units_wide_ok(y_stride64); }
+
 hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_total_wah, uint32_t max_wah) {
     if (!max_wah) return hipSuccess;
     const uint32_t per_wg = 4u * WAH_LINES_PER_WAVE;
+    if (wah_units_wide_ok(L.y_stride64)) return launch_wah_units_wide<false>(s, nullptr, L, d_total_wah, max_wah, nullptr, nullptr);
     if (wah_units_ok(L.y_stride64)) {
         const uint32_t lds = 4u * 4u * WAH_UNIT_WAVE_WORDS;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units<false>),
@@ -1569,6 +1723,7 @@ hipError_t launch_wah_write(hipStream_t s, const EncBlock* blocks, const EncLine
                             uint8_t* out, const uint64_t* d_result) {
     if (!max_wah) return hipSuccess;
     const uint32_t per_wg = 4u * WAH_LINES_PER_WAVE;
+    if (!L.wah_scratch && wah_units_wide_ok(L.y_stride64)) return launch_wah_units_wide<true>(s, blocks, L, nullptr, max_wah, out, d_result);
     if (!L.wah_scratch && wah_units_ok(L.y_stride64)) {  // classify again, words straight into place
         const uint32_t lds = 4u * 4u * WAH_UNIT_WAVE_WORDS;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units<true>),

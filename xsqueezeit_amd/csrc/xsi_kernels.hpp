@@ -80,6 +80,8 @@ hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n
 hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_total_wah, uint32_t max_wah);
 // rows short enough for the unit encoder (no WAH scratch is needed then)
 bool wah_units_ok(uint32_t y_stride64);
+// either form of the unit encoder applies (one wave per 4 lines up to 8 KiB, one workgroup per line above)
+bool wah_units_any(uint32_t y_stride64);
 hipError_t launch_block_layout(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
                                const EncSide& S, int32_t default_phased);
 hipError_t launch_scan_blocks_out(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, uint64_t capacity,
