@@ -105,6 +105,7 @@ int xsi_hip_ctx_synchronize(xsi_hip_ctx* c) {
     if (!c) return set_error(XSI_ERR_ARG, "null context");
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->side) HIP_TRY(hipStreamSynchronize(c->side));  // normally already joined; covers error exits
+    if (c->side2) HIP_TRY(hipStreamSynchronize(c->side2));
     return XSI_OK;
 }
 
