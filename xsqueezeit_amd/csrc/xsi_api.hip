@@ -844,7 +844,7 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
         const int v = e ? atoi(e) : 12;
         return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
     }();
-    if (n_phases > 1u && !any_haploid && P.n_wah >= 64u * P.n_blocks && rank_decode_phased_ok(L.N, L.yp_stride, P.n_blocks)) {
+    if (n_phases > 1u && !any_haploid && P.n_wah >= 256u * P.n_blocks && rank_decode_phased_ok(L.N, L.yp_stride, P.n_blocks)) {
         const uint32_t K = n_phases, nb = P.n_blocks, lpg = wah_expand_lines_per_group(L);
         // per phase and block: first WAH line (batch-wide rank), lines, and the running number of 4-line groups
         P.phase_tab.assign((size_t)K * (3u * nb + 1u), 0u);
