@@ -1,16 +1,19 @@
 // xsi_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the xSqueezeIt genotype-block codec.
 //
 // Encode: count -> classify (WAH vs sparse, per-block scans) -> PBWT chain -> WAH16 sizing / writing
-// (one wave per four lines) -> sparse lists (one wave per line, on the side stream) -> block layout +
-// dictionary.  The chain is the dominant kernel and comes in three forms:
+// (unit encoder: one wave per four lines up to 8 KiB rows, one workgroup per line above; the serial one-wave
+// encoder for very short rows) -> sparse lists (one wave per line, on the side stream) -> block layout +
+// dictionary.  The chain is the dominant kernel.  The element-major forms live in xsi_rankenc.hip
+// (k_chain_rank_enc up to 65 536 haplotypes, k_chain_rank_enc_multi up to 524 288); here are the position-major ones:
 //   k_chain_lds     prefix array `a` in LDS, bit columns staged through LDS, wave ballot + mbcnt for the
 //                   stable partition; with fewer blocks than CUs a block is cut into line segments and a
 //                   later segment gets its starting order from an LSD radix pre-pass (chain_prepass);
-//   k_chain_stream  N >= 49152: `a` ping-pongs in HBM/L2 and is read once per line, the per-segment
+//   k_chain_stream  above 524 288 haplotypes: `a` ping-pongs in HBM/L2 and is read once per line, the per-segment
 //                   zero counts are accumulated one line ahead;
 //   k_chain_global  two-pass fallback (blocks with fully haploid lines at large N; decode of those).
 // Decode mirrors it: parse -> flags -> WAH line boundaries (tiled scan) -> expansion to rank-select
-// rows -> element-major chain (xsi_rank.hip) -> sparse fill (side stream).
+// rows -> element-major chain (xsi_rank.hip), range of lines by range of lines with the expansion of the next
+// range underneath (decode_planes, xsi_api.hip) -> sparse fill (side stream).
 // Reference behaviour restated per kernel (paths relative to the reference tree).
 #include "xsi_kernels.hpp"
 

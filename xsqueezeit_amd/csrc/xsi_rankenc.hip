@@ -1,4 +1,5 @@
-// xsi_rankenc.hip — element-major ("rank tracking") PBWT encode chain for gfx950, N <= 65536.
+// xsi_rankenc.hip — element-major ("rank tracking") PBWT encode chains for gfx950: k_chain_rank_enc (N <= 65536, one
+// workgroup per block, described here) and k_chain_rank_enc_multi (N <= 524288, several workgroups per block, below).
 //
 // Reference behaviour (per block, for every WAH line k in order; sparse lines never touch `a`,
 // gt_block.hpp:299-326):
