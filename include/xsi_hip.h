@@ -256,6 +256,13 @@ int xsi_writer_open(xsi_writer** w, xsi_hip_ctx* ctx, const char* path, const xs
 /* XsiFactoryInterface::append(bcf_fri): one BCF line, host int32 row (bcf_fri.gt_arr), ngt values,
  * n_allele = bcf_fri.line->n_allele.  Lines are batched per block and encoded on the GPU. */
 int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t n_allele);
+/* The same without the copy: xsi_writer_row_buffer returns the next row's slot in the writer's pinned staging
+ * (room for 2 * n_samples int32 values; NULL on error) for the caller to fill - e.g. as the destination array of
+ * bcf_get_genotypes, which GtCompressorStream otherwise fills and hands to append - and xsi_writer_commit_row
+ * appends it.  One buffer is outstanding at a time.  The per-line memcpy of xsi_writer_append is what bounds the
+ * file-level write rate on one host core. */
+int32_t* xsi_writer_row_buffer(xsi_writer* w);
+int xsi_writer_commit_row(xsi_writer* w, uint32_t ngt, uint32_t n_allele);
 /* XsiFactoryInterface::finalize_file(max_ploidy); max_ploidy = 0 -> use the maximum seen. */
 int xsi_writer_finalize(xsi_writer* w, uint32_t max_ploidy);
 void xsi_writer_close(xsi_writer* w);

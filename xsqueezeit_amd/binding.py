@@ -45,7 +45,7 @@ SYMBOLS = [
     "xsi_hip_ctx_synchronize", "xsi_hip_ctx_workspace_bytes", "xsi_hip_ctx_set_timing",
     "xsi_hip_ctx_get_timing", "xsi_hip_stage_name", "xsi_hip_encode_bound", "xsi_hip_encode_packed",
     "xsi_hip_encode_gt", "xsi_hip_encode_gt_bound", "xsi_hip_make_header", "xsi_hip_decode_packed", "xsi_hip_decode_gt", "xsi_hip_decode_counts", "xsi_accessor_fill_allele_counts",
-    "xsi_hip_synth_packed", "xsi_hip_debug_chain_encode", "xsi_writer_open", "xsi_writer_append",
+    "xsi_hip_synth_packed", "xsi_hip_debug_chain_encode", "xsi_writer_open", "xsi_writer_append", "xsi_writer_row_buffer", "xsi_writer_commit_row",
     "xsi_writer_finalize", "xsi_writer_close", "xsi_accessor_open", "xsi_accessor_fill_genotype_array",
     "xsi_accessor_get_genotypes", "xsi_accessor_allele_counts", "xsi_accessor_get_internal_access", "xsi_accessor_hap_samples",
     "xsi_accessor_num_samples", "xsi_accessor_sample_name", "xsi_accessor_close",
@@ -151,6 +151,10 @@ def lib():
     L.xsi_writer_open.argtypes = [c.POINTER(vp), vp, c.c_char_p, c.POINTER(EncodeParams), c.POINTER(c.c_char_p)]
     L.xsi_writer_append.restype = c.c_int
     L.xsi_writer_append.argtypes = [vp, vp, u32, u32]
+    L.xsi_writer_row_buffer.restype = c.c_void_p
+    L.xsi_writer_row_buffer.argtypes = [vp]
+    L.xsi_writer_commit_row.restype = c.c_int
+    L.xsi_writer_commit_row.argtypes = [vp, u32, u32]
     L.xsi_writer_finalize.restype = c.c_int
     L.xsi_writer_finalize.argtypes = [vp, u32]
     L.xsi_writer_close.restype = None

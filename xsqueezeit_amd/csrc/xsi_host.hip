@@ -309,18 +309,25 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
     return XSI_OK;
 }
 
-int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t n_allele) {
-    if (!w || !h_gt) return set_error(XSI_ERR_ARG, "writer_append: null argument");
+int32_t* xsi_writer_row_buffer(xsi_writer* w) {
+    if (!w || !w->f) {
+        set_error(XSI_ERR_ARG, "writer_row_buffer: null / closed writer");
+        return nullptr;
+    }
+    // check_flush_block, xsi_factory.hpp:527-539, K blocks at a time
+    if (w->lines_in_batch == (uint64_t)w->p.block_len * w->batch_blocks) {
+        if (writer_flush_batch(w)) return nullptr;
+    }
+    return w->h_chunk + (size_t)w->chunk_fill * w->N;
+}
+
+int xsi_writer_commit_row(xsi_writer* w, uint32_t ngt, uint32_t n_allele) {
+    if (!w || !w->f) return set_error(XSI_ERR_ARG, "writer_commit_row: null / closed writer");
     if (ngt != w->p.n_samples && ngt != 2u * w->p.n_samples)
         return set_error(XSI_ERR_ARG, "PLOIDY ERROR: %u values for %u samples", ngt, w->p.n_samples);
     if (n_allele < 2) return set_error(XSI_ERR_UNSUPPORTED, "lines without an ALT allele are rejected (see xsi_hip_encode_gt)");
-    // check_flush_block, xsi_factory.hpp:527-539, K blocks at a time
-    if (w->lines_in_batch == (uint64_t)w->p.block_len * w->batch_blocks) {
-        int rc = writer_flush_batch(w);
-        if (rc) return rc;
-    }
-    int32_t* dst = w->h_chunk + (size_t)w->chunk_fill * w->N;
-    memcpy(dst, h_gt, (size_t)ngt * sizeof(int32_t));
+    if (w->lines_in_batch == (uint64_t)w->p.block_len * w->batch_blocks)
+        return set_error(XSI_ERR_ARG, "writer_commit_row without xsi_writer_row_buffer");
     w->chunk_fill++;
     w->lines_in_batch++;
     w->ngt[w->cur].push_back(ngt);
@@ -331,6 +338,17 @@ int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t
     w->entry_counter++;
     if (w->chunk_fill == w->chunk_rows) return writer_ship_chunk(w);
     return XSI_OK;
+}
+
+int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t n_allele) {
+    if (!w || !h_gt) return set_error(XSI_ERR_ARG, "writer_append: null argument");
+    if (ngt != w->p.n_samples && ngt != 2u * w->p.n_samples)
+        return set_error(XSI_ERR_ARG, "PLOIDY ERROR: %u values for %u samples", ngt, w->p.n_samples);
+    if (n_allele < 2) return set_error(XSI_ERR_UNSUPPORTED, "lines without an ALT allele are rejected (see xsi_hip_encode_gt)");
+    int32_t* dst = xsi_writer_row_buffer(w);
+    if (!dst) return XSI_ERR_HIP;  // the flush's own message stands
+    memcpy(dst, h_gt, (size_t)ngt * sizeof(int32_t));
+    return xsi_writer_commit_row(w, ngt, n_allele);
 }
 
 int xsi_writer_finalize(xsi_writer* w, uint32_t max_ploidy) {
