@@ -281,6 +281,9 @@ int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_
  * sets *ngt_arr = hap_samples (accessor.hpp:58-67). */
 int64_t xsi_accessor_get_genotypes(xsi_accessor* a, uint32_t n_alleles, uint64_t position, void** h_gt,
                                    int* ngt_arr);
+/* The line's values without the copy into a caller array: *h_gt points into the accessor's pinned host window
+ * (valid until the next call on this accessor); returns the number of values.  Counts as after a fill. */
+int64_t xsi_accessor_genotypes_view(xsi_accessor* a, uint32_t n_alleles, uint64_t position, const int32_t** h_gt);
 /* Decoded blocks stay resident in HBM (LRU) so that backward and random seeks do not replay a block
  * prefix the way accessor_internals_new.hpp:154-196 does.  Budget in bytes (default: half of the free
  * HBM at open, at most 64 GiB; XSI_ACCESSOR_CACHE_MB overrides); 0 keeps only the current block. */

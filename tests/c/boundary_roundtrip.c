@@ -165,12 +165,23 @@ int main(int argc, char** argv) {
     }
     const double t_r = now_s() - t0;
     free(gt);
+    /* the same through the view (no copy into a caller array) */
+    xsi_bm_init(&bm);
+    t0 = now_s();
+    for (uint64_t l = 0; l < n_lines; ++l) {
+        const int64_t pos = xsi_bm_next(&bm, block_len, 2);
+        const int32_t* v = NULL;
+        const int64_t n = xsi_accessor_genotypes_view(a, 2, (uint64_t)pos, &v);
+        CHECK(n);
+        if ((uint32_t)n != n_haps || v[0] != rows[l * n_haps] || v[n_haps - 1] != rows[l * n_haps + n_haps - 1]) ++bad;
+    }
+    const double t_v = now_s() - t0;
     xsi_accessor_close(a);
     xsi_hip_ctx_destroy(ctx);
     const double cells = (double)n_lines * n_haps;
     printf("%s lines=%llu haps=%u bad_lines=%llu write_cells_per_s=%.4g zero_copy_write_cells_per_s=%.4g "
-           "zero_copy_hot_source_cells_per_s=%.4g read_cells_per_s=%.4g\n",
+           "zero_copy_hot_source_cells_per_s=%.4g read_cells_per_s=%.4g view_read_cells_per_s=%.4g\n",
            bad ? "MISMATCH" : "ok", (unsigned long long)n_lines, n_haps, (unsigned long long)bad, cells / t_w, cells / t_zc,
-           cells / t_hot, cells / t_r);
+           cells / t_hot, cells / t_r, cells / t_v);
     return bad ? 7 : 0;
 }

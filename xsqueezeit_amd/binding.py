@@ -47,7 +47,7 @@ SYMBOLS = [
     "xsi_hip_encode_gt", "xsi_hip_encode_gt_bound", "xsi_hip_make_header", "xsi_hip_decode_packed", "xsi_hip_decode_gt", "xsi_hip_decode_counts", "xsi_accessor_fill_allele_counts",
     "xsi_hip_synth_packed", "xsi_hip_debug_chain_encode", "xsi_writer_open", "xsi_writer_append", "xsi_writer_row_buffer", "xsi_writer_commit_row",
     "xsi_writer_finalize", "xsi_writer_close", "xsi_accessor_open", "xsi_accessor_fill_genotype_array",
-    "xsi_accessor_get_genotypes", "xsi_accessor_allele_counts", "xsi_accessor_get_internal_access", "xsi_accessor_hap_samples",
+    "xsi_accessor_get_genotypes", "xsi_accessor_genotypes_view", "xsi_accessor_allele_counts", "xsi_accessor_get_internal_access", "xsi_accessor_hap_samples",
     "xsi_accessor_num_samples", "xsi_accessor_sample_name", "xsi_accessor_close",
     "xsi_accessor_set_cache_bytes", "xsi_accessor_cache_stats", "xsi_file_num_samples", "xsi_hip_decode_dot", "xsi_hip_decode_dot_gt",
     "xsi_hip_ctx_set_workspace_budget", "xsi_hip_chain_kernel", "xsi_mac_threshold", "xsi_default_phased",
@@ -165,6 +165,8 @@ def lib():
     L.xsi_accessor_fill_genotype_array.argtypes = [vp, vp, u64, u32, u64]
     L.xsi_accessor_get_genotypes.restype = c.c_int64
     L.xsi_accessor_get_genotypes.argtypes = [vp, u32, u64, c.POINTER(vp), c.POINTER(c.c_int)]
+    L.xsi_accessor_genotypes_view.restype = c.c_int64
+    L.xsi_accessor_genotypes_view.argtypes = [vp, u32, u64, vp]
     L.xsi_accessor_get_internal_access.restype = c.c_int
     L.xsi_accessor_get_internal_access.argtypes = [vp, u32, u64, c.POINTER(InternalAccess), vp, vp, vp]
     L.xsi_accessor_allele_counts.restype = c.c_int

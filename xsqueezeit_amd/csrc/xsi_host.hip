@@ -828,9 +828,26 @@ int xsi_accessor_cache_stats(const xsi_accessor* a, uint64_t* blocks, uint64_t* 
     return XSI_OK;
 }
 
+// the line's values in the accessor's pinned window (valid until the next call on the accessor) and their number
+static int64_t accessor_line_view(xsi_accessor* a, uint32_t n_alleles, uint64_t position, const int32_t** view);
+
 int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_t gt_size, uint32_t n_alleles,
                                          uint64_t position) {
     if (!a || !h_gt) return set_error(XSI_ERR_ARG, "fill_genotype_array: null argument");
+    const int32_t* view = nullptr;
+    const int64_t ngt = accessor_line_view(a, n_alleles, position, &view);
+    if (ngt < 0) return ngt;
+    if (gt_size < (uint64_t)ngt) return set_error(XSI_ERR_CAPACITY, "gt array holds %llu values, line has %lld", (unsigned long long)gt_size, (long long)ngt);
+    memcpy(h_gt, view, (size_t)ngt * sizeof(int32_t));
+    return ngt;
+}
+
+int64_t xsi_accessor_genotypes_view(xsi_accessor* a, uint32_t n_alleles, uint64_t position, const int32_t** h_gt) {
+    if (!a || !h_gt) return set_error(XSI_ERR_ARG, "genotypes_view: null argument");
+    return accessor_line_view(a, n_alleles, position, h_gt);
+}
+
+static int64_t accessor_line_view(xsi_accessor* a, uint32_t n_alleles, uint64_t position, const int32_t** view) {
     if (n_alleles < 2) return set_error(XSI_ERR_ARG, "fill_genotype_array: n_alleles < 2");
     // AccessorInternalsNewTemplate::seek, accessor_internals_new.hpp:722-738
     const uint64_t block = (position & 0xFFFFFFFFull) >> BM_BLOCK_BITS;
@@ -867,8 +884,7 @@ int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_
         row = 0;
     }
     const uint32_t ngt = a->h_meta[2ull * a->win_rows + row];
-    if (gt_size < ngt) return set_error(XSI_ERR_CAPACITY, "gt array holds %llu values, line has %u", (unsigned long long)gt_size, ngt);
-    memcpy(h_gt, a->h_rows + (size_t)row * N, (size_t)ngt * sizeof(int32_t));
+    *view = a->h_rows + (size_t)row * N;
     a->last_counts.assign(a->h_counts + (size_t)row * n_alleles, a->h_counts + (size_t)(row + 1) * n_alleles);
     return (int64_t)ngt;
 }
