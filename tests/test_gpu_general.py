@@ -616,10 +616,16 @@ def test_accessor_internal_access(tmp_path):
                 if k == 1:
                     assert info.default_allele == (1 if neg else 0)
     assert checked_wah >= 5 and checked_sparse >= 5
-    # the accessor still serves genotypes afterwards
+    # the accessor still serves genotypes afterwards, by copy and by view (a pointer into its pinned window)
     buf = np.zeros(N, dtype=np.int32)
     assert L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, N, lines[7][1], bms[7]) == N
     assert np.array_equal(buf, lines[7][0])
+    for i in (0, 7, block_len + 3, len(lines) - 1):
+        ptr = ctypes.c_void_p()
+        n = L.xsi_accessor_genotypes_view(a, lines[i][1], bms[i], ctypes.byref(ptr))
+        assert n == N and ptr.value
+        view = np.frombuffer((ctypes.c_int32 * n).from_address(ptr.value), dtype=np.int32)
+        assert np.array_equal(view, lines[i][0]), "line %d" % i
     L.xsi_accessor_close(a)
 
 
