@@ -93,6 +93,25 @@ def test_chain_kernel_variants_at_depth(n_haps, n_blocks, block_len, thr, force,
     assert np.array_equal(out, packed)
 
 
+def test_phased_decode_with_a_short_last_block(monkeypatch):
+    """The decode runs every block's WAH lines in ranges (expansion of the next range underneath the chain of the
+    current one).  A block with fewer WAH lines than ranges has empty ranges: its first lines must still start
+    from the identity and its ranks must survive the launches in which it has nothing to do."""
+    import gpu_util as G
+    monkeypatch.setenv("XSI_RANK_WG_MIN_BLOCKS", "1")
+    monkeypatch.setenv("XSI_DEC_PHASES", "7")
+    n_haps, block_len, thr = 40000, 777, 40
+    n_lines = 3 * block_len + 4   # the fourth block: 4 lines
+    bits, packed, stride = _device_synth(n_haps, n_lines, 11)
+    p = G.params(n_haps // 2, block_len, thr)
+    ref = G.oracle_file_from_bits(bits, p)
+    region, offsets, res = G.encode_packed(packed, n_haps, p)
+    got = G.assemble_file(region, offsets, p, n_lines, n_lines, ["S%d" % i for i in range(n_haps // 2)])
+    assert got == ref
+    out, _ = G.decode_packed(got, n_haps, stride)
+    assert np.array_equal(out, packed)
+
+
 def test_block_batched_calls_equal_single_call():
     """A workspace budget smaller than the job: encode and decode run as several batches of whole
     blocks inside one call and must produce the bytes / rows of the unbatched call."""

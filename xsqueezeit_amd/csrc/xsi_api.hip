@@ -887,7 +887,7 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
         for (uint32_t p = 0; p < K; ++p) {
             const uint32_t* tab = d_tab + (size_t)p * (3u * nb + 1u);
             if (p) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_phase[p], 0));
-            HIP_TRY(launch_rank_decode_phase(s, P.d_blocks, nb, L, out, stride_w, tab, tab + nb, d_state, p == 0u, p + 1u == K));
+            HIP_TRY(launch_rank_decode_phase(s, P.d_blocks, nb, L, out, stride_w, tab, tab + nb, d_state));
         }
     } else {
         stage_mark(ctx, XSI_ST_DEC_EXPAND);

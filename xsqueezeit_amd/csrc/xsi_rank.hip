@@ -47,12 +47,11 @@ struct RankArgs {
     uint32_t N;
     uint32_t batch;             // lines staged per LDS batch
     uint32_t log2_cwp;
-    // phased decode (k_chain_decode_rank_wg): this launch runs ph_cnt[b] lines of block b from batch-wide
-    // rank ph_start[b]; ranks come from / go to `state` unless it is the first / last range.  nullptr: all lines.
+    // phased decode: this launch runs ph_cnt[b] lines of block b from batch-wide rank ph_start[b]; ranks come from /
+    // go to `state` unless the range holds the block's first / last line.  nullptr: all lines.
     const uint32_t* ph_start;
     const uint32_t* ph_cnt;
     uint32_t* state;            // [block][chunk of the wave][1024 threads]
-    uint32_t ph_first, ph_last;
 };
 
 constexpr int RANK_RP = 6;  // {bits, prefix} pairs a thread carries while a batch is in flight
@@ -228,7 +227,9 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
 
     uint32_t r[E];
     uint32_t* park = A.state + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (uint32_t)E) * T + tid;  // chunk e: park[e * T]
-    if (!A.ph_start || A.ph_first) {
+    // the block's first line is in this range: identity; else the ranks parked by the launch of the range before
+    // (a short block has empty ranges: "first" and "last" are the block's own, not the launch's)
+    if (!A.ph_start || wah_first == D.wah_first) {
         static_for<0, E>([&](auto ecn) {
             constexpr int e = decltype(ecn)::value;
             r[e] = (cg0 + (uint32_t)e) * 64u + lane;
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
         Z = Z_n;
         __syncthreads();
     }
-    if (A.ph_start && !A.ph_last) {
+    if (A.ph_start && wah_first + n_wah != D.wah_first + D.n_wah) {
         static_for<0, E>([&](auto ecn) {
             constexpr int e = decltype(ecn)::value;
             park[(size_t)e * T] = r[e];
@@ -362,7 +363,9 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
 
     uint32_t r[E];
     uint32_t* park = A.state + ((size_t)blockIdx.x * (uint32_t)E) * T + tid;  // chunk e of my wave: park[e * T]
-    if (!A.ph_start || A.ph_first) {
+    // the block's first line is in this range: identity; else the ranks parked by the launch of the range before
+    // (a short block has empty ranges: "first" and "last" are the block's own, not the launch's)
+    if (!A.ph_start || wah_first == D.wah_first) {
         static_for<0, E>([&](auto ecn) {
             constexpr int e = decltype(ecn)::value;
             r[e] = (cg0 + (uint32_t)e) * 64u + lane;
@@ -459,7 +462,7 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
         Z = Z_n;
         __syncthreads();  // the next row is staged; everyone is done with this one
     }
-    if (A.ph_start && !A.ph_last) {
+    if (A.ph_start && wah_first + n_wah != D.wah_first + D.n_wah) {
         static_for<0, E>([&](auto ecn) {
             constexpr int e = decltype(ecn)::value;
             park[(size_t)e * T] = r[e];
@@ -649,7 +652,7 @@ uint64_t rank_decode_state_words(uint32_t N, uint32_t n_blocks) {  // ranks of e
 
 hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                                     uint32_t* out_rows, uint32_t out_stride_w, const uint32_t* ph_start,
-                                    const uint32_t* ph_cnt, uint32_t* state, bool first, bool last) {
+                                    const uint32_t* ph_cnt, uint32_t* state) {
     if (!n_blocks) return hipSuccess;
     RankArgs R{};
     R.blocks = blocks;
@@ -663,8 +666,6 @@ hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint3
     R.ph_start = ph_start;
     R.ph_cnt = ph_cnt;
     R.state = state;
-    R.ph_first = first ? 1u : 0u;
-    R.ph_last = last ? 1u : 0u;
     return rank_decode_family(L.N, L.yp_stride, n_blocks) == 1 ? launch_rank_wg(s, n_blocks, R) : launch_rank_big(s, n_blocks, R);
 }
 
