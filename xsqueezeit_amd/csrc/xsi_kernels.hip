@@ -2313,6 +2313,22 @@ constexpr uint32_t BND_T = 256, BND_K = 8, BND_TILE = BND_T * BND_K;
 
 __device__ __forceinline__ uint32_t wah_groups_of(uint32_t word) { return (word & 0x8000u) ? (word & WAH_MAXC) : 1u; }
 
+// The BND_K = 8 consecutive WAH16 words of a thread: one 16-byte load (the matrix is only 2-byte aligned; gfx950
+// global loads take that) instead of eight 2-byte loads; the ragged end of the matrix word by word.
+struct __attribute__((packed, aligned(2))) WahWords8 {
+    uint32_t v[4];
+};
+__device__ __forceinline__ void load_words8(const uint16_t* __restrict__ wm, uint32_t w0, uint32_t nwords, uint32_t (&wd)[8]) {
+    if (w0 + 8u <= nwords) {
+        const WahWords8 p = *reinterpret_cast<const WahWords8*>(wm + w0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wd[k] = (p.v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) wd[k] = w0 + k < nwords ? (uint32_t)wm[w0 + k] : 0x10000u;  // marker: no word
+    }
+}
+
 __global__ void __launch_bounds__(BND_T) k_wah_tile_sums(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
                                                           DecLines L) {
     __shared__ uint32_t s_part[BND_T / 64];
@@ -2321,10 +2337,13 @@ __global__ void __launch_bounds__(BND_T) k_wah_tile_sums(const uint8_t* __restri
     if (D.error || D.n_wah == 0 || c0 >= D.wah_words) return;
     const uint16_t* wm = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah);
     const uint32_t w0 = c0 + threadIdx.x * BND_K;
+    static_assert(BND_K == 8, "load_words8");
+    uint32_t wd[8];
+    load_words8(wm, w0, D.wah_words, wd);
     uint32_t sum = 0;
 #pragma unroll
     for (uint32_t k = 0; k < BND_K; ++k)
-        if (w0 + k < D.wah_words) sum += wah_groups_of(wm[w0 + k]);
+        if (wd[k] < 0x10000u) sum += wah_groups_of(wd[k]);
     sum = wave_sum(sum);
     if (lane_id() == 0) s_part[threadIdx.x >> 6] = sum;
     __syncthreads();
@@ -2380,11 +2399,15 @@ __global__ void __launch_bounds__(BND_T) k_wah_boundaries(const uint8_t* __restr
     const uint32_t w0 = c0 + threadIdx.x * K;
     uint32_t g[K];
     uint32_t sum = 0;
+    {
+        uint32_t wd[8];
+        load_words8(wm, w0, nwords, wd);
 #pragma unroll
-    for (uint32_t k = 0; k < K; ++k) {
-        const uint32_t ng = (w0 + k < nwords) ? wah_groups_of(wm[w0 + k]) : 0u;
-        g[k] = ng;
-        sum += ng;
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t ng = wd[k] < 0x10000u ? wah_groups_of(wd[k]) : 0u;
+            g[k] = ng;
+            sum += ng;
+        }
     }
     uint64_t tot;
     uint64_t ex = L.tile_base[(size_t)blockIdx.y * L.max_tiles + blockIdx.x] + block_scan_excl64(sum, s_scan, &tot);
