@@ -833,6 +833,9 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
     HIP_TRY(launch_sparse_walk(ctx->side, f, P.d_blocks, P.n_blocks, L));
     HIP_TRY(launch_sparse_fill(ctx->side, f, P.d_blocks, L, P.n_sparse, P.d_totals, out, stride_w, apply_negation));
     HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
+    // rows for the one-workgroup-per-block chain in the compact form (10 instead of 16 bytes per 64 positions)
+    L.yp_rows = P.n_wah ? P.n_wah : 1u;
+    L.yp_compact = (!any_haploid && rank_decode_takes_compact(L.N, L.yp_stride, P.n_blocks)) ? 1u : 0u;
     stage_mark(ctx, XSI_ST_DEC_BOUND);
     HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
     // Phased: the chain needs line j of every block at its step j, so the WAH lines of every block are cut into K

@@ -2570,9 +2570,40 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
         uint32_t ones;
         (void)wave_wah_expand_row(src, maxw, nbits, row, &ones, pre);
         __syncthreads();
+        uint32_t base = 0;
+        if (L.yp_compact) {
+            // compact form: 64-bit chunks of the row + 16-bit "ones before the chunk" (see DecLines)
+            uint2* dc = reinterpret_cast<uint2*>(L.yp) + (size_t)j * L.y_stride64;
+            uint16_t* dp = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(L.yp) + 8ull * L.y_stride64 * L.yp_rows) +
+                           (size_t)j * L.y_stride64;
+            for (uint32_t i0 = 0; i0 < L.y_stride64; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                uint2 v = make_uint2(0u, 0u);
+                if (i < L.y_stride64) {
+                    v = make_uint2(row[2u * i], row[2u * i + 1u]);
+                    row[2u * i] = 0;  // ready for the next line
+                    row[2u * i + 1u] = 0;
+                }
+                const uint32_t c = (uint32_t)__popc(v.x) + (uint32_t)__popc(v.y);
+                const uint32_t inc = wave_scan_incl_dpp(c);
+                if (i < L.y_stride64) {
+                    dc[i] = v;
+                    dp[i] = (uint16_t)(base + inc - c);
+                }
+                base += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            }
+            if (lane == 0) {
+                L.ones[l] = ones;
+                L.wah_z[j] = nbits - base;
+            }
+            __syncthreads();
+            src = src_n;
+            maxw = maxw_n;
+            pre = pre_n;
+            continue;
+        }
         // {32 row bits, ones before them}: the decode chain's rank-select table for this line
         uint2* dst = L.yp + (size_t)j * L.yp_stride;
-        uint32_t base = 0;
         for (uint32_t i0 = 0; i0 < L.yp_stride; i0 += 64u) {
             const uint32_t i = i0 + lane;
             uint32_t v = 0;

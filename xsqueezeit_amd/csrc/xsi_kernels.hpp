@@ -110,6 +110,11 @@ struct DecLines {
     uint32_t* sparse_lines;
     uint2* yp;             // [wah rank][yp_stride] permuted rows as {32 bits, ones before these bits} pairs
     uint32_t yp_stride;    // pairs per row (>= ceil(N/32), even)
+    // compact form of the same buffer (one-workgroup-per-block decode chain, rows of at most 65 536 bits): rows
+    // of y_stride64 64-bit chunks, then - behind all yp_rows of them - 16-bit "ones before the chunk": 10 bytes
+    // per 64 positions instead of 16; the chain kernel forms the pairs while it stages a row in LDS
+    uint32_t yp_compact;
+    uint32_t yp_rows;
     uint32_t* wah_z;       // [wah rank] zeros of the line (line bits - ones)
     uint32_t y_stride64;   // ceil(N/64): 64-bit words of a plain bit row
     uint32_t* ones;        // per binary line: allele count (accessor "ones")
@@ -142,6 +147,7 @@ hipError_t launch_wah_expand_phase(hipStream_t s, const uint8_t* file, const Dec
                                    const uint32_t* ph_gpre, uint32_t n_blocks, uint32_t n_groups);
 // the one-workgroup-per-block decode chain over one range of lines; ranks parked in `state` between the launches
 bool rank_decode_phased_ok(uint32_t N, uint32_t yp_stride, uint32_t n_blocks);
+bool rank_decode_takes_compact(uint32_t N, uint32_t yp_stride, uint32_t n_blocks);
 uint64_t rank_decode_state_words(uint32_t N, uint32_t n_blocks);
 hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                                     uint32_t* out_rows, uint32_t out_stride_w, const uint32_t* ph_start,

@@ -52,6 +52,10 @@ struct RankArgs {
     const uint32_t* ph_start;
     const uint32_t* ph_cnt;
     uint32_t* state;            // [block][chunk of the wave][1024 threads]
+    // compact rank-select rows (DecLines::yp_compact): 64-bit chunks + 16-bit ones-before, nullptr = pairs in yp
+    const uint2* yc;            // [rank][yc_stride] chunks
+    const uint16_t* ypre;       // [rank][yc_stride]
+    uint32_t yc_stride;
 };
 
 constexpr int RANK_RP = 6;  // {bits, prefix} pairs a thread carries while a batch is in flight
@@ -341,7 +345,7 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
 // workgroups only multiplies the row staging.  The {bits, prefix} row of line j+1 is fetched into two
 // registers per thread while line j runs and parked in the other half of a double buffer: one barrier per
 // line.  Per 64 haplotypes: one ds_read_b64 gather, 11 vector instructions, no scalar work.
-template <int E>
+template <int E, bool COMPACT>
 __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
     constexpr uint32_t T = 1024, W = 16;
     constexpr int G = 8;
@@ -391,20 +395,37 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
     const bool store_lane = lane < (uint32_t)E && cg0 + lane < row_chunks && (A.out_stride_w & 1u) == 0u;
     const bool odd_tail = (A.out_stride_w & 1u) != 0u;  // rows of an odd number of words: rare, word stores
 
+    // pairs form: R[0], R[1] = pairs tid and 1024 + tid; compact form: R[0] = chunk tid (64 row bits), R[1].x = ones before it
     uint2 R[2];
     auto load_row = [&](uint32_t j) {
-        const uint2* src = A.yp + (size_t)(wah_first + j) * CWP;
+        if constexpr (COMPACT) {
+            // threads beyond the row read chunk 0 and store nothing: an unconditional load stays in flight across
+            // the line (with a default value for them the compiler waits for the load where it is issued)
+            const uint2* src = A.yc + (size_t)(wah_first + j) * A.yc_stride;       // uniform: scalar address arithmetic
+            const uint16_t* srp = A.ypre + (size_t)(wah_first + j) * A.yc_stride;
+            const uint32_t t = tid < A.yc_stride ? tid : 0u;
+            R[0] = src[t];
+            R[1] = make_uint2((uint32_t)srp[t], 0u);
+        } else {
+            const uint2* src = A.yp + (size_t)(wah_first + j) * CWP;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint32_t idx = (uint32_t)q * T + tid;
-            R[q] = idx < CWP ? src[idx] : make_uint2(0, 0);
+            for (int q = 0; q < 2; ++q) {
+                const uint32_t idx = (uint32_t)q * T + tid;
+                R[q] = src[idx < CWP ? idx : 0u];  // unconditional (see above); store_row keeps to the row
+            }
         }
     };
     auto store_row = [&](uint32_t buf) {
+        if constexpr (COMPACT) {  // pairs 2 tid, 2 tid + 1 of the staged row (16 bytes per lane: no bank conflicts)
+            if (2u * tid < CWP)
+                *reinterpret_cast<uint4*>(stage + buf * (SLOT / 8u) + 2u * tid) =
+                    make_uint4(R[0].x, R[1].x, R[0].y, R[1].x + (uint32_t)__popc(R[0].x));
+        } else {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint32_t idx = (uint32_t)q * T + tid;
-            if (idx < CWP) stage[buf * (SLOT / 8u) + idx] = R[q];
+            for (int q = 0; q < 2; ++q) {
+                const uint32_t idx = (uint32_t)q * T + tid;
+                if (idx < CWP) stage[buf * (SLOT / 8u) + idx] = R[q];
+            }
         }
     };
     load_row(0);
@@ -614,10 +635,11 @@ static hipError_t launch_rank_wg(hipStream_t s, uint32_t n_blocks, const RankArg
     const uint32_t lds = 2u * 16384u;
 #define XSI_WG_CASE(EE)                                                                                    \
     if (e == EE) {                                                                                          \
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank_wg<EE>),    \
+        auto kern = R.yc ? &k_chain_decode_rank_wg<EE, true> : &k_chain_decode_rank_wg<EE, false>;          \
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                           \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
         if (err != hipSuccess) return err;                                                                  \
-        k_chain_decode_rank_wg<EE><<<dim3(n_blocks), dim3(1024), lds, s>>>(R);                              \
+        kern<<<dim3(n_blocks), dim3(1024), lds, s>>>(R);                                                    \
         return hipGetLastError();                                                                           \
     }
     XSI_WG_CASE(16)
@@ -646,6 +668,23 @@ static int rank_decode_family(uint32_t N, uint32_t yp_stride, uint32_t n_blocks)
 
 bool rank_decode_phased_ok(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) { return rank_decode_family(N, yp_stride, n_blocks) != 0; }
 
+bool rank_decode_takes_compact(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
+    return N <= 65536u && rank_decode_family(N, yp_stride, n_blocks) == 1 && !getenv("XSI_NO_COMPACT_YP");
+}
+
+static void rank_args_rows(RankArgs& R, const DecLines& L) {
+    R.yp = L.yp;
+    R.yp_stride = L.yp_stride;
+    R.yc = nullptr;
+    R.ypre = nullptr;
+    R.yc_stride = 0;
+    if (L.yp_compact) {
+        R.yc = reinterpret_cast<const uint2*>(L.yp);
+        R.ypre = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(L.yp) + 8ull * L.y_stride64 * L.yp_rows);
+        R.yc_stride = L.y_stride64;
+    }
+}
+
 uint64_t rank_decode_state_words(uint32_t N, uint32_t n_blocks) {  // ranks of every workgroup: whole 16 384-haplotype units
     return (uint64_t)n_blocks * (((uint64_t)N + 65535u) / 65536u) * 65536u;
 }
@@ -657,8 +696,7 @@ hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint3
     RankArgs R{};
     R.blocks = blocks;
     R.wah_lines = L.wah_lines;
-    R.yp = L.yp;
-    R.yp_stride = L.yp_stride;
+    rank_args_rows(R, L);
     R.wah_z = L.wah_z;
     R.out = out_rows;
     R.out_stride_w = out_stride_w;
@@ -675,8 +713,7 @@ hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_
     RankArgs R{};
     R.blocks = blocks;
     R.wah_lines = L.wah_lines;
-    R.yp = L.yp;
-    R.yp_stride = L.yp_stride;
+    rank_args_rows(R, L);
     R.wah_z = L.wah_z;
     R.out = out_rows;
     R.out_stride_w = out_stride_w;
