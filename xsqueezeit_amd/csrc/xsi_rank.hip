@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
 #pragma unroll
         for (int q = 0; q < RP; ++q) {
             const uint32_t idx = (uint32_t)q * T + tid;
-            R[q] = idx < CWP ? src[idx] : make_uint2(0, 0);
+            R[q] = src[idx < CWP ? idx : 0u];  // unconditional: stays in flight across the line; store_row keeps to the row
         }
     };
     auto store_row = [&]() {
