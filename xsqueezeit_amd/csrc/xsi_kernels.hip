@@ -1463,7 +1463,7 @@ __global__ void __launch_bounds__(256) k_wah_units(const EncBlock* __restrict__ 
 #pragma unroll
         for (int q = 0; q < WAH_STAGE_Q; ++q) {
             const uint32_t idx = (uint32_t)q * 64u + lane;
-            R[q] = idx < np ? src[idx] : make_uint2(0u, 0u);
+            R[q] = src[idx < np ? idx : 0u];  // unconditional: with a default value the compiler waits for the load at once
         }
     };
     auto park = [&]() {
