@@ -70,15 +70,27 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t cg0 = (blockIdx.y * W + w) * E;  // first chunk of my wave
-    const uint32_t wah_first = D.wah_first, n_wah = D.n_wah;
+    const uint32_t wah_first = A.ph_start ? A.ph_start[blockIdx.x] : D.wah_first;
+    const uint32_t n_wah = A.ph_start ? A.ph_cnt[blockIdx.x] : D.n_wah;
+    if (n_wah == 0) return;  // no line of this block in this range: its ranks stay parked
     const uint32_t CWP = A.yp_stride;
 
     uint32_t r[E];
-    static_for<0, E>([&](auto ecn) {
-        constexpr int e = decltype(ecn)::value;
-        r[e] = (cg0 + (uint32_t)e) * 64u + lane;
-        if (r[e] >= N) r[e] = 0;  // haplotypes beyond N idle on position 0; their output is masked
-    });
+    uint32_t* park = A.state + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (uint32_t)E) * T + tid;  // chunk e: park[e * T]
+    // the block's first line is in this range: identity; else the ranks parked by the launch of the range before
+    if (!A.ph_start || wah_first == D.wah_first) {
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            r[e] = (cg0 + (uint32_t)e) * 64u + lane;
+            if (r[e] >= N) r[e] = 0;  // haplotypes beyond N idle on position 0; their output is masked
+        });
+    } else {
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            r[e] = park[(size_t)e * T];
+        });
+    }
+    const bool park_after = A.ph_start && wah_first + n_wah != D.wah_first + D.n_wah;
     // lane e (< E) stores chunk cg0+e's word; valid-bit mask of that chunk for the row tail
     uint32_t vm_lo = 0, vm_hi = 0;
     {
@@ -128,6 +140,12 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
             }
             if (pad_writer)
                 for (uint32_t i = row_words + tid; i < A.out_stride_w; i += T) A.out[(size_t)line * A.out_stride_w + i] = 0;
+        }
+        if (park_after) {
+            static_for<0, E>([&](auto ecn) {
+                constexpr int e = decltype(ecn)::value;
+                park[(size_t)e * T] = r[e];
+            });
         }
         return;
     }
@@ -201,6 +219,12 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
         }
         if (more) store_batch((bt + 1u) & 1u);
         __syncthreads();
+    }
+    if (park_after) {
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            park[(size_t)e * T] = r[e];
+        });
     }
 }
 
@@ -666,7 +690,11 @@ static int rank_decode_family(uint32_t N, uint32_t yp_stride, uint32_t n_blocks)
     return 0;
 }
 
-bool rank_decode_phased_ok(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) { return rank_decode_family(N, yp_stride, n_blocks) != 0; }
+// Every element-major decode kernel can park its ranks, but the small-N kernels do not gain: at 5008 haplotypes x 123
+// blocks the twelve ranges cost the chain 0.6 ms for 0.6 ms of expansion hidden (8.76 against 8.67 ms per step).
+bool rank_decode_phased_ok(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
+    return rank_decode_family(N, yp_stride, n_blocks) != 0 || getenv("XSI_DEC_PHASES_SMALL") != nullptr;
+}
 
 bool rank_decode_takes_compact(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
     return N <= 65536u && rank_decode_family(N, yp_stride, n_blocks) == 1 && !getenv("XSI_NO_COMPACT_YP");
@@ -685,8 +713,8 @@ static void rank_args_rows(RankArgs& R, const DecLines& L) {
     }
 }
 
-uint64_t rank_decode_state_words(uint32_t N, uint32_t n_blocks) {  // ranks of every workgroup: whole 16 384-haplotype units
-    return (uint64_t)n_blocks * (((uint64_t)N + 65535u) / 65536u) * 65536u;
+uint64_t rank_decode_state_words(uint32_t N, uint32_t n_blocks) {  // ranks of every workgroup of a block: N rounded up to
+    return (uint64_t)n_blocks * ((((uint64_t)N + 65535u) / 65536u) * 65536u + 16384u);  // its workgroups' capacity, with room
 }
 
 hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
@@ -704,7 +732,13 @@ hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint3
     R.ph_start = ph_start;
     R.ph_cnt = ph_cnt;
     R.state = state;
-    return rank_decode_family(L.N, L.yp_stride, n_blocks) == 1 ? launch_rank_wg(s, n_blocks, R) : launch_rank_big(s, n_blocks, R);
+    const int fam = rank_decode_family(L.N, L.yp_stride, n_blocks);
+    if (fam == 1) return launch_rank_wg(s, n_blocks, R);
+    if (fam == 2) return launch_rank_big(s, n_blocks, R);
+    const RankGeom g = rank_geometry(L.N, L.yp_stride, n_blocks);
+    R.batch = g.batch;
+    R.log2_cwp = g.log2_cwp;
+    return g.stage ? launch_rank<true>(s, g, n_blocks, R) : launch_rank<false>(s, g, n_blocks, R);
 }
 
 hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
