@@ -2117,29 +2117,32 @@ __global__ void __launch_bounds__(256) k_parse_blocks(const uint8_t* __restrict_
         blocks[b] = D;
         return;
     }
-    uint32_t vals[0x40];
-    for (int i = 0; i < 0x40; ++i) vals[i] = VAL_UNDEFINED;
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t k = rd32(gt + 8 + 8 * i), v = rd32(gt + 12 + 8 * i);
-        if (k < 0x40u) vals[k] = v;
-    }
-    D.n_bcf = vals[KEY_BCF_LINES];
-    D.n_bin = vals[KEY_BINARY_LINES];
-    D.max_ploidy = vals[KEY_MAX_LINE_PLOIDY] == VAL_UNDEFINED ? 2u : vals[KEY_MAX_LINE_PLOIDY];
-    D.default_phasing = vals[KEY_DEFAULT_PHASING] == 1u ? 1u : 0u;  // accessor_internals_new.hpp:77-81
-    D.strategy = vals[KEY_WEIRDNESS_STRATEGY] == VAL_UNDEFINED ? WS_PBWT_WAH : vals[KEY_WEIRDNESS_STRATEGY];
-    D.off_select = vals[KEY_LINE_SELECT];
-    D.off_wah = vals[KEY_MATRIX_WAH];
-    D.off_sparse = vals[KEY_MATRIX_SPARSE];
-    D.off_line_missing = vals[KEY_LINE_MISSING];
-    D.off_miss_wah = vals[KEY_MATRIX_MISSING];
-    D.off_miss_sparse = vals[KEY_MATRIX_MISSING_SPARSE];
-    D.off_line_eov = vals[KEY_LINE_END_OF_VECTORS];
-    D.off_eov_wah = vals[KEY_MATRIX_END_OF_VECTORS];
-    D.off_eov_sparse = vals[KEY_MATRIX_END_OF_VECTORS_SPARSE];
-    D.off_line_phase = vals[KEY_LINE_NON_UNIFORM_PHASING];
-    D.off_phase = vals[KEY_MATRIX_NON_UNIFORM_PHASING];
-    D.off_line_haploid = vals[KEY_LINE_HAPLOID];
+    // the dictionary is walked once per key (the last entry of a key wins, as an array indexed by key would have it):
+    // a private array indexed at run time would live in scratch memory
+    auto val = [&](uint32_t key) {
+        uint32_t v = VAL_UNDEFINED;
+        for (uint32_t i = 0; i < n; ++i)
+            if (rd32(gt + 8 + 8 * i) == key) v = rd32(gt + 12 + 8 * i);
+        return v;
+    };
+    D.n_bcf = val(KEY_BCF_LINES);
+    D.n_bin = val(KEY_BINARY_LINES);
+    const uint32_t v_ploidy = val(KEY_MAX_LINE_PLOIDY), v_strategy = val(KEY_WEIRDNESS_STRATEGY);
+    D.max_ploidy = v_ploidy == VAL_UNDEFINED ? 2u : v_ploidy;
+    D.default_phasing = val(KEY_DEFAULT_PHASING) == 1u ? 1u : 0u;  // accessor_internals_new.hpp:77-81
+    D.strategy = v_strategy == VAL_UNDEFINED ? WS_PBWT_WAH : v_strategy;
+    D.off_select = val(KEY_LINE_SELECT);
+    D.off_wah = val(KEY_MATRIX_WAH);
+    D.off_sparse = val(KEY_MATRIX_SPARSE);
+    D.off_line_missing = val(KEY_LINE_MISSING);
+    D.off_miss_wah = val(KEY_MATRIX_MISSING);
+    D.off_miss_sparse = val(KEY_MATRIX_MISSING_SPARSE);
+    D.off_line_eov = val(KEY_LINE_END_OF_VECTORS);
+    D.off_eov_wah = val(KEY_MATRIX_END_OF_VECTORS);
+    D.off_eov_sparse = val(KEY_MATRIX_END_OF_VECTORS_SPARSE);
+    D.off_line_phase = val(KEY_LINE_NON_UNIFORM_PHASING);
+    D.off_phase = val(KEY_MATRIX_NON_UNIFORM_PHASING);
+    D.off_line_haploid = val(KEY_LINE_HAPLOID);
     if (D.n_bcf == VAL_UNDEFINED || D.n_bin == VAL_UNDEFINED || D.n_bin > MAX_BIN_PER_BLOCK ||
         D.off_select == VAL_UNDEFINED || D.off_wah == VAL_UNDEFINED || D.off_sparse == VAL_UNDEFINED ||
         D.off_sparse < D.off_wah)
