@@ -11,6 +11,8 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python3 bench.py --config 1 > $O/${TAG}_bench_config1.json 2> $O/${TAG}_bench_config1.err
+# the 153-block x 500 000-haplotype shard one of 8 GPUs gets of BASELINE configs[3]
+python3 bench.py --config 3 --sites-fraction 0.125 --steps 3 --warmup 1 > $O/${TAG}_config3_shard.json 2> $O/${TAG}_config3_shard.err
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_stats -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_stats.json 2> $O/${TAG}_stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${TAG}_fetch -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/${TAG}_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${TAG}_write -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/${TAG}_write.err

@@ -38,7 +38,7 @@ def main():
     src, tag, dst, when = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
     os.makedirs(dst, exist_ok=True)
     p = lambda *a: os.path.join(src, *a)
-    for name in ("bench", "bench_config1"):
+    for name in ("bench", "bench_config1", "config3_shard"):
         f = p("%s_%s.json" % (tag, name))
         if os.path.exists(f):
             shutil.copy(f, os.path.join(dst, "%s_%s.json" % (tag, name)))
