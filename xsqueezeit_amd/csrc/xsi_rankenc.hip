@@ -316,6 +316,7 @@ struct RankEncMultiArgs {
     uint32_t S;             // workgroups per block
     uint32_t gpx;           // groups per XCD slot: the grid is 8 * gpx * S workgroups
     uint32_t* sync;         // [0] abort, [16 + g] arrivals of group g
+    uint32_t test_desert;   // testing only: member 1 of every group leaves before its first meeting (the others must time out, not hang)
     uint32_t* lists;        // [group][parity][S * 16 waves][MULTI_LIST_CAP] ranks, whole 64-entry stores (padding: ~0)
     uint32_t* counts;       // [group][parity][S * 16] entries of each list
 };
@@ -354,6 +355,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
     };
     // all members of the group have published their lists: true; false = the launch is aborting
     auto meet = [&]() -> bool {
+        if (A.test_desert && member == 1u) return false;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores have left
         __syncthreads();
         // every wave is done with the table of the line before: its bit words are cleared here, while lane 0 waits
@@ -599,6 +601,7 @@ hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint3
     if (A.gpx < 1u || 8u * A.gpx > CHAIN_SYNC_WORDS - 16u) return hipErrorInvalidValue;
     while (A.gpx > 1u && 8u * (A.gpx - 1u) >= n_blocks) --A.gpx;  // no more groups than blocks need
     A.sync = L.chain_sync;
+    A.test_desert = getenv("XSI_MULTI_TEST_DESERT") ? 1u : 0u;
     A.counts = L.chain_sync + CHAIN_SYNC_WORDS;
     A.lists = L.chain_lists;
     if (8u * A.gpx * A.S > CHAIN_MAX_WGS) return hipErrorInvalidValue;
