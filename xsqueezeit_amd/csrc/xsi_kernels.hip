@@ -2583,9 +2583,9 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
                 const uint32_t i = i0 + lane;
                 uint2 v = make_uint2(0u, 0u);
                 if (i < L.y_stride64) {
-                    v = make_uint2(row[2u * i], row[2u * i + 1u]);
-                    row[2u * i] = 0;  // ready for the next line
-                    row[2u * i + 1u] = 0;
+                    uint2* rp = reinterpret_cast<uint2*>(row) + i;  // one 8-byte LDS read and write per chunk
+                    v = *rp;
+                    *rp = make_uint2(0u, 0u);  // ready for the next line
                 }
                 const uint32_t c = (uint32_t)__popc(v.x) + (uint32_t)__popc(v.y);
                 const uint32_t inc = wave_scan_incl_dpp(c);
