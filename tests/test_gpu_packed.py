@@ -338,3 +338,53 @@ def test_corrupt_images_are_rejected_not_dereferenced():
         with pytest.raises(binding.XsiError) as ei:
             decode(bad)
         assert ei.value.code == -4, "%s: %s" % (name, ei.value)  # XSI_ERR_FORMAT
+
+
+@pytest.mark.parametrize("n_haps", [12320, 15360, 16384, 30000, 65534, 131072, 140000])
+def test_wah_unit_encoder_on_adversarial_rows(n_haps):
+    """The unit WAH16 encoder (32 groups = 480 bits per lane, heads by bit logic, fill counts from the distance to
+    the next head) on rows built to sit on its seams: runs that start or end exactly at group (15), word (32) and
+    unit (480) boundaries, runs one bit short or long of them, alternating fills, literals at the ends of a unit,
+    rows that end inside a group.  Every line is a block of its own, so the permuted row IS the input row."""
+    import gpu_util as G
+    rng = np.random.default_rng(n_haps)
+    rows = []
+    def row_from_runs(runs):  # [(value, length)] repeated to fill the row
+        out = np.zeros(n_haps, dtype=np.uint8)
+        pos, k = 0, 0
+        while pos < n_haps:
+            v, ln = runs[k % len(runs)]
+            out[pos:pos + ln] = v
+            pos += ln
+            k += 1
+        return out
+    for a in (15, 30, 32, 480, 465, 495, 479, 481, 960, 7, 16):
+        for b in (15, 1, 480, 14, 16, 31):
+            rows.append(row_from_runs([(1, a), (0, b)]))
+            rows.append(row_from_runs([(0, a), (1, b)]))
+    for start in (0, 14, 15, 479, 480, 481, 959, n_haps - 16, n_haps - 15, n_haps - 1):
+        r = np.zeros(n_haps, dtype=np.uint8)
+        r[start:start + 1] = 1                      # a lone literal at a seam
+        rows.append(r)
+        r = np.ones(n_haps, dtype=np.uint8)
+        r[start:start + 1] = 0
+        r[n_haps // 2] = 0                          # keep the minor count above 0 on both sides
+        rows.append(r)
+    r = np.zeros(n_haps, dtype=np.uint8); r[:n_haps // 3] = 1; rows.append(r)      # two long runs
+    r = np.zeros(n_haps, dtype=np.uint8); r[1::2] = 1; rows.append(r)              # all literals
+    r = (rng.random(n_haps) < 0.5).astype(np.uint8); rows.append(r)
+    r = np.zeros(n_haps, dtype=np.uint8); r[480 * 3:480 * 5] = 1; rows.append(r)   # a run of whole units
+    bits = np.stack(rows)
+    stride = synth.row_stride_bytes(n_haps)
+    packed = synth.pack_rows(bits, stride)
+    p = G.params(n_haps // 2, 1, 0)   # block_len 1, MAC threshold 0: every polymorphic line is a WAH line
+    names = ["S%d" % i for i in range(n_haps // 2)]
+    ref = G.oracle_file_from_bits(bits, p, names)
+    region, offsets, res = G.encode_packed(packed, n_haps, p)
+    assert res.n_wah_lines == len(rows)
+    got = G.assemble_file(region, offsets, p, len(rows), len(rows), names)
+    if got != ref:
+        first = next(i for i in range(min(len(got), len(ref))) if got[i] != ref[i])
+        raise AssertionError("file differs at offset %d (sizes %d vs %d)" % (first, len(got), len(ref)))
+    out, _ = G.decode_packed(got, n_haps, stride)
+    assert np.array_equal(out, packed)
