@@ -670,31 +670,37 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
     // Nothing in the serial chain may wait on HBM.  Line ids (+ haploid flag) are fetched two
     // batches ahead into an LDS ring; with them the bit columns are fetched one batch ahead into
     // registers while the current batch is processed, then parked in LDS.
-    auto load_info = [&](uint32_t bt) {
-        Rinfo = 0;
-        if (tid < B && bt < n_batches && bt * B + tid < n_wah) {
-            const uint32_t line = A.wah_lines[wah_first + bt * B + tid];
-            Rinfo = line | ((A.kind && (A.kind[line] & KIND_HAPLOID)) ? 0x80000000u : 0u);
-        }
+    // line id, then its kind byte: two dependent loads, taken one batch apart (ids three batches ahead, kinds two) so
+    // that neither is waited for where it is issued.  Both are unconditional (clamped index, dummy address without
+    // a kind array): a load under a branch makes the compiler drain vmcnt at the loop head.
+    uint32_t Rline = 0, Rkind = 0;
+    const uint8_t* kind_p = A.kind ? A.kind : reinterpret_cast<const uint8_t*>(A.wah_lines);
+    const uint32_t kind_mask = A.kind ? KIND_HAPLOID : 0u;
+    auto load_line = [&](uint32_t bt) {
+        const uint32_t j = bt * B + (tid < B ? tid : 0u);
+        Rline = A.wah_lines[wah_first + (j < n_wah ? j : n_wah - 1u)];
     };
-    auto store_info = [&](uint32_t bt) {
+    auto load_kind = [&]() { Rkind = kind_p[A.kind ? Rline : 0u]; };  // of the ids in Rline
+    auto store_info = [&](uint32_t bt) {  // ids in Rline, kinds in Rkind: both of batch bt
+        Rinfo = (bt * B + tid < n_wah) ? (Rline | ((Rkind & kind_mask) ? 0x80000000u : 0u)) : 0u;
         if (tid < B) linfo[(bt % 3u) * 16u + tid] = Rinfo;
     };
+    // unconditional loads (word 0 of the source where there is nothing to fetch; store_cols zeroes those): see above
     auto load_cols = [&](uint32_t bt) {
 #pragma unroll
         for (int r = 0; r < CHAIN_RMAX; ++r) {
             const uint32_t idx = (uint32_t)r * T + tid;
             const uint32_t jj = idx >> A.log2_cwp, wi = idx & cwp_mask;
             const uint32_t j = bt * B + jj;
-            uint32_t v = 0;
-            if (jj < B && j < n_wah && wi < src_words) {
-                const size_t row = DECODE ? (size_t)(wah_first + j) : (size_t)(linfo[(bt % 3u) * 16u + jj] & 0x7FFFFFFFu);
-                v = A.src[row * A.src_stride_w + ((size_t)wi << A.src_elem_shift)];
-            }
-            R[r] = v;
+            const bool ok = jj < B && j < n_wah && wi < src_words;
+            const size_t row = DECODE ? (size_t)(wah_first + j) : (size_t)(linfo[(bt % 3u) * 16u + (ok ? jj : 0u)] & 0x7FFFFFFFu);
+            R[r] = A.src[ok ? row * A.src_stride_w + ((size_t)wi << A.src_elem_shift) : (size_t)0];
         }
     };
-    auto store_cols = [&](uint32_t buf) {
+    auto store_cols = [&](uint32_t bt) {
+        const uint32_t buf = bt & 1u;
+#pragma unroll
+        for (int r = 0; r < CHAIN_RMAX; ++r) asm volatile("" ::"v"(R[r]));  // waited for on every path
 #pragma unroll
         for (int r = 0; r < CHAIN_RMAX; ++r) {
             const uint32_t idx = (uint32_t)r * T + tid;
@@ -702,7 +708,7 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
             if (jj < B && wi < CW) {
                 // positions [N, NA) of `a` hold padding members whose key is always 1, so they stay
                 // behind every real member (stable partition) and never need a validity test
-                uint32_t v = R[r];
+                uint32_t v = (bt * B + jj < n_wah && wi < src_words) ? R[r] : 0u;
                 const uint32_t b0 = wi * 32u;
                 if (b0 + 32u > N) v |= (b0 >= N) ? 0xFFFFFFFFu : (0xFFFFFFFFu << (N - b0));
                 col[(buf * B + jj) * CW + wi] = v;
@@ -710,10 +716,13 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
         }
     };
 
-    load_info(0);
+    load_line(0);
+    load_kind();
     store_info(0);
-    load_info(1);
+    load_line(1);
+    load_kind();
     store_info(1);
+    load_line(2);
     lds_barrier();
     load_cols(0);
     store_cols(0);
@@ -723,9 +732,12 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
     using LdsAT = __attribute__((address_space(3))) AT;
     const uint32_t a_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     for (uint32_t bt = 0; bt < n_batches; ++bt) {
-        const bool more = bt + 1u < n_batches;
-        load_info(bt + 2u);
-        if (more) load_cols(bt + 1u);
+        load_kind();  // of batch bt + 2, whose ids arrived a batch ago
+        const uint32_t Rline_cur = Rline;
+        load_line(bt + 3u);
+        const uint32_t Rline_nxt = Rline;
+        Rline = Rline_cur;
+        load_cols(bt + 1u);  // (beyond the last batch: nothing valid, zeros are parked)
         const uint32_t jn = (n_wah - bt * B) < B ? (n_wah - bt * B) : B;
         uint32_t info_v = linfo[(bt % 3u) * 16u];  // line id of the next step, read one step ahead
         for (uint32_t jj = 0; jj < jn; ++jj) {
@@ -829,8 +841,9 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
             });
             lds_barrier();
         }
-        if (more) store_cols((bt + 1u) & 1u);
+        store_cols(bt + 1u);
         store_info(bt + 2u);
+        Rline = Rline_nxt;
         lds_barrier();
     }
 }

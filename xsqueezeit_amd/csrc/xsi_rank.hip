@@ -150,16 +150,24 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
         return;
     }
 
+    // Staged path.  Loads and stores share one in-order counter (vmcnt), so a wait for prefetched rows that
+    // comes behind output stores also waits for those stores to complete.  Hence: a line's output words go to
+    // LDS, a batch's outputs are flushed right after the barrier that ends it, and the loads of the batch after
+    // next follow the flush - when they are waited for, a whole batch later, the flush has long completed.
+    // All loads are unconditional (clamped addresses): under a branch the compiler drains vmcnt at the loop head.
+    constexpr uint32_t CH = (uint32_t)W * E;                             // chunks of this workgroup
     uint2* stage = reinterpret_cast<uint2*>(smem);                       // 2 x B x CWP pairs
     const uint32_t B = A.batch;
-    uint32_t* meta = reinterpret_cast<uint32_t*>(stage + 2u * B * CWP);  // 2 x B x {line, Z}
+    uint32_t* meta = reinterpret_cast<uint32_t*>(stage + 2u * B * CWP);  // 3 x B x {line, Z}
+    uint2* obuf = reinterpret_cast<uint2*>(meta + 6u * B);               // 2 x B x CH output words
     const uint32_t cwp_mask = (1u << A.log2_cwp) - 1u;
     const uint32_t n_batches = (n_wah + B - 1u) / B;
     uint2 R[RANK_RP];
     uint2 Rm = make_uint2(0, 0);
     auto load_batch = [&](uint32_t bt) {
-        if (tid < B && bt * B + tid < n_wah) {
-            const uint32_t rank = wah_first + bt * B + tid;
+        {
+            const uint32_t j = bt * B + (tid < B ? tid : 0u);
+            const uint32_t rank = wah_first + (j < n_wah ? j : n_wah - 1u);
             Rm = make_uint2(A.wah_lines[rank], A.wah_z[rank]);
         }
 #pragma unroll
@@ -167,15 +175,20 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
             const uint32_t idx = (uint32_t)q * T + tid;
             const uint32_t jj = idx >> A.log2_cwp, wi = idx & cwp_mask;
             const uint32_t j = bt * B + jj;
-            uint2 v = make_uint2(0, 0);
-            if (jj < B && j < n_wah && wi < CWP) v = A.yp[(size_t)(wah_first + j) * CWP + wi];
-            R[q] = v;
+            const bool ok = jj < B && j < n_wah && wi < CWP;
+            R[q] = A.yp[(size_t)wah_first * CWP + (ok ? j * CWP + wi : 0u)];
         }
     };
-    auto store_batch = [&](uint32_t buf) {
+    auto store_batch = [&](uint32_t bt) {
+        const uint32_t buf = bt & 1u, mb = bt % 3u;
+        // every loaded register is consumed on every path: what a skipped branch leaves "maybe pending" turns into
+        // vmcnt bounds at later writes of these registers, inside the line loop
+        asm volatile("" ::"v"(Rm.x), "v"(Rm.y));
+#pragma unroll
+        for (int q = 0; q < RANK_RP; ++q) asm volatile("" ::"v"(R[q].x), "v"(R[q].y));
         if (tid < B) {
-            meta[(buf * B + tid) * 2u] = Rm.x;
-            meta[(buf * B + tid) * 2u + 1u] = Rm.y;
+            meta[(mb * B + tid) * 2u] = Rm.x;
+            meta[(mb * B + tid) * 2u + 1u] = Rm.y;
         }
 #pragma unroll
         for (int q = 0; q < RANK_RP; ++q) {
@@ -184,17 +197,41 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
             if (jj < B && wi < CWP) stage[(buf * B + jj) * CWP + wi] = R[q];
         }
     };
+    // ranks restored from `park` are waited for here: left pending into the loop, every use of r[] in it carries a
+    // vmcnt bound that also covers the flush stores and prefetch loads of the batch
+#pragma unroll
+    for (int e = 0; e < E; ++e) asm volatile("" : "+v"(r[e]));
+    const uint32_t wg_c0 = blockIdx.y * CH;  // first chunk of this workgroup
+    const bool last_split = blockIdx.y + 1u == gridDim.y;
+    auto flush = [&](uint32_t bt, uint32_t jn) {
+        const uint32_t buf = bt & 1u, mb = bt % 3u;
+        for (uint32_t idx = tid; idx < jn * CH; idx += T) {
+            const uint32_t jj = idx / CH, c = idx - jj * CH;
+            if (wg_c0 + c < row_chunks) {
+                const uint32_t line = meta[(mb * B + jj) * 2u];
+                reinterpret_cast<uint2*>(A.out + (size_t)line * A.out_stride_w)[wg_c0 + c] = obuf[(buf * B + jj) * CH + c];
+            }
+        }
+        // rows padded beyond the chunks any workgroup holds: zeroed by the last split (rare geometry)
+        if (last_split && row_chunks > gridDim.y * CH)
+            for (uint32_t jj = 0; jj < jn; ++jj) {
+                const uint32_t line = meta[(mb * B + jj) * 2u];
+                for (uint32_t i = 2u * gridDim.y * CH + tid; i < A.out_stride_w; i += T) A.out[(size_t)line * A.out_stride_w + i] = 0;
+            }
+    };
     load_batch(0);
     store_batch(0);
     __syncthreads();
     for (uint32_t bt = 0; bt < n_batches; ++bt) {
-        const bool more = bt + 1u < n_batches;
-        if (more) load_batch(bt + 1u);
+        const uint32_t bt_n = bt + 1u < n_batches ? bt + 1u : bt;  // the last batch fetches itself again
+        load_batch(bt_n);
         const uint32_t jn = (n_wah - bt * B) < B ? (n_wah - bt * B) : B;
+        const uint32_t buf = bt & 1u, mb = bt % 3u;
+        uint32_t Zv = meta[mb * B * 2u + 1u];  // zeros of the next line, read one line ahead
         for (uint32_t jj = 0; jj < jn; ++jj) {
-            const uint2* row = stage + ((bt & 1u) * B + jj) * CWP;
-            const uint32_t line = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[((bt & 1u) * B + jj) * 2u]);
-            const uint32_t Z = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta[((bt & 1u) * B + jj) * 2u + 1u]);
+            const uint2* row = stage + (buf * B + jj) * CWP;
+            const uint32_t Z = (uint32_t)__builtin_amdgcn_readfirstlane((int)Zv);
+            Zv = meta[(mb * B + (jj + 1u < jn ? jj + 1u : jj)) * 2u + 1u];
             uint2 pr[E];
             static_for<0, E>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
@@ -210,15 +247,11 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
                 mine_lo = write_lane(mine_lo, (uint32_t)m, (uint32_t)e);
                 mine_hi = write_lane(mine_hi, (uint32_t)(m >> 32), (uint32_t)e);
             });
-            if (store_lane) {
-                uint2* orow = reinterpret_cast<uint2*>(A.out + (size_t)line * A.out_stride_w);
-                orow[cg0 + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
-            }
-            if (pad_writer)
-                for (uint32_t i = row_words + tid; i < A.out_stride_w; i += T) A.out[(size_t)line * A.out_stride_w + i] = 0;
+            if (lane < (uint32_t)E) obuf[(buf * B + jj) * CH + w * E + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
         }
-        if (more) store_batch((bt + 1u) & 1u);
+        store_batch(bt + 1u);  // (after the last batch: a copy nobody reads)
         __syncthreads();
+        flush(bt, jn);
     }
     if (park_after) {
         static_for<0, E>([&](auto ecn) {
@@ -311,13 +344,11 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
     uint32_t line = A.wah_lines[wah_first], Z = A.wah_z[wah_first];
     __syncthreads();
     for (uint32_t j = 0; j < n_wah; ++j) {
-        const bool more = j + 1u < n_wah;
-        uint32_t line_n = 0, Z_n = 0;
-        if (more) {
-            load_row(j + 1u);
-            line_n = A.wah_lines[wah_first + j + 1u];
-            Z_n = A.wah_z[wah_first + j + 1u];
-        }
+        // unconditional prefetch (the last line fetches its own row again), see k_chain_decode_rank_wg
+        const uint32_t jn = j + 1u < n_wah ? j + 1u : j;
+        load_row(jn);
+        const uint32_t line_n = A.wah_lines[wah_first + jn];
+        const uint32_t Z_n = A.wah_z[wah_first + jn];
         uint32_t mine_lo = 0, mine_hi = 0;
         const uint32_t Zs = (uint32_t)__builtin_amdgcn_readfirstlane((int)Z);  // wave-uniform: keep it scalar
         uint32_t tbase = tab_lds;
@@ -344,16 +375,20 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
 #pragma unroll
             for (int e = 0; e < G; ++e) asm volatile("" : "+v"(r[g0 + e]));  // this group's updates end here
         });
+        // The single row buffer is rewritten between two barriers; the output stores come after that, so that the
+        // wait for the prefetched row does not also wait for them (loads and stores return in order on one counter).
+        const size_t orow_w = (size_t)line * A.out_stride_w;
+        __syncthreads();  // everyone is done with the row
+        store_row();
+        line = (uint32_t)__builtin_amdgcn_readfirstlane((int)line_n);
+        Z = (uint32_t)__builtin_amdgcn_readfirstlane((int)Z_n);
+        asm volatile("" : "+s"(line), "+s"(Z)::"memory");
         if (store_lane) {
-            uint2* orow = reinterpret_cast<uint2*>(A.out + (size_t)line * A.out_stride_w);
+            uint2* orow = reinterpret_cast<uint2*>(A.out + orow_w);
             orow[cg0 + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
         }
         if (pad_writer)
-            for (uint32_t i = row_words + tid; i < A.out_stride_w; i += T) A.out[(size_t)line * A.out_stride_w + i] = 0;
-        __syncthreads();  // everyone is done with the row
-        if (more) store_row();
-        line = line_n;
-        Z = Z_n;
+            for (uint32_t i = row_words + tid; i < A.out_stride_w; i += T) A.out[orow_w + i] = 0;
         __syncthreads();
     }
     if (A.ph_start && wah_first + n_wah != D.wah_first + D.n_wah) {
@@ -458,13 +493,13 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
     __syncthreads();
     using LdsPair = __attribute__((address_space(3))) rank_u32x2;
     for (uint32_t j = 0; j < n_wah; ++j) {
-        const bool more = j + 1u < n_wah;
-        uint32_t line_n = 0, Z_n = 0;
-        if (more) {
-            load_row(j + 1u);
-            line_n = A.wah_lines[wah_first + j + 1u];
-            Z_n = A.wah_z[wah_first + j + 1u];
-        }
+        // The prefetch is unconditional (the last line fetches its own row again): with it under a branch the
+        // compiler cannot tell at the loop head whether the loads have been waited for and drains vmcnt there,
+        // which also waits for the output stores of the line before.
+        const uint32_t jn = j + 1u < n_wah ? j + 1u : j;
+        load_row(jn);
+        const uint32_t line_n = A.wah_lines[wah_first + jn];
+        const uint32_t Z_n = A.wah_z[wah_first + jn];
         const uint32_t Zs = (uint32_t)__builtin_amdgcn_readfirstlane((int)Z);  // wave-uniform: keep it scalar
         uint32_t tbase = tab_lds + (j & 1u) * SLOT;
         uint32_t mine_lo = 0, mine_hi = 0;
@@ -493,7 +528,13 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
 #pragma unroll
             for (int e = 0; e < G; ++e) asm volatile("" : "+v"(r[g0 + e]));  // this group's updates end here
         });
+        // Park the prefetched row BEFORE this line's output stores: loads and stores share vmcnt and return in order,
+        // so a wait for the row placed behind the stores would also wait for them to complete, every line.
         uint32_t* orow = A.out + (size_t)line * A.out_stride_w;
+        store_row((j + 1u) & 1u);
+        line = (uint32_t)__builtin_amdgcn_readfirstlane((int)line_n);  // the two small loads are consumed here too
+        Z = (uint32_t)__builtin_amdgcn_readfirstlane((int)Z_n);
+        asm volatile("" : "+s"(line), "+s"(Z)::"memory");
         if (store_lane) reinterpret_cast<uint2*>(orow)[cg0 + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
         if (odd_tail && lane < (uint32_t)E) {
             const uint32_t wi = 2u * (cg0 + lane);
@@ -502,9 +543,6 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
         }
         // words of the output row beyond the chunks this workgroup holds (rows padded past 16*E chunks)
         for (uint32_t i = 2u * W * E + tid; i < A.out_stride_w; i += T) orow[i] = 0;
-        if (more) store_row((j + 1u) & 1u);
-        line = line_n;
-        Z = Z_n;
         __syncthreads();  // the next row is staged; everyone is done with this one
     }
     if (A.ph_start && wah_first + n_wah != D.wah_first + D.n_wah) {
@@ -544,7 +582,8 @@ static RankGeom rank_geometry(uint32_t N, uint32_t yp_stride, uint32_t n_blocks)
     {
         const uint32_t s_target = n_blocks >= 256u ? 1u : (256u + n_blocks / 2u) / (n_blocks ? n_blocks : 1u);
         const uint32_t per_wg = (nch + s_target - 1u) / s_target;  // chunks one workgroup should cover
-        T = per_wg <= 8u ? 256 : (per_wg <= 64u ? 512 : 1024);
+        // (16 waves of 3 chunks beat 8 waves of 5 at 5008 haplotypes, 2.14 against 2.33 ms: half the staging per thread)
+        T = per_wg <= 8u ? 256 : (per_wg <= 32u ? 512 : 1024);
         const uint32_t waves = (uint32_t)T / 64u;
         uint32_t e = (per_wg + waves - 1u) / waves;
         if (e < 1u) e = 1u;
@@ -562,7 +601,7 @@ static RankGeom rank_geometry(uint32_t N, uint32_t yp_stride, uint32_t n_blocks)
         uint32_t B = (uint32_t)(RANK_RP * g.T) >> g.log2_cwp;
         if (B > 16u) B = 16u;
         if (B < 1u) B = 1u;
-        auto need = [&](uint32_t b) { return 2u * b * yp_stride * 8u + 2u * b * 8u + 64u; };
+        auto need = [&](uint32_t b) { return 2u * b * yp_stride * 8u + 3u * b * 8u + 2u * b * per_wg * 8u + 64u; };
         while (B > 1u && need(B) > 64u * 1024u) B >>= 1;
         g.batch = B;
         g.lds_bytes = need(B);
@@ -752,7 +791,8 @@ hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_
     R.out = out_rows;
     R.out_stride_w = out_stride_w;
     R.N = L.N;
-    const RankGeom g = rank_geometry(L.N, L.yp_stride, n_blocks);
+    RankGeom g = rank_geometry(L.N, L.yp_stride, n_blocks);
+    if (const char* e = getenv("XSI_DEC_B")) { uint32_t b = (uint32_t)atoi(e); if (b >= 1 && b < g.batch) g.batch = b; }
     R.batch = g.batch;
     R.log2_cwp = g.log2_cwp;
     const int fam = rank_decode_family(L.N, L.yp_stride, n_blocks);
