@@ -792,7 +792,7 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
         uint32_t max_words = 0;
         for (auto& b : P->blocks_h)
             if (!b.error && b.wah_words > max_words) max_words = b.wah_words;
-        L.max_tiles = (max_words + 2047u) / 2048u;
+        L.max_tiles = (max_words + WAH_BND_TILE_WORDS - 1u) / WAH_BND_TILE_WORDS;
         const size_t cells = (size_t)(L.max_tiles ? L.max_tiles : 1) * n_blocks;
         WS(L.tile_sum, "dec.tile_sum", 4ull * cells);
         WS(L.tile_base, "dec.tile_base", 8ull * cells);

@@ -117,6 +117,45 @@ __global__ void __launch_bounds__(256) k_count_rows_v4(const uint4* __restrict__
     }
 }
 
+// Long rows (stride a multiple of 16 bytes, above 1 KiB): one wave per row, 16-byte loads, eight in flight per
+// lane before the first popcount (the dword loop above reaches 5.4 TB/s at configs[2]; this is the pass that reads
+// the whole input once, so it is priced against the streaming rate of the chip).
+__global__ void __launch_bounds__(256) k_count_rows_wide(const uint4* __restrict__ planes, uint32_t stride_q,
+                                                         uint32_t nbits, uint32_t n_rows, uint32_t* __restrict__ cnt) {
+    constexpr uint32_t MAXQ = 8;
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const uint32_t lane = lane_id();
+    const uint32_t nw = (nbits + 31u) >> 5, nq = (nw + 3u) >> 2;
+    const uint4* base = planes + (size_t)row * stride_q;
+    const uint32_t last_mask = (nbits & 31u) ? (1u << (nbits & 31u)) - 1u : ~0u;
+    uint32_t c = 0;
+    for (uint32_t q0 = 0; q0 < nq; q0 += 64u * MAXQ) {
+        uint4 v[MAXQ];
+#pragma unroll
+        for (uint32_t i = 0; i < MAXQ; ++i) {
+            const uint32_t q = q0 + i * 64u + lane;
+            typedef uint32_t cnt_u32x4 __attribute__((ext_vector_type(4)));
+            const cnt_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const cnt_u32x4*>(base + (q < nq ? q : nq - 1u)));
+            v[i] = make_uint4(t[0], t[1], t[2], t[3]);  // unconditional: all in flight together
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < MAXQ; ++i) {
+            const uint32_t q = q0 + i * 64u + lane;
+            const uint32_t x[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t wi = q * 4u + j;
+                uint32_t t = (q < nq && wi < nw) ? x[j] : 0u;
+                if (wi == nw - 1u) t &= last_mask;
+                c += (uint32_t)__popc(t);
+            }
+        }
+    }
+    c = wave_sum(c);
+    if (lane == 0) cnt[row] = c;
+}
+
 __global__ void __launch_bounds__(256) k_wah_lines_per_block(const uint32_t* __restrict__ cnt, uint64_t n_lines,
                                                              uint32_t block_len, uint32_t nbits, uint32_t thr,
                                                              uint32_t* __restrict__ out) {
@@ -148,6 +187,11 @@ hipError_t launch_count_rows(hipStream_t s, const uint32_t* planes, uint32_t str
     if ((stride_w & 3u) == 0 && (reinterpret_cast<uintptr_t>(planes) & 15u) == 0 && stride_w / 4u * 8u <= 64u * 8u) {
         k_count_rows_v4<<<dim3((n_rows + 31u) / 32u), dim3(256), 0, s>>>(reinterpret_cast<const uint4*>(planes),
                                                                           stride_w / 4u, nbits, n_rows, cnt);
+        return hipGetLastError();
+    }
+    if ((stride_w & 3u) == 0 && (reinterpret_cast<uintptr_t>(planes) & 15u) == 0 && !getenv("XSI_COUNT_DWORD")) {
+        k_count_rows_wide<<<dim3((n_rows + 3u) / 4u), dim3(256), 0, s>>>(reinterpret_cast<const uint4*>(planes), stride_w / 4u,
+                                                                        nbits, n_rows, cnt);
         return hipGetLastError();
     }
     k_count_rows<<<dim3((n_rows + 3u) / 4u), dim3(256), 0, s>>>(planes, stride_w, nbits, n_rows, cnt);
@@ -2325,7 +2369,10 @@ hipError_t launch_dec_line_lists(hipStream_t s, const DecBlock* blocks, uint32_t
 // workgroups: (1) groups per tile of 2048 words, (2) per block exclusive scan of the tile sums
 // (+ the cumulative line offsets of mixed-ploidy blocks), (3) per tile: scan inside the tile and
 // report the words at which a line starts.
-constexpr uint32_t BND_T = 256, BND_K = 8, BND_TILE = BND_T * BND_K;
+// A thread takes BND_Q consecutive 8-word groups (64 bytes); smaller tiles (one group per thread: 343 000 workgroups
+// at configs[2]) were bound by workgroup dispatch and by the scan's barrier, not by the 1.4 GB they read.
+constexpr uint32_t BND_T = 256, BND_K = 8, BND_Q = 4, BND_TILE = BND_T * BND_K * BND_Q;
+static_assert(BND_TILE == WAH_BND_TILE_WORDS, "the host sizes tile_sum / tile_base with WAH_BND_TILE_WORDS");
 
 __device__ __forceinline__ uint32_t wah_groups_of(uint32_t word) { return (word & 0x8000u) ? (word & WAH_MAXC) : 1u; }
 
@@ -2352,14 +2399,17 @@ __global__ void __launch_bounds__(BND_T) k_wah_tile_sums(const uint8_t* __restri
     const uint32_t c0 = blockIdx.x * BND_TILE;
     if (D.error || D.n_wah == 0 || c0 >= D.wah_words) return;
     const uint16_t* wm = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah);
-    const uint32_t w0 = c0 + threadIdx.x * BND_K;
+    const uint32_t w0 = c0 + threadIdx.x * BND_K * BND_Q;
     static_assert(BND_K == 8, "load_words8");
-    uint32_t wd[8];
-    load_words8(wm, w0, D.wah_words, wd);
+    uint32_t wd[BND_Q][8];
+#pragma unroll
+    for (uint32_t q = 0; q < BND_Q; ++q) load_words8(wm, w0 + q * BND_K, D.wah_words, wd[q]);
     uint32_t sum = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < BND_K; ++k)
-        if (wd[k] < 0x10000u) sum += wah_groups_of(wd[k]);
+    for (uint32_t q = 0; q < BND_Q; ++q)
+#pragma unroll
+        for (uint32_t k = 0; k < BND_K; ++k)
+            if (wd[q][k] < 0x10000u) sum += wah_groups_of(wd[q][k]);
     sum = wave_sum(sum);
     if (lane_id() == 0) s_part[threadIdx.x >> 6] = sum;
     __syncthreads();
@@ -2409,18 +2459,20 @@ __global__ void __launch_bounds__(BND_T) k_wah_boundaries(const uint8_t* __restr
     if (D.error || D.n_wah == 0 || c0 >= D.wah_words) return;
     const uint16_t* wm = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah);
     const uint32_t nwords = D.wah_words;
-    constexpr uint32_t K = BND_K;
+    constexpr uint32_t K = BND_K * BND_Q;
     const uint32_t Gd = (L.N + WAH_BITS - 1u) / WAH_BITS;
     const bool mixed = D.off_line_haploid != VAL_UNDEFINED;
     const uint32_t w0 = c0 + threadIdx.x * K;
     uint32_t g[K];
     uint32_t sum = 0;
     {
-        uint32_t wd[8];
-        load_words8(wm, w0, nwords, wd);
+        uint32_t wd[BND_Q][8];
+#pragma unroll
+        for (uint32_t q = 0; q < BND_Q; ++q) load_words8(wm, w0 + q * BND_K, nwords, wd[q]);
 #pragma unroll
         for (uint32_t k = 0; k < K; ++k) {
-            const uint32_t ng = wd[k] < 0x10000u ? wah_groups_of(wd[k]) : 0u;
+            const uint32_t word = wd[k / BND_K][k % BND_K];
+            const uint32_t ng = word < 0x10000u ? wah_groups_of(word) : 0u;
             g[k] = ng;
             sum += ng;
         }

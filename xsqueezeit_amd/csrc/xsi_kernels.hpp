@@ -96,6 +96,8 @@ hipError_t launch_sparse_copy(hipStream_t s, const EncBlock* blocks, uint32_t n_
                               const uint64_t* d_result, const uint8_t* scratch, uint64_t scratch_stride);
 
 // ---- decode ----
+constexpr uint32_t WAH_BND_TILE_WORDS = 8192u;  // words per tile of the WAH line-boundary scan (k_wah_tile_sums / k_wah_boundaries)
+
 struct DecLines {
     uint32_t N;            // 2 * n_samples
     uint32_t n_samples;
@@ -119,7 +121,7 @@ struct DecLines {
     uint32_t y_stride64;   // ceil(N/64): 64-bit words of a plain bit row
     uint32_t* ones;        // per binary line: allele count (accessor "ones")
     uint32_t* wah_cumg;    // [wah rank] cumulative 15-bit groups before the line (mixed-ploidy blocks)
-    uint32_t* tile_sum;    // [block][max_tiles] 15-bit groups per 2048-word tile of the WAH matrix
+    uint32_t* tile_sum;    // [block][max_tiles] 15-bit groups per tile of WAH_BND_TILE_WORDS words of the WAH matrix
     uint64_t* tile_base;   // [block][max_tiles] groups before the tile
     uint32_t max_tiles;
     uint64_t file_len;     // bytes of the file image (bounds every read)
