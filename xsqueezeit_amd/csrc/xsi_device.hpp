@@ -79,6 +79,18 @@ __device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t v) {
     return v;
 }
 
+// 64-lane inclusive prefix maximum (unsigned; lanes outside a row read 0, the identity)
+__device__ __forceinline__ uint32_t wave_scan_max_incl_dpp(uint32_t v) {
+    auto mx = [](uint32_t a, int b) { return a > (uint32_t)b ? a : (uint32_t)b; };
+    v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true));
+    v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true));
+    v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true));
+    v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true));
+    v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1,3
+    v = mx(v, __builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 __device__ __forceinline__ uint64_t wave_scan_incl64(uint64_t v) {
     const uint32_t lane = lane_id();
 #pragma unroll
@@ -289,7 +301,27 @@ __device__ __forceinline__ uint32_t wah_units_classify_line(LdsCU32* row, uint32
     const uint32_t inc = wave_scan_incl_dpp(cnt);
     return (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
 }
-// Emit the words of the line to dst (2-byte aligned).  `fh` = LDS scratch of 64 * WAH_UNIT_ROUNDS words.
+// position of the k-th (0-based) set bit of x, k < popcount(x)
+__device__ __forceinline__ uint32_t select_bit32(uint32_t x, uint32_t k) {
+    uint32_t pos = 0, t;
+    t = (uint32_t)__popc(x & 0xFFFFu);
+    if (k >= t) { k -= t; pos = 16u; x >>= 16; }
+    t = (uint32_t)__popc(x & 0xFFu);
+    if (k >= t) { k -= t; pos += 8u; x >>= 8; }
+    t = (uint32_t)__popc(x & 0xFu);
+    if (k >= t) { k -= t; pos += 4u; x >>= 4; }
+    t = (uint32_t)__popc(x & 0x3u);
+    if (k >= t) { k -= t; pos += 2u; x >>= 2; }
+    if (k >= (x & 1u)) pos += 1u;
+    return pos;
+}
+// Emit the words of the line to dst (2-byte aligned).  `fh` = LDS scratch of 64 * WAH_UNIT_ROUNDS + 16 words.
+// WORD-major: lane i of a step forms word i of the round.  The heads are spread very unevenly over the units (2.4 a
+// unit on average at configs[2], ~30 in the busiest of a round), so a loop in which every unit emits its own heads runs
+// as long as the busiest unit at a few percent lane use.  A word's unit: the units whose first word falls into the
+// step's 64 words leave their lane number at that word's slot of a 64-byte LDS strip, a prefix maximum over the lanes
+// spreads it (carry: the unit of the step before); the unit's masks come over ds_bpermute, the head inside the unit
+// by select_bit32; the 64 words of a step leave in one 128-byte store.
 __device__ __forceinline__ void wah_units_emit_line(LdsCU32* row, LdsU32W* fh, uint32_t G, const WahUnit (&m)[WAH_UNIT_ROUNDS],
                                                     uint16_t* __restrict__ dst) {
     const uint32_t lane = lane_id();
@@ -301,11 +333,12 @@ __device__ __forceinline__ void wah_units_emit_line(LdsCU32* row, LdsU32W* fh, u
         fh[(uint32_t)r * 64u + lane] = ((uint32_t)r * 64u + lane) * 32u + (uint32_t)__builtin_ctz(m[r].H | 0x80000000u);
     }
     const uint64_t above = (lane == 63u) ? 0ull : (~0ull << (lane + 1u));
+    using LdsU8W = __attribute__((address_space(3))) uint8_t;
+    LdsU8W* mk = reinterpret_cast<LdsU8W*>(fh + 64u * (uint32_t)WAH_UNIT_ROUNDS);
     uint32_t round_off = 0;
 #pragma unroll
     for (int r = 0; r < WAH_UNIT_ROUNDS; ++r) {
         if ((uint32_t)r >= rounds) break;  // wave-uniform
-        const uint32_t gb = ((uint32_t)r * 64u + lane) * 32u;
         // first head after my unit: a later lane of this round, else the first unit with a head of a later round
         uint32_t later = ~0u;  // wave-uniform
 #pragma unroll
@@ -316,21 +349,35 @@ __device__ __forceinline__ void wah_units_emit_line(LdsCU32* row, LdsU32W* fh, u
         const uint32_t nh = tu != ~0u ? fh[tu] : G;
         const uint32_t cnt = (uint32_t)__popc(m[r].H);
         const uint32_t inc = wave_scan_incl_dpp(cnt);
-        uint32_t idx = round_off + inc - cnt;
-        round_off += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        uint32_t Hr = m[r].H;
-        while (__any(Hr != 0u)) {
-            if (Hr) {
-                const uint32_t k = (uint32_t)__builtin_ctz(Hr);
-                Hr &= Hr - 1u;
-                const uint32_t g = gb + k;
-                const uint32_t nxt = Hr ? gb + (uint32_t)__builtin_ctz(Hr) : nh;
-                const uint32_t o = g * WAH_BITS;
-                const uint32_t lit = __builtin_amdgcn_alignbit(row[(o >> 5) + 1u], row[o >> 5], o & 31u) & 0x7FFFu;
-                const uint32_t fill = 0x8000u | (((m[r].O >> k) & 1u) << 14) | (nxt - g);
-                dst[idx++] = (uint16_t)(((m[r].F >> k) & 1u) ? fill : lit);
-            }
+        const uint32_t excl = inc - cnt;
+        const uint32_t Wr = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);  // words of this round
+        uint32_t carry = 0;  // unit lane + 1 of the last word of the step before
+        for (uint32_t t0 = 0; t0 < Wr; t0 += 64u) {
+            mk[lane] = 0;
+            if (cnt && excl - t0 < 64u) mk[excl - t0] = (uint8_t)(lane + 1u);  // (excl < t0 wraps to a large number)
+            asm volatile("" ::: "memory");  // other lanes' stores: no forwarding of my own zero to the load below
+            uint32_t u = wave_scan_max_incl_dpp((uint32_t)mk[lane]);  // one wave: its LDS operations stay in order
+            u = u > carry ? u : carry;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)u, 63);
+            const uint32_t ul = u - 1u;  // u >= 1: word 0 of a round is the first word of a unit
+            const uint32_t t = t0 + lane;
+            const int ua = (int)(ul << 2);
+            const uint32_t Hs = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)m[r].H);
+            const uint32_t Fs = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)m[r].F);
+            const uint32_t Os = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)m[r].O);
+            const uint32_t ex = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)excl);
+            const uint32_t nhs = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)nh);
+            const uint32_t kk = t - ex;  // lanes beyond the round: anything, nothing is stored
+            const uint32_t k = select_bit32(Hs, kk < 32u ? kk : 31u) & 31u;
+            const uint32_t g = ((uint32_t)r * 64u + ul) * 32u + k;
+            const uint32_t rest = (Hs >> k) >> 1;
+            const uint32_t nxt = rest ? g + 1u + (uint32_t)__builtin_ctz(rest) : nhs;
+            const uint32_t o = g * WAH_BITS;
+            const uint32_t lit = __builtin_amdgcn_alignbit(row[(o >> 5) + 1u], row[o >> 5], o & 31u) & 0x7FFFu;
+            const uint32_t fill = 0x8000u | (((Os >> k) & 1u) << 14) | (nxt - g);
+            if (t < Wr) dst[round_off + t] = (uint16_t)(((Fs >> k) & 1u) ? fill : lit);
         }
+        round_off += Wr;
     }
 }
 

@@ -1479,7 +1479,7 @@ __global__ void __launch_bounds__(256) k_wah_sizes(EncLines L, const uint32_t* _
 // xsi_device.hpp on it.  The sizing pass counts heads; the writing pass (after the layout is known) classifies
 // again and stores the words straight into the file image: no scratch copy of the words (10 GB at 64 976 x 2 M).
 constexpr int WAH_STAGE_Q = 16;  // 16 x 64 lanes x 8 bytes = 8 KiB
-constexpr uint32_t WAH_UNIT_WAVE_WORDS = WAH_UNIT_ROW_WORDS + 64u * (uint32_t)WAH_UNIT_ROUNDS;
+constexpr uint32_t WAH_UNIT_WAVE_WORDS = WAH_UNIT_ROW_WORDS + 64u * (uint32_t)WAH_UNIT_ROUNDS + 16u;  // row, fh, 64-byte strip
 template <bool WRITE_PASS>
 __global__ void __launch_bounds__(256) k_wah_units(const EncBlock* __restrict__ blocks, EncLines L,
                                                    const uint32_t* __restrict__ d_total_wah, uint32_t max_wah,
