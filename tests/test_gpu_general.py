@@ -732,3 +732,43 @@ def test_reencode_on_device(tmp_path):
     bad = G.params(n + 1, 80, 3, dp)
     assert L.xsi_hip_reencode(G.ctx().handle, d_file.data_ptr(), len(src), nal.ctypes.data, len(lines), ctypes.byref(bad),
                               None, 0, d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)) == binding.XSI_ERR_ARG
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bad", [(3 + 1) << 1, ((2 + 1) << 1) | 1, -1, -2, -3, -4, -2147483646])
+def test_unknown_allele_is_an_error(bad):
+    """An allele number outside [0, n_allele) ends the encode with "Unknown allele error !" (scan_genotypes,
+    gt_block.hpp:226-268): too large, and the negative int32 values that are neither missing (0, 1, INT_MIN)
+    nor end-of-vector (INT_MIN + 1).  The same rows without the bad value encode, and missing / end-of-vector
+    values right next to it are not mistaken for alleles."""
+    import gpu_util as G
+    torch = G.torch_mod()
+    L = binding.lib()
+    n, n_lines = 70, 6          # 140 values: the bad one sits in the ragged last chunk of 64
+    N = 2 * n
+    rng = np.random.default_rng(77)
+    m = (((rng.integers(0, 2, size=(n_lines, N)) + 1) << 1) | (np.arange(N) & 1)).astype(np.int32)
+    m[1, 5] = 0                          # missing
+    m[1, 6] = np.int32(-2147483648)      # missing (bcf_int32_missing)
+    m[2, 7] = np.int32(-2147483647)      # end of vector
+    ngt = np.full(n_lines, N, dtype=np.uint32)
+    nal = np.full(n_lines, 2, dtype=np.uint32)
+    p = G.params(n, 8192, 1)
+    cap = int(L.xsi_hip_encode_gt_bound(ctypes.byref(p), n_lines, n_lines))
+    d_out = G.dev_empty(cap)
+    d_off = torch.zeros(1, dtype=torch.int64, device="cuda")
+    res = binding.EncodeResult()
+
+    def run(mat):
+        d_gt = torch.from_numpy(mat).cuda()
+        return L.xsi_hip_encode_gt(G.ctx().handle, ctypes.byref(p), d_gt.data_ptr(), N, n_lines, ngt.ctypes.data,
+                                   nal.ctypes.data, d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res))
+
+    assert run(m) == 0
+    for pos in (3, 131):                 # first chunk; last (partial) chunk
+        mb = m.copy()
+        mb[4, pos] = np.int32(bad)
+        rc = run(mb)
+        assert rc == binding.XSI_ERR_ARG, (bad, pos, rc)
+        assert b"Unknown allele" in L.xsi_hip_last_error()
+    assert run(m) == 0                   # the context stays usable

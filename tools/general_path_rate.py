@@ -57,9 +57,15 @@ def main():
     ngt_out = np.zeros(S, dtype=np.uint32)
     d_file = torch.empty(cap + 256 + 8 * n_blocks + 64, dtype=torch.uint8, device=dev)
 
+    wall = {"encode_gt": 0.0, "harness_between": 0.0, "decode_gt": 0.0}
+
     def step():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         binding.check(L.xsi_hip_encode_gt(ctx.handle, ctypes.byref(p), d_gt.data_ptr(), N, S, ngt.ctypes.data,
                                           nal.ctypes.data, d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         nb = res.blocks_bytes
         pad = (-(256 + nb)) % 8
         io = 256 + nb + pad
@@ -71,11 +77,20 @@ def main():
         d_file[256:256 + nb] = d_out[:nb]
         d_file[256 + nb:io] = 0
         d_file[io:so] = d_off.view(torch.uint8)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
         binding.check(L.xsi_hip_decode_gt(ctx.handle, d_file.data_ptr(), so, 0, n_blocks, nal.ctypes.data, S,
                                           d_dec.data_ptr(), N, ngt_out.ctypes.data, d_cnt.data_ptr(), 2))
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        wall["encode_gt"] += t1 - t0
+        wall["harness_between"] += t2 - t1
+        wall["decode_gt"] += t3 - t2
 
     step()
     torch.cuda.synchronize()
+    for k in wall:
+        wall[k] = 0.0
     ctx.set_timing(True)
     t = time.perf_counter()
     for _ in range(args.steps):
@@ -87,7 +102,8 @@ def main():
     cells = float(N) * S
     print(json.dumps({"workload": "%d hap x %d bi-allelic sites, int32 rows in HBM -> xsi_hip_encode_gt -> xsi_hip_decode_gt -> int32 rows"
                                   % (N, S), "ms_per_step": 1e3 * dt, "cells_per_s": cells / dt,
-                      "int32_GBps_each_way": 4 * cells / dt / 1e9, "xsi_bytes": int(res.blocks_bytes), "rows_equal": ok, "stage_ms_per_step": stages}))
+                      "int32_GBps_each_way": 4 * cells / dt / 1e9, "xsi_bytes": int(res.blocks_bytes), "rows_equal": ok,
+                      "wall_ms_per_step": {k: round(1e3 * v / args.steps, 3) for k, v in wall.items()}, "stage_ms_per_step": stages}))
 
 
 if __name__ == "__main__":

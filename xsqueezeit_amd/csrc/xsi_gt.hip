@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_unpack_gt(UnpackArgs U) {
     __syncthreads();
     const int32_t* row = U.gt + (size_t)l * U.gt_stride;
     const uint32_t nchunks = U.stride_w / 2u;  // 64-bit words per plane row (all written, pad = 0)
-    uint32_t c_ref = 0, c_miss = 0, c_eov = 0, any_phase = 0, c_alt1 = 0;
+    uint32_t c_ref = 0, c_miss = 0, c_eov = 0, any_phase = 0, c_alt1 = 0, maxc = 0;
     // Each wave owns a contiguous quarter of the row.  The 64-bit ballot words of up to 64 chunks are
     // parked one per lane (v_writelane) and leave as one coalesced store per plane; the int32 loads
     // of four chunks are issued before the first one is used.
@@ -97,13 +97,20 @@ __global__ void __launch_bounds__(256) k_unpack_gt(UnpackArgs U) {
     for (uint32_t g0 = c_begin; g0 < c_end; g0 += 64u) {
         const uint32_t gn = c_end - g0 < 64u ? c_end - g0 : 64u;  // chunks in this group
         uint32_t a_ref[2] = {0, 0}, a_miss[2] = {0, 0}, a_eov[2] = {0, 0}, a_ph[2] = {0, 0}, a_alt[2] = {0, 0};
-        for (uint32_t q0 = 0; q0 < gn; q0 += 4u) {
-            int32_t vv[4];
+        // The int32 loads of the NEXT four chunks are in flight while the current four are worked on.  They are
+        // unconditional (clamped index; `in` below discards the value): with a default value under a condition the
+        // compiler waits for each load where it is issued.
+        int32_t vv[4], vn[4];
+        auto issue = [&](uint32_t q0, int32_t (&dst)[4]) {
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u) {
                 const uint32_t i = (g0 + q0 + u) * 64u + lane;
-                vv[u] = (q0 + u < gn && i < ngt) ? row[i] : 0;
+                dst[u] = row[(q0 + u < gn && i < ngt) ? i : 0u];
             }
+        };
+        issue(0u, vv);
+        for (uint32_t q0 = 0; q0 < gn; q0 += 4u) {
+            issue(q0 + 4u, vn);
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u) {
                 if (q0 + u >= gn) break;  // wave-uniform
@@ -111,16 +118,22 @@ __global__ void __launch_bounds__(256) k_unpack_gt(UnpackArgs U) {
                 const uint32_t i = cgi * 64u + lane;
                 const bool in = i < ngt;
                 const int32_t v = vv[u];
-                const bool missing = in && (((v >> 1) == 0) || v == GT_INT32_MISSING);
-                const bool eov = in && !missing && v == GT_VECTOR_END;
-                const bool called = in && !missing && !eov;
-                const int32_t allele = (v >> 1) - 1;
-                if (called && (allele < 0 || allele >= (int32_t)n_allele)) *U.d_error = 1;  // "Unknown allele error !"
-                const bool ph = in && diploid && (i & 1u) && ((v & 1) != U.default_phased);
-                const uint64_t m_ref = __ballot(called && allele == 0);
-                const uint64_t m_miss = __ballot(missing);
-                const uint64_t m_eov = __ballot(eov);
-                const uint64_t m_ph = __ballot(ph);
+                // One code per value - 0 missing, 1 end of vector, allele + 2 when called, ~0 beyond the line - so
+                // that every plane is a ballot of ONE vector compare (a ballot of a combination of conditions is
+                // lowered through a select and a second compare).
+                const uint32_t t = (uint32_t)(v >> 1);
+                uint32_t code = (t < 0x7FFFFFFFu ? t : 0x7FFFFFFFu) + 1u;  // saturating: a negative allele number cannot wrap into 0 / 1
+                code = (t == 0u || v == GT_INT32_MISSING) ? 0u : code;
+                code = (v == GT_VECTOR_END) ? 1u : code;  // (its t is 0xC0000000: not "missing")
+                code = in ? code : ~0u;
+                const bool called = code >= 2u && in;
+                const int32_t allele = (int32_t)code - 2;
+                maxc = in ? (code > maxc ? code : maxc) : maxc;  // "Unknown allele error !": an allele outside [0, n_allele)
+                const uint32_t phx = (in && diploid && (i & 1u)) ? (((uint32_t)v & 1u) ^ (uint32_t)U.default_phased) : 0u;
+                const uint64_t m_ref = __builtin_amdgcn_ballot_w64(code == 2u);
+                const uint64_t m_miss = __builtin_amdgcn_ballot_w64(code == 0u);
+                const uint64_t m_eov = __builtin_amdgcn_ballot_w64(code == 1u);
+                const uint64_t m_ph = __builtin_amdgcn_ballot_w64(phx != 0u);
                 const uint32_t slot = q0 + u;
                 a_ref[0] = write_lane(a_ref[0], (uint32_t)m_ref, slot);
                 a_ref[1] = write_lane(a_ref[1], (uint32_t)(m_ref >> 32), slot);
@@ -136,19 +149,21 @@ __global__ void __launch_bounds__(256) k_unpack_gt(UnpackArgs U) {
                 any_phase |= m_ph ? 1u : 0u;
                 // first ALT allele through the lane-parked path, further ALT alleles directly
                 {
-                    const uint64_t m = __ballot(called && allele == 1);
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(code == 3u);
                     a_alt[0] = write_lane(a_alt[0], (uint32_t)m, slot);
                     a_alt[1] = write_lane(a_alt[1], (uint32_t)(m >> 32), slot);
                     c_alt1 += (uint32_t)__popcll(m);
                 }
                 for (uint32_t k = 2; k < n_allele; ++k) {
-                    const uint64_t m = __ballot(called && allele == (int32_t)k);
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(called && allele == (int32_t)k);
                     if (lane == 0) {
                         reinterpret_cast<uint64_t*>(U.planes + (size_t)(b0 + k - 1u) * U.stride_w)[cgi] = m;
                         if (m) atomicAdd(&s_alt[(k - 1u) & 63u], (uint32_t)__popcll(m));
                     }
                 }
             }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) vv[u] = vn[u];
         }
         if (lane < gn) {
             p_ref[g0 + lane] = ((uint64_t)a_ref[1] << 32) | a_ref[0];
@@ -158,6 +173,7 @@ __global__ void __launch_bounds__(256) k_unpack_gt(UnpackArgs U) {
             p_alt[g0 + lane] = ((uint64_t)a_alt[1] << 32) | a_alt[0];
         }
     }
+    if (maxc >= n_allele + 2u) *U.d_error = 1;  // (a negative allele number shows as a huge code)
     if (lane == 0) {
         if (c_alt1) atomicAdd(&s_alt[0], c_alt1);
         atomicAdd(&s_cnt[0], c_ref);
@@ -916,7 +932,9 @@ int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_
     const uint32_t n_bcf = (uint32_t)n_lines;
     const uint32_t n_blocks = (uint32_t)((n_lines + p->block_len - 1) / p->block_len);
     // host-side line bookkeeping
-    std::vector<uint32_t> first_bin(n_bcf), parent, nbits_bin;
+    // (two plain passes over the caller's arrays: this loop runs in front of every launch of the call, and at a
+    //  million lines a division and three push_backs per line cost as much as the kernels behind it)
+    std::vector<uint32_t> first_bin(n_bcf);
     std::vector<EncBlock> blocks(n_blocks);
     uint64_t n_bin64 = 0;
     uint32_t max_ploidy = 0;
@@ -925,17 +943,21 @@ int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_
             return set_error(XSI_ERR_UNSUPPORTED, "line %u has %u alleles: lines without an ALT allele corrupt the reference's "
                              "flag reindexing (gt_block.hpp:650-666) and are rejected", l, h_n_allele[l]);
         if (h_ngt[l] != p->n_samples && h_ngt[l] != N) return set_error(XSI_ERR_ARG, "PLOIDY ERROR: line %u has %u values", l, h_ngt[l]);
-        const uint32_t pl = h_ngt[l] / p->n_samples;
+        const uint32_t pl = h_ngt[l] == N ? 2u : 1u;
         if (pl > max_ploidy) max_ploidy = pl;
         first_bin[l] = (uint32_t)n_bin64;
-        for (uint32_t k = 1; k < h_n_allele[l]; ++k) {
-            parent.push_back(l);
-            nbits_bin.push_back(h_ngt[l]);
-        }
         n_bin64 += h_n_allele[l] - 1;
         if (n_bin64 > 0x7FFFFFFFull) return set_error(XSI_ERR_ARG, "too many binary lines in one call");
     }
     const uint32_t n_bin = (uint32_t)n_bin64;
+    std::vector<uint32_t> parent(n_bin), nbits_bin(n_bin);
+    for (uint32_t l = 0; l < n_bcf; ++l) {
+        const uint32_t b = first_bin[l], na = h_n_allele[l] - 1u, ng = h_ngt[l];
+        for (uint32_t k = 0; k < na; ++k) {
+            parent[b + k] = l;
+            nbits_bin[b + k] = ng;
+        }
+    }
     for (uint32_t b = 0; b < n_blocks; ++b) {
         memset(&blocks[b], 0, sizeof(EncBlock));
         const uint32_t f = b * p->block_len;
@@ -1036,7 +1058,8 @@ int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_
     int rc = encode_run(ctx, p, L, S, blocks, d_out, out_capacity, d_block_offsets, h_result);
     if (rc) return rc;
     uint32_t err = 0;
-    HIP_TRY(hipMemcpy(&err, U.d_error, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(&err, U.d_error, 4, hipMemcpyDeviceToHost, s));  // on the context's stream: a copy on the
+    HIP_TRY(hipStreamSynchronize(s));                                       // null stream drags every other stream in
     if (err) return set_error(XSI_ERR_ARG, "Unknown allele error !");
     if (h_result) h_result->max_ploidy = max_ploidy;
     return XSI_OK;
