@@ -526,12 +526,13 @@ __global__ void __launch_bounds__(256) k_compose_gt(ComposeArgs C) {
     const uint32_t* pp = C.S.phase_planes ? C.S.phase_planes + (size_t)start * C.S.stride_w : nullptr;
     int32_t* orow = C.out + (size_t)li * C.out_stride;
     // value of haplotype i of this line
-    auto value_of = [&](uint32_t i) -> int32_t {
+    // w0 = word i / 32 of the line's first plane (the callers fetch it ahead of time)
+    auto value_of = [&](uint32_t i, uint32_t w0) -> int32_t {
         const int32_t ph = (int32_t)(i & 1u) & DP;
         const uint32_t wi = i >> 5, bi = i & 31u;
         int32_t gt;
         {
-            const uint32_t bit = (C.planes[(size_t)start * C.stride_w + wi] >> bi) & 1u;
+            const uint32_t bit = (w0 >> bi) & 1u;
             if (!(k0 & KIND_WAH)) {
                 const bool neg = (k0 & KIND_NEGATED) != 0u;
                 const int32_t allele = neg ? (bit ? 0 : 1) : (bit ? 1 : 0);
@@ -567,14 +568,38 @@ __global__ void __launch_bounds__(256) k_compose_gt(ComposeArgs C) {
     };
     // grid.y workgroups share one line (few lines of many haplotypes: random access); four values per
     // thread leave as one 16-byte store when the row base allows it
+    const uint32_t* p0 = C.planes + (size_t)start * C.stride_w;
     if (((C.out_stride & 3u) | (reinterpret_cast<uintptr_t>(C.out) & 15u)) == 0) {
+        // the plane words of a thread's next KU quads are fetched together (unconditionally: clamped index), then the
+        // 16-byte stores follow one another; written once and not read back here, so the stores are non-temporal
+        constexpr uint32_t KU = 8;
+        typedef int32_t gt_i32x4 __attribute__((ext_vector_type(4)));
         const uint32_t Nq = Nl / 4u;
-        int4* orow4 = reinterpret_cast<int4*>(orow);
-        for (uint32_t q = blockIdx.y * blockDim.x + threadIdx.x; q < Nq; q += blockDim.x * gridDim.y)
-            orow4[q] = make_int4(value_of(4u * q), value_of(4u * q + 1u), value_of(4u * q + 2u), value_of(4u * q + 3u));
-        if (blockIdx.y == 0 && threadIdx.x < (Nl & 3u)) orow[Nq * 4u + threadIdx.x] = value_of(Nq * 4u + threadIdx.x);
+        gt_i32x4* orow4 = reinterpret_cast<gt_i32x4*>(orow);
+        const uint32_t qs = blockDim.x * gridDim.y;
+        for (uint32_t q0 = blockIdx.y * blockDim.x + threadIdx.x; q0 < Nq; q0 += qs * KU) {
+            uint32_t pw[KU];
+#pragma unroll
+            for (uint32_t k = 0; k < KU; ++k) {
+                const uint32_t q = q0 + k * qs;
+                pw[k] = p0[(q < Nq ? q : 0u) >> 3];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < KU; ++k) {
+                const uint32_t q = q0 + k * qs;
+                if (q < Nq) {
+                    const gt_i32x4 v = {value_of(4u * q, pw[k]), value_of(4u * q + 1u, pw[k]), value_of(4u * q + 2u, pw[k]),
+                                        value_of(4u * q + 3u, pw[k])};
+                    __builtin_nontemporal_store(v, orow4 + q);
+                }
+            }
+        }
+        if (blockIdx.y == 0 && threadIdx.x < (Nl & 3u)) {
+            const uint32_t i = Nq * 4u + threadIdx.x;
+            orow[i] = value_of(i, p0[i >> 5]);
+        }
     } else {
-        for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < Nl; i += blockDim.x * gridDim.y) orow[i] = value_of(i);
+        for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < Nl; i += blockDim.x * gridDim.y) orow[i] = value_of(i, p0[i >> 5]);
     }
     if (threadIdx.x == 0 && blockIdx.y == 0) {
         C.line_ngt[li] = Nl;
