@@ -397,10 +397,15 @@ __device__ __forceinline__ uint32_t wave_wah_expand_row(const uint16_t* __restri
     const uint32_t row_bits = ((nbits + 31u) >> 5) << 5;
     uint32_t gbase = 0, wbase = 0, cnt1 = 0;
     uint32_t cur = pre0;
+    // The words are in global memory; said so explicitly, because a pointer rebuilt from two v_readlane halves is
+    // "generic" to the compiler and its loads become flat_load (counted in vmcnt AND lgkmcnt: every wait for one
+    // also drains the LDS queue).  The look-ahead load is unconditional (clamped index, `have` discards the value):
+    // under a condition with a default it is waited for where it is issued.
+    const __attribute__((address_space(1))) uint16_t* gsrc = (const __attribute__((address_space(1))) uint16_t*)src;
     while (gbase < G && wbase < max_words) {
         const uint32_t wi = wbase + lane;
         const bool have = wi < max_words;
-        const uint32_t nxt = wi + 64u < max_words ? (uint32_t)src[wi + 64u] : 0u;
+        const uint32_t nxt = (uint32_t)gsrc[wi + 64u < max_words ? wi + 64u : 0u];
         const uint32_t word = have ? cur : 0u;
         const bool fill = (word & 0x8000u) != 0u;
         const uint32_t ng = have ? (fill ? (word & WAH_MAXC) : 1u) : 0u;

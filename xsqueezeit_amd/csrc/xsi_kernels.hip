@@ -2621,7 +2621,8 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
     };
     const uint16_t* src = src_of(0);
     uint32_t maxw = (uint32_t)__builtin_amdgcn_readlane((int)m_maxw, 0);
-    uint32_t pre = lane < maxw ? (uint32_t)src[lane] : 0u;
+    using GlobU16 = const __attribute__((address_space(1))) uint16_t;  // see wave_wah_expand_row
+    uint32_t pre = lane < maxw ? (uint32_t)((GlobU16*)src)[lane] : 0u;
     __syncthreads();
     for (uint32_t k = 0; k < WAH_LINES_PER_WAVE && j0 + k < total; ++k) {
         const uint32_t j = j0 + k;
@@ -2633,7 +2634,7 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
         if (k + 1u < WAH_LINES_PER_WAVE && j + 1u < total) {
             src_n = src_of(k + 1u);
             maxw_n = (uint32_t)__builtin_amdgcn_readlane((int)m_maxw, (int)(k + 1u));
-            pre_n = lane < maxw_n ? (uint32_t)src_n[lane] : 0u;
+            pre_n = (uint32_t)((GlobU16*)src_n)[lane < maxw_n ? lane : 0u];  // unconditional: in flight across this line's expansion
         }
         uint32_t ones;
         (void)wave_wah_expand_row(src, maxw, nbits, row, &ones, pre);
