@@ -333,6 +333,9 @@ __device__ __forceinline__ void wah_units_emit_line(LdsCU32* row, LdsU32W* fh, u
         fh[(uint32_t)r * 64u + lane] = ((uint32_t)r * 64u + lane) * 32u + (uint32_t)__builtin_ctz(m[r].H | 0x80000000u);
     }
     const uint64_t above = (lane == 63u) ? 0ull : (~0ull << (lane + 1u));
+    // dst is rebuilt from two v_readlane halves by the caller: say that it is global memory, or the stores are flat
+    // stores, which count in lgkmcnt too and are then waited for by every LDS wait that follows
+    __attribute__((address_space(1))) uint16_t* gdst = (__attribute__((address_space(1))) uint16_t*)dst;
     using LdsU8W = __attribute__((address_space(3))) uint8_t;
     LdsU8W* mk = reinterpret_cast<LdsU8W*>(fh + 64u * (uint32_t)WAH_UNIT_ROUNDS);
     uint32_t round_off = 0;
@@ -375,7 +378,7 @@ __device__ __forceinline__ void wah_units_emit_line(LdsCU32* row, LdsU32W* fh, u
             const uint32_t o = g * WAH_BITS;
             const uint32_t lit = __builtin_amdgcn_alignbit(row[(o >> 5) + 1u], row[o >> 5], o & 31u) & 0x7FFFu;
             const uint32_t fill = 0x8000u | (((Os >> k) & 1u) << 14) | (nxt - g);
-            if (t < Wr) dst[round_off + t] = (uint16_t)(((Fs >> k) & 1u) ? fill : lit);
+            if (t < Wr) gdst[round_off + t] = (uint16_t)(((Fs >> k) & 1u) ? fill : lit);
         }
         round_off += Wr;
     }

@@ -718,7 +718,10 @@ __global__ void __launch_bounds__(T) k_chain_lds(const EncBlock* __restrict__ eb
     // that neither is waited for where it is issued.  Both are unconditional (clamped index, dummy address without
     // a kind array): a load under a branch makes the compiler drain vmcnt at the loop head.
     uint32_t Rline = 0, Rkind = 0;
-    const uint8_t* kind_p = A.kind ? A.kind : reinterpret_cast<const uint8_t*>(A.wah_lines);
+    // (explicitly a global pointer: the select of two pointers is "generic" to the compiler, and a flat load counts in
+    //  lgkmcnt as well - the first LDS wait of the batch would wait for it)
+    using GlobU8 = const __attribute__((address_space(1))) uint8_t;
+    GlobU8* kind_p = A.kind ? (GlobU8*)A.kind : (GlobU8*)A.wah_lines;
     const uint32_t kind_mask = A.kind ? KIND_HAPLOID : 0u;
     auto load_line = [&](uint32_t bt) {
         const uint32_t j = bt * B + (tid < B ? tid : 0u);
@@ -1766,7 +1769,7 @@ __global__ void __launch_bounds__(256) k_wah_write(const EncBlock* __restrict__ 
         if (n <= head) continue;
         const uint32_t m = n - head;  // words from src + head to the 4-byte aligned dst + head
         const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
-        uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+        __attribute__((address_space(1))) uint32_t* d32 = (__attribute__((address_space(1))) uint32_t*)(dst + head);  // global, not flat
         for (uint32_t i = lane; i < m / 2u; i += 64u) {
             uint32_t v;
             if (head)
