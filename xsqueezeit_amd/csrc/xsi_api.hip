@@ -346,7 +346,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
         for (auto& b : blocks_h) max_bin = b.n_bin > max_bin ? b.n_bin : max_bin;
         const uint64_t per_line = (1ull + (p->mac_threshold < N / 2u ? p->mac_threshold : N / 2u)) * L.aet;
         sp_stride = (max_bin * per_line + 255u) & ~255ull;
-        if (sp_stride * n_blocks <= (1ull << 30)) WS(sp_scratch, "enc.sparse_scratch", sp_stride * n_blocks);
+        if (sp_stride * n_blocks <= (1ull << 30) && !getenv("XSI_NO_SPARSE_OVERLAP")) WS(sp_scratch, "enc.sparse_scratch", sp_stride * n_blocks);
     }
     if (sp_scratch) {
         HIP_TRY(hipEventRecord(ctx->ev_fork, s));
