@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep, GPU path against the CPU oracle (test infrastructure, like tests/): random shapes of the
+packed path (haplotypes 2 .. 140 000, block lengths, MAC thresholds) and of the general int32 path (multi-allelic,
+missing, end-of-vector, phase, haploid lines).  Not part of the pytest suite (minutes, not seconds):
+    gpurun -- python3 tools/stress_parity.py --seed 1 --cases 60
+Prints one line per case and exits non-zero on the first mismatch."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cases", type=int, default=60)
+    args = ap.parse_args()
+    import gpu_util as G
+    from oracle import oracle
+    from test_oracle import _random_lines
+    from xsqueezeit_amd import synth
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time()
+    for c in range(args.cases):
+        kind = "packed" if c % 3 else "general"
+        if kind == "packed":
+            # sizes around every kernel boundary: 12 288, 16 384, 20 000, 49 152, 65 536, 131 072
+            base = int(rng.choice([2, 64, 130, 1000, 5008, 12288, 16384, 20000, 32768, 49152, 65534, 65536, 70002, 131072, 140000]))
+            n_haps = max(2, base + int(rng.integers(-70, 70))) & ~1
+            if 65536 <= n_haps <= 131070 and False:
+                pass
+            if 32768 * 2 <= n_haps <= 65535 * 2:   # the reference's A_T mismatch window is refused by design
+                n_haps = 131072 + 2 * int(rng.integers(0, 3000))
+            cells_budget = 24_000_000
+            n_lines = int(min(max(1, cells_budget // n_haps), rng.integers(1, 400)))
+            block_len = int(rng.choice([1, 3, 8, 16, 64, 100, 8192]))
+            thr = int(rng.choice([0, 1, n_haps // 1000, n_haps // 100, n_haps // 10]))
+            dens = float(rng.choice([0.0005, 0.01, 0.1, 0.5, 0.9]))
+            bits = (rng.random((n_lines, n_haps)) < dens).astype(np.uint8)
+            # runs: copy founders so that PBWT produces long fills
+            if rng.random() < 0.5 and n_lines > 4:
+                f = rng.integers(0, 8, size=n_haps)
+                fb = (rng.random((n_lines, 8)) < dens).astype(np.uint8)
+                bits = fb[:, f] ^ (rng.random((n_lines, n_haps)) < 0.002).astype(np.uint8)
+            stride = synth.row_stride_bytes(n_haps)
+            packed = synth.pack_rows(bits, stride)
+            p = G.params(n_haps // 2, block_len, thr)
+            names = ["S%d" % i for i in range(n_haps // 2)]
+            ref = G.oracle_file_from_bits(bits, p, names)
+            region, offsets, res = G.encode_packed(packed, n_haps, p)
+            got = G.assemble_file(region, offsets, p, n_lines, n_lines, names)
+            ok = got == ref
+            out, counts = G.decode_packed(got, n_haps, stride)
+            ok2 = np.array_equal(out, packed) and np.array_equal(counts, bits.sum(1).astype(np.int32))
+            print("%3d packed  haps=%6d lines=%4d block=%4d thr=%5d dens=%.4f bytes=%8d  encode %s decode %s  (%.0f s)"
+                  % (c, n_haps, n_lines, block_len, thr, dens, len(got), "ok" if ok else "MISMATCH", "ok" if ok2 else "MISMATCH",
+                     time.time() - t0), flush=True)
+            if not (ok and ok2):
+                sys.exit(1)
+        else:
+            n = int(rng.choice([3, 37, 333, 2504, 6000, 9000, 20000]))
+            n_lines = int(min(max(2, 6_000_000 // (2 * n)), rng.integers(2, 300)))
+            block_len = int(rng.choice([1, 4, 32, 100, 8192]))
+            kw = dict(multi=bool(rng.integers(0, 2)), missing=bool(rng.integers(0, 2)), eov=bool(rng.integers(0, 2)),
+                      phase=bool(rng.integers(0, 2)))
+            lines = _random_lines(rng, n, n_lines, **kw)
+            # fully haploid lines only without multi-allelic ones in the block: the reference writes KEY_LINE_HAPLOID per BCF
+            # line and reads it per binary line, such blocks do not decode back to their input anywhere
+            if not kw["multi"] and rng.random() < 0.6:
+                for i in range(0, n_lines, 5):
+                    al = (rng.random(n) < 0.3).astype(np.int32)
+                    lines[i] = (((al + 1) << 1).astype(np.int32), 2)
+            dp = oracle.default_phased_of(lines, n)
+            thr = int(rng.choice([0, 1, max(1, 2 * n // 100)]))
+            p = G.params(n, block_len, thr, dp)
+            ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=thr, default_phased=dp)
+            region, offsets, res = G.encode_gt(lines, n, p)
+            names = ["S%d" % i for i in range(n)]
+            got = G.assemble_file(region, offsets, p, n_lines, G.num_variants(lines), names, 2)
+            ok = got == ref
+            nal = [na for _, na in lines]
+            rows, counts = G.decode_gt(got, nal)
+            ok2 = all(np.array_equal(rows[i][:len(lines[i][0])], lines[i][0]) for i in range(n_lines))
+            print("%3d general samples=%6d lines=%4d block=%4d thr=%4d %s bytes=%8d  encode %s decode %s  (%.0f s)"
+                  % (c, n, n_lines, block_len, thr, "".join(k[0] for k, v in kw.items() if v) or "-", len(got),
+                     "ok" if ok else "MISMATCH", "ok" if ok2 else "MISMATCH", time.time() - t0), flush=True)
+            if not (ok and ok2):
+                sys.exit(1)
+    print("all %d cases ok" % args.cases)
+
+
+if __name__ == "__main__":
+    main()
