@@ -20,6 +20,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--cells", type=int, default=24_000_000, help="packed cases: haplotypes x lines at most")
+    ap.add_argument("--max-lines", type=int, default=400)
     args = ap.parse_args()
     import gpu_util as G
     from oracle import oracle
@@ -37,8 +39,8 @@ def main():
                 pass
             if 32768 * 2 <= n_haps <= 65535 * 2:   # the reference's A_T mismatch window is refused by design
                 n_haps = 131072 + 2 * int(rng.integers(0, 3000))
-            cells_budget = 24_000_000
-            n_lines = int(min(max(1, cells_budget // n_haps), rng.integers(1, 400)))
+            cells_budget = args.cells
+            n_lines = int(min(max(1, cells_budget // n_haps), rng.integers(1, args.max_lines)))
             block_len = int(rng.choice([1, 3, 8, 16, 64, 100, 8192]))
             thr = int(rng.choice([0, 1, n_haps // 1000, n_haps // 100, n_haps // 10]))
             dens = float(rng.choice([0.0005, 0.01, 0.1, 0.5, 0.9]))
