@@ -388,3 +388,58 @@ def test_wah_unit_encoder_on_adversarial_rows(n_haps):
         raise AssertionError("file differs at offset %d (sizes %d vs %d)" % (first, len(got), len(ref)))
     out, _ = G.decode_packed(got, n_haps, stride)
     assert np.array_equal(out, packed)
+
+
+@pytest.mark.parametrize("n_haps", [32, 482, 962, 1442, 5008, 7682, 12224])
+def test_small_row_unit_encoder_on_adversarial_rows(n_haps):
+    """Rows short enough for several lines per wave (k_wah_units_small: lane = (line, unit), heads counted per line by a
+    segmented scan, units 1 .. 26 per line here): runs on the group / word / unit seams, lone literals at the first
+    and last positions of a line and of a unit, neighbouring lines with very different head counts (the per-line
+    offsets come from the lane before the line), lines that are not WAH lines in between (they are skipped: the
+    lines of a wave are then not consecutive binary lines)."""
+    import gpu_util as G
+    rng = np.random.default_rng(n_haps)
+    rows = []
+
+    def row_from_runs(runs):
+        out = np.zeros(n_haps, dtype=np.uint8)
+        pos, k = 0, 0
+        while pos < n_haps:
+            v, ln = runs[k % len(runs)]
+            out[pos:pos + ln] = v
+            pos += ln
+            k += 1
+        return out
+    for a in (15, 30, 32, 480, 465, 479, 481, 7):
+        for b in (15, 1, 480, 14, 31):
+            rows.append(row_from_runs([(1, a), (0, b)]))
+            rows.append(row_from_runs([(0, a), (1, b)]))
+    for start in (0, 14, 15, 479, 480, 481, n_haps - 16, n_haps - 15, n_haps - 1):
+        if 0 <= start < n_haps:
+            r = np.zeros(n_haps, dtype=np.uint8)
+            r[start] = 1
+            rows.append(r)                          # (a singleton: sparse at threshold 0? no - minor count 1 > 0: WAH)
+            r = np.ones(n_haps, dtype=np.uint8)
+            r[start] = 0
+            rows.append(r)
+    rows.append(np.zeros(n_haps, dtype=np.uint8))   # monomorphic: not a WAH line, sits between WAH lines
+    r = np.zeros(n_haps, dtype=np.uint8); r[1::2] = 1; rows.append(r)              # all literals next to ...
+    r = np.zeros(n_haps, dtype=np.uint8); r[:n_haps // 2] = 1; rows.append(r)      # ... two words
+    rows.append(np.ones(n_haps, dtype=np.uint8))    # monomorphic again
+    for _ in range(12):
+        rows.append((rng.random(n_haps) < rng.choice([0.01, 0.3, 0.5, 0.97])).astype(np.uint8))
+    order = rng.permutation(len(rows))
+    bits = np.stack([rows[i] for i in order])
+    stride = synth.row_stride_bytes(n_haps)
+    packed = synth.pack_rows(bits, stride)
+    for block_len in (1, 7):
+        p = G.params(n_haps // 2, block_len, 0)
+        names = ["S%d" % i for i in range(n_haps // 2)]
+        ref = G.oracle_file_from_bits(bits, p, names)
+        region, offsets, res = G.encode_packed(packed, n_haps, p)
+        got = G.assemble_file(region, offsets, p, len(rows), len(rows), names)
+        if got != ref:
+            first = next(i for i in range(min(len(got), len(ref))) if got[i] != ref[i])
+            raise AssertionError("block_len %d: file differs at offset %d (sizes %d vs %d)" % (block_len, first, len(got), len(ref)))
+        out, _ = G.decode_packed(got, n_haps, stride)
+        assert np.array_equal(out, packed)

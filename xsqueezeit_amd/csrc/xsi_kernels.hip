@@ -1477,6 +1477,99 @@ __global__ void __launch_bounds__(256) k_wah_sizes(EncLines L, const uint32_t* _
     }
 }
 
+// Short rows (at most 32 units of 480 bits: up to 15 360 haplotypes): the unit encoder of xsi_device.hpp with SEVERAL
+// lines per wave.  A line has upl = ceil(groups / 32) units; a wave takes 64 / upl lines at once, lane = (line, unit).
+// The rows sit back to back in LDS, upl * 15 words each, so lane L reads from word 15 L: no bank conflicts.  Heads are
+// counted per line with a segmented wave scan; with a scratch row per line the words are emitted at once (the serial
+// encoder this replaces walks a line 64 groups at a time with a carried run state, about 150 instructions per step of a
+// dependent chain: 0.61 ms at 5008 haplotypes x 1 M sites).
+constexpr uint32_t WAH_SMALL_ROW_WORDS = 64u * 15u + 16u;  // rows of one wave + room for the one-word over-read of a literal
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_wah_units_small(EncLines L, const uint32_t* __restrict__ d_total_wah, uint32_t upl) {
+    __shared__ uint32_t s_rows[4][WAH_SMALL_ROW_WORDS];
+    __shared__ uint32_t s_fh[4][64];
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t lpw = 64u / upl;  // lines per wave
+    const uint32_t j0 = (blockIdx.x * 4u + wv) * lpw;
+    const uint32_t total = d_total_wah[0];
+    if (j0 >= total) return;
+    using LdsRowW = __attribute__((address_space(3))) uint32_t;
+    LdsRowW* rows = reinterpret_cast<LdsRowW*>((__attribute__((address_space(3))) unsigned char*)&s_rows[wv][0]);
+    LdsRowW* fh = reinterpret_cast<LdsRowW*>((__attribute__((address_space(3))) unsigned char*)&s_fh[wv][0]);
+    const uint32_t li = lane / upl, u = lane - li * upl;  // my line of the wave, my unit of the line
+    const bool mine = li < lpw && j0 + li < total;
+    const uint32_t j = mine ? j0 + li : j0;
+    const uint32_t nbits = mine ? nbits_of(L, L.wah_lines[j]) : 0u;
+    // stage: unit `u` of line `li` = 15 words; bits at or beyond nbits read as zero (wah.hpp:547-565)
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(L.yrows + (size_t)j * L.y_stride64);
+        const uint32_t nw = (nbits + 31u) >> 5;
+        uint32_t w[15];
+#pragma unroll
+        for (uint32_t i = 0; i < 15u; ++i) {
+            const uint32_t wi = u * 15u + i;
+            w[i] = src[(mine && wi < nw) ? wi : 0u];  // unconditional loads, all in flight
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 15u; ++i) {
+            const uint32_t wi = u * 15u + i;
+            uint32_t v = (mine && wi < nw) ? w[i] : 0u;
+            if (wi + 1u == nw && (nbits & 31u)) v &= (1u << (nbits & 31u)) - 1u;
+            rows[lane * 15u + i] = v;
+        }
+        if (lane < 16u) rows[64u * 15u + lane] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");  // other lanes' LDS stores are read below (one wave: its LDS operations stay in order)
+    const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
+    WahUnit m{0u, 0u, 0u};
+    LdsCU32* row = reinterpret_cast<LdsCU32*>(rows + li * upl * 15u);  // my line's row
+    if (mine) wah_unit_classify(row, u, G, m);
+    const uint32_t cnt = (uint32_t)__popc(m.H);
+    const uint32_t inc = wave_scan_incl_dpp(cnt);
+    // heads before my line = inclusive count of the last lane of the line before
+    const uint32_t first_lane = li * upl, last_lane = first_lane + upl - 1u;
+    // (the cross-lane read outside any condition: under a lane-dependent branch the lanes it reads from may be switched off)
+    const uint32_t inc_prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((first_lane ? first_lane - 1u : 0u) << 2), (int)inc);
+    const uint32_t before_line = first_lane ? inc_prev : 0u;
+    const uint32_t line_total = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((last_lane < 64u ? last_lane : 63u) << 2), (int)inc) - before_line;
+    if (mine && u == 0u) L.wah_len[j] = line_total;
+    if (!WRITE) return;
+    // emission into the line's scratch row: every unit its own heads (few units per line: the trip count is small)
+    fh[lane] = u * 32u + (uint32_t)__builtin_ctz(m.H | 0x80000000u);  // first head of my unit (group index in the line)
+    const uint64_t B = __ballot(m.H != 0u);
+    asm volatile("" ::: "memory");
+    const uint64_t above = (lane == 63u) ? 0ull : (~0ull << (lane + 1u));
+    const uint64_t upto = last_lane >= 63u ? ~0ull : ((1ull << (last_lane + 1u)) - 1ull);
+    const uint64_t later = B & above & upto;  // units of MY line behind me that have a head
+    const uint32_t fh_later = (uint32_t)fh[later ? (uint32_t)__builtin_ctzll(later) : 0u];
+    const uint32_t nh = later ? fh_later : G;
+    __attribute__((address_space(1))) uint16_t* dst =
+        (__attribute__((address_space(1))) uint16_t*)(L.wah_scratch + (size_t)j * L.wah_scratch_stride);
+    uint32_t idx = inc - cnt - before_line;
+    uint32_t Hr = mine ? m.H : 0u;
+    const uint32_t gb = u * 32u;
+    while (__any(Hr != 0u)) {
+        if (Hr) {
+            const uint32_t k = (uint32_t)__builtin_ctz(Hr);
+            Hr &= Hr - 1u;
+            const uint32_t g = gb + k;
+            const uint32_t nxt = Hr ? gb + (uint32_t)__builtin_ctz(Hr) : nh;
+            const uint32_t o = g * WAH_BITS;
+            const uint32_t lit = __builtin_amdgcn_alignbit(row[(o >> 5) + 1u], row[o >> 5], o & 31u) & 0x7FFFu;
+            const uint32_t fill = 0x8000u | (((m.O >> k) & 1u) << 14) | (nxt - g);
+            dst[idx++] = (uint16_t)(((m.F >> k) & 1u) ? fill : lit);
+        }
+    }
+}
+
+// rows the small-row kernel takes: at least two lines per wave, and none of the longer-row kernels applies
+static uint32_t wah_units_small_upl(const EncLines& L) {
+    static const bool off = getenv("XSI_WAH_NO_SMALL") != nullptr;
+    const uint32_t G = (L.N + WAH_BITS - 1u) / WAH_BITS, upl = (G + 31u) / 32u;
+    return (!off && upl >= 1u && upl <= 32u && !wah_units_any(L.y_stride64)) ? upl : 0u;
+}
+
 // Rows of at most 8 KiB (N <= 65 536): each wave stages its line in LDS with 8-byte loads, all in flight at
 // once, fetches the next line into registers while it works on the current one, and runs the unit encoder of
 // xsi_device.hpp on it.  The sizing pass counts heads; the writing pass (after the layout is known) classifies
@@ -1726,6 +1819,14 @@ hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_
         if (e != hipSuccess) return e;
         k_wah_units<false><<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), lds, s>>>(nullptr, L, d_total_wah, max_wah,
                                                                                          nullptr, nullptr);
+        return hipGetLastError();
+    }
+    if (const uint32_t upl = wah_units_small_upl(L)) {
+        const uint32_t lines_per_wg = 4u * (64u / upl);
+        if (L.wah_scratch)
+            k_wah_units_small<true><<<dim3((max_wah + lines_per_wg - 1u) / lines_per_wg), dim3(256), 0, s>>>(L, d_total_wah, upl);
+        else
+            k_wah_units_small<false><<<dim3((max_wah + lines_per_wg - 1u) / lines_per_wg), dim3(256), 0, s>>>(L, d_total_wah, upl);
         return hipGetLastError();
     }
     k_wah_sizes<<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), 0, s>>>(L, d_total_wah);
