@@ -443,3 +443,22 @@ def test_small_row_unit_encoder_on_adversarial_rows(n_haps):
             raise AssertionError("block_len %d: file differs at offset %d (sizes %d vs %d)" % (block_len, first, len(got), len(ref)))
         out, _ = G.decode_packed(got, n_haps, stride)
         assert np.array_equal(out, packed)
+
+
+def test_sparse_lists_on_the_main_stream(monkeypatch):
+    """The sparse lists are normally written into a scratch underneath the chain (side stream) and moved into place;
+    when that scratch would be too large - or with XSI_NO_SPARSE_OVERLAP - they are written in place after the layout.
+    Both orders must give the same file."""
+    import gpu_util as G
+    n_haps, n_lines, block_len, thr = 5008, 900, 256, 40
+    bits, packed, stride = _mk(n_haps, n_lines, 4242)
+    p = G.params(n_haps // 2, block_len, thr)
+    names = ["S%d" % i for i in range(n_haps // 2)]
+    ref = G.oracle_file_from_bits(bits, p, names)
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("XSI_NO_SPARSE_OVERLAP", env)
+        region, offsets, res = G.encode_packed(packed, n_haps, p)
+        assert res.n_wah_lines < n_lines            # there are sparse lines
+        got = G.assemble_file(region, offsets, p, n_lines, n_lines, names)
+        assert got == ref, "sparse overlap %s" % ("off" if env else "on")
