@@ -58,7 +58,7 @@ struct RankArgs {
     uint32_t yc_stride;
 };
 
-constexpr int RANK_RP = 6;  // {bits, prefix} pairs a thread carries while a batch is in flight
+constexpr int RANK_RP = 8;  // {bits, prefix} pairs a thread carries while a batch is in flight
 
 template <int T, int E, bool STAGE>
 __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
@@ -599,10 +599,15 @@ static RankGeom rank_geometry(uint32_t N, uint32_t yp_stride, uint32_t n_blocks)
     g.log2_cwp = next_pow2_log2(yp_stride);
     if (g.stage) {
         uint32_t B = (uint32_t)(RANK_RP * g.T) >> g.log2_cwp;
-        if (B > 16u) B = 16u;
+        // A batch costs a barrier, a flush and a wait for its rows whatever its size (configs[1], 1024 threads: 8 lines
+        // per batch 2.58 ms, 16: 2.15, 24: 2.06, 32: 2.05), so batches are as long as the registers
+        // (RANK_RP pairs per thread) and LDS allow: 64 KB when several workgroups share a CU, 128 KB when one has it.
+        static const uint32_t bcap = [] { const char* e = getenv("XSI_DEC_BCAP"); const int v = e ? atoi(e) : 32; return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
+        if (B > bcap) B = bcap;
         if (B < 1u) B = 1u;
         auto need = [&](uint32_t b) { return 2u * b * yp_stride * 8u + 3u * b * 8u + 2u * b * per_wg * 8u + 64u; };
-        while (B > 1u && need(B) > 64u * 1024u) B >>= 1;
+        const uint32_t lds_limit = ((uint64_t)n_blocks * g.splits <= 256u ? 128u : 64u) * 1024u;
+        while (B > 1u && need(B) > lds_limit) B -= (B > 16u ? 4u : B / 2u);
         g.batch = B;
         g.lds_bytes = need(B);
         if ((uint32_t)(RANK_RP * g.T) < yp_stride) g.stage = false;  // one row does not fit a register batch
