@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--cells", type=int, default=24_000_000, help="packed cases: haplotypes x lines at most")
     ap.add_argument("--max-lines", type=int, default=400)
+    ap.add_argument("--files", action="store_true", help="every fourth case through xsi_writer_* / xsi_accessor_*")
     args = ap.parse_args()
     import gpu_util as G
     from oracle import oracle
@@ -29,8 +30,66 @@ def main():
     from xsqueezeit_amd import synth
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
+    import ctypes
+    import tempfile
+    from xsqueezeit_amd import binding
+    L = binding.lib()
+    tmpdir = tempfile.mkdtemp(prefix="xsi_stress_")
     for c in range(args.cases):
         kind = "packed" if c % 3 else "general"
+        if args.files and c % 4 == 1:
+            kind = "file"
+        if kind == "file":
+            # xsi_writer_* / xsi_accessor_*: many small blocks (several writer batches), random read order
+            n = int(rng.choice([3, 20, 120, 700, 2504]))
+            n_lines = int(min(max(2, 3_000_000 // (2 * n)), rng.integers(2, 2500)))
+            block_len = int(rng.choice([1, 2, 5, 16, 100, 8192]))
+            kw = dict(multi=bool(rng.integers(0, 2)), missing=bool(rng.integers(0, 2)), eov=bool(rng.integers(0, 2)),
+                      phase=bool(rng.integers(0, 2)))
+            lines = _random_lines(rng, n, n_lines, **kw)
+            dp = oracle.default_phased_of(lines, n)
+            names = ["s%d" % i for i in range(n)]
+            mac = int(rng.choice([0, 1, 3]))
+            ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=mac, default_phased=dp, sample_names=names)
+            path = os.path.join(tmpdir, "f%d.xsi" % c).encode()
+            p = G.params(n, block_len, mac, dp)
+            w = ctypes.c_void_p()
+            arr = (ctypes.c_char_p * n)(*[x.encode() for x in names])
+            binding.check(L.xsi_writer_open(ctypes.byref(w), G.ctx().handle, path, ctypes.byref(p), arr))
+            for gt, na in lines:
+                gt = np.ascontiguousarray(gt, dtype=np.int32)
+                binding.check(L.xsi_writer_append(w, gt.ctypes.data, gt.size, na))
+            binding.check(L.xsi_writer_finalize(w, 0))
+            L.xsi_writer_close(w)
+            got = open(path, "rb").read()
+            ok = got == ref
+            a = ctypes.c_void_p()
+            binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, path))
+            bms = []
+            block = off = 0
+            for i, (_, na) in enumerate(lines):
+                if i and i % block_len == 0:
+                    block += 1
+                    off = 0
+                bms.append((block << 15) | off)
+                off += na - 1
+            buf = np.zeros(2 * n, dtype=np.int32)
+            order = [int(x) for x in rng.permutation(n_lines)[:400]] + list(range(min(n_lines, 200)))
+            ok2 = True
+            for i in order:
+                na = lines[i][1]
+                r = L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, na, bms[i])
+                if r != len(lines[i][0]) or not np.array_equal(buf[:r], lines[i][0]):
+                    ok2 = False
+                    break
+            L.xsi_accessor_close(a)
+            os.remove(path)
+            print("%3d file    samples=%6d lines=%4d block=%4d thr=%4d %s bytes=%8d  write %s read %s  (%.0f s)"
+                  % (c, n, n_lines, block_len, mac, "".join(k[0] for k, v in kw.items() if v) or "-", len(got),
+                     "ok" if ok else "MISMATCH", "ok" if ok2 else "MISMATCH", time.time() - t0), flush=True)
+            if not (ok and ok2):
+                sys.exit(1)
+            continue
         if kind == "packed":
             # sizes around every kernel boundary: 12 288, 16 384, 20 000, 49 152, 65 536, 131 072
             base = int(rng.choice([2, 64, 130, 1000, 5008, 12288, 16384, 20000, 32768, 49152, 65534, 65536, 70002, 131072, 140000]))
