@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--block-len", type=int, default=8192)
     ap.add_argument("--maf", type=float, default=0.001)
     ap.add_argument("--seed", type=int, default=None)
-    ap.add_argument("--cpu-sample-cells", type=float, default=1.2e9, help="cells of the CPU-oracle baseline sample")
+    ap.add_argument("--cpu-sample-cells", type=float, default=3.2e9, help="cells of the CPU-oracle baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the block-parallel CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
