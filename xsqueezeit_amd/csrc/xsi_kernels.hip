@@ -1,9 +1,9 @@
 // xsi_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the xSqueezeIt genotype-block codec.
 //
 // Encode: count -> classify (WAH vs sparse, per-block scans) -> PBWT chain -> WAH16 sizing / writing
-// (unit encoder: one wave per four lines up to 8 KiB rows, one workgroup per line above; the serial one-wave
-// encoder for very short rows) -> sparse lists (one wave per line, on the side stream) -> block layout +
-// dictionary.  The chain is the dominant kernel.  The element-major forms live in xsi_rankenc.hip
+// (unit encoder: several lines per wave for rows of at most 32 units, one wave per four lines up to 8 KiB rows,
+// one workgroup per line above; the serial one-wave encoder only where a caller asks for no scratch copy of short
+// rows) -> sparse lists (one wave per line, on the side stream) -> block layout + dictionary.  The chain is the dominant kernel.  The element-major forms live in xsi_rankenc.hip
 // (k_chain_rank_enc up to 65 536 haplotypes, k_chain_rank_enc_multi up to 524 288); here are the position-major ones:
 //   k_chain_lds     prefix array `a` in LDS, bit columns staged through LDS, wave ballot + mbcnt for the
 //                   stable partition; with fewer blocks than CUs a block is cut into line segments and a
