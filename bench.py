@@ -13,6 +13,9 @@ encoded to the .xsi blocks region and decoded back to packed bits.  Workloads (B
                         rank generates its own shard on the device; --sites-fraction scales the total
                         (0.125 on one GPU = the 153-block shard one of 8 GPUs gets).
 
+--gpus N without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself, as children of
+torch.distributed.run, before this process touches the GPU; under a launcher it is rank RANK of WORLD_SIZE.
+
 No data-path collective: blocks are independent.  The path's one exchange step, the gather of the
 compressed block streams to the writer rank over RCCL, runs inside the timed region (overlapped with the
 decode) and is also timed on its own after it (`gather_ms`).  Prints ONE JSON line on rank 0.
@@ -45,6 +48,47 @@ VALU_PER_CHUNK_LINE = {"k_chain_rank_enc": 9.8, "k_chain_decode_rank_wg": 12.9, 
                        "k_chain_rank_enc_multi": 15.0}  # _multi: 9.8 of the main phase + the per-line table build
 
 
+def launch_ranks(n):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <the same arguments>, one rank
+    per GPU; returns its exit code."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch_rank(args, real_stdout):
+    """--dry-launch: what a rank does before and after the GPU work (rendezvous, per-rank report to rank 0, the
+    one JSON line), over gloo and without a device."""
+    import torch
+    import torch.distributed as tdist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    mine = torch.tensor([float(rank), float(os.getpid())], dtype=torch.float64)
+    got = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+    tdist.all_gather(got, mine)
+    tdist.barrier()
+    if rank == 0:
+        out = {"dry_launch": True, "n_gpus": world, "ranks_reported": [int(t[0]) for t in got],
+               "pids": [int(t[1]) for t in got]}
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    tdist.destroy_process_group()
+    return 0
+
+
 def main():
     # Libraries (RCCL prints a version banner) write to stdout; the contract is ONE JSON line there.
     # Park the real stdout and point fd 1 at stderr until the line is ready.
@@ -67,7 +111,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (process group + RCCL gather) even with one rank (testing)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher check without a GPU: the ranks only form a gloo group and report in (CPU test)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # No launcher around us: start the N ranks ourselves, as CHILD processes of torch.distributed.run, before
+        # anything in this process has touched HIP (a process that has initialised the GPU must never exec).
+        # Rank 0 of the children prints the one JSON line to the stdout they inherit.
+        os.dup2(real_stdout, 1)
+        raise SystemExit(launch_ranks(args.gpus))
+    if args.dry_launch:
+        raise SystemExit(dry_launch_rank(args, real_stdout))
     cfg = CONFIGS[args.config]
     custom = args.haps is not None or args.sites is not None
     N = args.haps if args.haps is not None else cfg["haps"]
@@ -160,19 +214,32 @@ def main():
         state["file_len"] = so
         return so
 
+    # the writer rank's buffers for the gathered streams: sized like the per-rank output (every rank has the same
+    # share of the job, +1 block of slack for the rounding of the shards)
+    gat = xdist.RcclGather(ctx, tdist, dev) if distributed else None
+    gat_blocks = (n_blocks + 1) * world
+
+    def exchange():
+        """The path's one exchange step: compressed block streams -> writer rank over RCCL / xGMI, through the
+        library's own communicator (xsi_hip_gather_block_streams).  It runs on the communicator's stream behind the
+        encode and overlaps with the decode that follows (both only read d_out)."""
+        if "gat_cap" not in state:
+            # the writer rank's receive buffer: the sum of the ranks' regions (the same in every step), learnt once
+            t = torch.tensor([int(res.blocks_bytes)], dtype=torch.int64, device=dev)
+            tdist.all_reduce(t)
+            state["gat_cap"] = int(t.item())
+        return gat.gather(d_out, res.blocks_bytes, d_off - 256, state["gat_cap"], gat_blocks)
+
     def step():
         binding.check(L.xsi_hip_encode_packed(ctx.handle, ctypes.byref(p), d_bits.data_ptr(), S, stride,
                                               d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)))
-        handle = None
-        if distributed:
-            # the path's one exchange step: compressed block streams -> writer rank over RCCL/xGMI,
-            # started as soon as the encode is done and overlapped with the decode (both only read d_out)
-            handle = xdist.gather_block_streams_async(d_out, res.blocks_bytes, d_off - 256, tdist, dev)
+        got = exchange() if distributed else None
         flen = make_file_image()
         binding.check(L.xsi_hip_decode_packed(ctx.handle, d_file.data_ptr(), flen, 0, n_blocks, d_dec.data_ptr(),
                                               stride, S, ctypes.byref(rows), None))
-        if handle is not None:
-            state["gathered"] = handle.wait()
+        if got is not None:
+            gat.wait()
+            state["gathered"] = got
 
     def fence():
         torch.cuda.synchronize()
@@ -191,8 +258,12 @@ def main():
     dt = time.perf_counter() - t0
     timing = ctx.timing()
     ctx.set_timing(False)
+    per_rank_ms = [dt / steps * 1e3]
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        every = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        tdist.all_gather(every, t)
+        per_rank_ms = [float(e.item()) / steps * 1e3 for e in every]
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
     gather_ms = None
@@ -200,7 +271,8 @@ def main():
         # the exchange step alone, not overlapped with anything
         fence()
         tg = time.perf_counter()
-        xdist.gather_block_streams_async(d_out, res.blocks_bytes, d_off - 256, tdist, dev).wait()
+        exchange()
+        gat.wait()
         fence()
         gather_ms = (time.perf_counter() - tg) * 1e3
 
@@ -283,6 +355,14 @@ def main():
         }
         if gather_ms is not None:
             out["gather_ms"] = gather_ms
+            out["ms_per_step_per_rank"] = per_rank_ms
+            region_all, offs_all, per_b, per_n = state["gathered"]  # the last timed step's exchange, on the writer rank
+            offs_np = offs_all.cpu().numpy()
+            out["gathered"] = {"ranks": len(per_b), "bytes": int(region_all.numel()), "blocks": int(offs_np.size),
+                               "bytes_per_rank": [int(x) for x in per_b],
+                               "offsets_ascending": bool(np.all(np.diff(offs_np) > 0)) if offs_np.size > 1 else True,
+                               "own_part_equals_encode_output": bool(torch.equal(region_all[:xsi_bytes], d_out[:xsi_bytes])),
+                               "via": "xsi_hip_gather_block_streams (RCCL from libxsi_hip.so)"}
 
     # ---- CPU baseline: the oracle (parity-pinned restatement of the reference), 1 thread ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -365,6 +445,8 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if gat is not None:
+        gat.close()
     ctx.close()
     if distributed:
         tdist.destroy_process_group()

@@ -58,9 +58,15 @@ int xsi_hip_ctx_synchronize(xsi_hip_ctx* ctx);
 /* Bytes of device workspace currently held by the context. */
 uint64_t xsi_hip_ctx_workspace_bytes(const xsi_hip_ctx* ctx);
 
+/* Encode batches this context has run a second time with the one-workgroup-per-block streaming chain because
+ * the launch of the chain that spreads a block over several workgroups (65 536 < haplotypes <= 524 288) was
+ * aborted: its workgroups must all be resident at once, which another process, stream or CU mask can prevent.
+ * The bytes written are the same either way (pbwt_sort, include/internal_gt_record.hpp:32-59). */
+uint64_t xsi_hip_ctx_chain_fallbacks(const xsi_hip_ctx* ctx);
+
 /* Bytes of per-line device workspace one block-level call may hold.  A job that needs more (e.g. 153 blocks
  * of 500 000 haplotypes) is run as several batches of whole blocks inside the call; the bytes written are
- * those of a single pass, since blocks are independent.  0 (default) = 50 % of the HBM that is free at
+ * those of a single pass, since blocks are independent.  0 (default) = 40 % of the HBM that is free at
  * the call; the environment variable XSI_WS_BUDGET_MB overrides the default. */
 int xsi_hip_ctx_set_workspace_budget(xsi_hip_ctx* ctx, uint64_t bytes);
 
@@ -244,6 +250,48 @@ int32_t xsi_default_phased(const int32_t* const* h_gt_rows, const uint32_t* h_ng
 typedef struct xsi_bm_state { uint64_t line, block, offset; } xsi_bm_state;
 void xsi_bm_init(xsi_bm_state* st);
 int64_t xsi_bm_next(xsi_bm_state* st, uint32_t block_len, uint32_t n_allele);
+
+/* ---- multi-GPU: block sharding and the gather of the compressed block streams over RCCL ----
+ * Every 8192-line block is independent (fresh GtBlock with a = iota, include/gt_block.hpp:179-180,
+ * include/xsi_factory.hpp:536-537; the decoder resets `a` per block, include/accessor_internals_new.hpp:144), so
+ * rank r of G runs the block calls above on its own contiguous block range and no collective touches the data
+ * path.  The one exchange step feeds XsiFactoryExt::finalize_file (include/xsi_factory.hpp:543-605) on the writer
+ * rank: every rank's blocks region in rank (= file) order plus the offset of every block.  One process per GPU;
+ * the communicator is RCCL's (librccl.so.1 is bound at run time, a single-GPU user does not need it). */
+typedef struct xsi_hip_comm xsi_hip_comm;
+#define XSI_HIP_COMM_ID_BYTES 128
+/* Contiguous block range [*lo, *hi) of `rank`: block b goes to rank floor(b * world / n_blocks), so the gathered
+ * streams concatenate in file order. */
+void xsi_hip_shard_blocks(uint64_t n_blocks, int world, int rank, uint64_t* lo, uint64_t* hi);
+/* ncclGetUniqueId: made by one rank, handed to the others by whatever the host program has (MPI, a file, a socket). */
+int xsi_hip_comm_unique_id(uint8_t id[XSI_HIP_COMM_ID_BYTES]);
+/* ncclCommInitRank on the context's device; collective over all `world` ranks. */
+int xsi_hip_comm_create(xsi_hip_comm** comm, xsi_hip_ctx* ctx, int world, int rank, const uint8_t id[XSI_HIP_COMM_ID_BYTES]);
+void xsi_hip_comm_destroy(xsi_hip_comm* comm);
+int xsi_hip_comm_world(const xsi_hip_comm* comm);
+int xsi_hip_comm_rank(const xsi_hip_comm* comm);
+/*
+ * Collective.  Every rank passes its blocks region (d_region[0..nbytes), as xsi_hip_encode_* wrote it) and the
+ * offsets of its blocks RELATIVE TO ITS REGION (d_offsets[0..n_blocks); xsi_hip_encode_* returns file offsets of
+ * a single-rank file: subtract 256).  On rank `dst`, d_region_all receives the regions back to back in rank
+ * order and d_offsets_all the offsets of all blocks relative to the start of the concatenated region (file offset
+ * = 256 + that); the other ranks pass NULL / 0 for them.  h_bytes_per_rank / h_blocks_per_rank (optional, `world`
+ * entries) are filled on every rank.  Sizes travel by ncclAllGather, the bytes by grouped ncclSend / ncclRecv of
+ * exactly each rank's size.  The exchange runs on the communicator's own stream, ordered behind everything the
+ * context's stream held at the call (the encode), so work enqueued on the context afterwards (the decode of the
+ * same blocks, the next batch's H2D copies) overlaps with it; the call returns once everything is enqueued (the
+ * size exchange synchronises once).  d_region / d_offsets must stay untouched, and the outputs unread, until
+ * xsi_hip_comm_wait.  XSI_ERR_CAPACITY is returned on EVERY rank, before any byte moves, when the writer rank's
+ * buffers are too small.
+ */
+int xsi_hip_gather_block_streams(xsi_hip_comm* comm, const void* d_region, uint64_t nbytes, const uint64_t* d_offsets,
+                                 uint64_t n_blocks, int dst, void* d_region_all, uint64_t region_capacity,
+                                 uint64_t* d_offsets_all, uint64_t offsets_capacity, uint64_t* h_bytes_per_rank,
+                                 uint64_t* h_blocks_per_rank);
+
+/* Wait for the exchange started last: host != 0 blocks the calling thread, host == 0 makes the context's stream
+ * wait (work enqueued on it afterwards sees the gathered bytes). */
+int xsi_hip_comm_wait(xsi_hip_comm* comm, int host);
 
 /* ---- host-side writer / accessor (file level), mirroring XsiFactoryInterface and Accessor ---- */
 typedef struct xsi_writer xsi_writer;

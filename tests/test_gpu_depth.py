@@ -94,29 +94,31 @@ def test_chain_kernel_variants_at_depth(n_haps, n_blocks, block_len, thr, force,
     assert np.array_equal(out, packed)
 
 
-def test_multi_workgroup_chain_times_out_instead_of_hanging(monkeypatch):
-    """The encode chain over several workgroups per block waits at a counter once per line.  If a workgroup never
-    arrives (here: member 1 of every group leaves before its first meeting) the others give up after a bounded
-    number of polls, raise the abort flag, every workgroup of the launch ends, and the call reports an error."""
+def test_multi_workgroup_chain_falls_back_instead_of_hanging(monkeypatch):
+    """The encode chain over several workgroups per block exchanges rank lists and row slices once per line and
+    needs every workgroup of a block resident at once.  If a workgroup never shows up (here: member 1 of every
+    group leaves at once) the waits of the others run out (bounded by the 100 MHz clock, not by a poll count), the
+    abort flag ends every workgroup of the launch, and the call runs the batch again with the one-workgroup-per-block
+    streaming chain: same bytes as the oracle, and the context counts the fallback."""
     import gpu_util as G
+    L = binding.lib()
     monkeypatch.setenv("XSI_MULTI_TEST_DESERT", "1")
+    monkeypatch.setenv("XSI_MULTI_TIMEOUT_MS", "200")
     n_haps, n_lines = 140000, 24
     bits, packed, stride = _device_synth(n_haps, n_lines, 3)
     p = G.params(n_haps // 2, 8, 140)
-    torch = G.torch_mod()
-    d_bits = G.dev_u8(packed)
-    cap = binding.lib().xsi_hip_encode_bound(ctypes.byref(p), n_lines, n_lines)
-    d_out = G.dev_empty(cap)
-    d_off = torch.zeros(8, dtype=torch.int64, device="cuda")
-    res = binding.EncodeResult()
-    rc = binding.lib().xsi_hip_encode_packed(G.ctx().handle, ctypes.byref(p), d_bits.data_ptr(), n_lines, stride,
-                                             d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res))
-    assert rc == binding.XSI_ERR_HIP
-    assert b"failed to meet" in binding.lib().xsi_hip_last_error()
-    # the context is usable afterwards
-    monkeypatch.delenv("XSI_MULTI_TEST_DESERT")
+    before = L.xsi_hip_ctx_chain_fallbacks(G.ctx().handle)
     region, offsets, res = G.encode_packed(packed, n_haps, p)
+    assert L.xsi_hip_ctx_chain_fallbacks(G.ctx().handle) == before + 1
     assert res.n_blocks == 3
+    names = ["S%d" % i for i in range(n_haps // 2)]
+    got = G.assemble_file(region, offsets, p, n_lines, n_lines, names)
+    assert got == G.oracle_file_from_bits(bits, p)
+    # and without the desertion the same call takes the multi-workgroup chain, no fallback
+    monkeypatch.delenv("XSI_MULTI_TEST_DESERT")
+    region2, offsets2, res2 = G.encode_packed(packed, n_haps, p)
+    assert L.xsi_hip_ctx_chain_fallbacks(G.ctx().handle) == before + 1
+    assert bytes(region2) == bytes(region)
 
 
 def test_phased_decode_with_a_short_last_block(monkeypatch):

@@ -1,0 +1,87 @@
+"""Multi-GPU layer on the GPU box (one rank: the box has one GPU): the C-ABI shard / gather over RCCL
+(include/xsi_hip.h "multi-GPU") on GPU-encoded blocks, and bench.py's multi-rank code path with --force-dist."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from xsqueezeit_amd import binding, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True)
+def _torch_first():
+    import gpu_util as G
+    G.ctx()
+
+
+def test_c_abi_gather_world_one_on_gpu_encoded_blocks():
+    """xsi_hip_comm_create (ncclCommInitRank, world 1) + xsi_hip_gather_block_streams on what the GPU encoder wrote:
+    the writer rank's image must be the encoder's region, its offsets the encoder's file offsets - 256; a writer
+    buffer that is too small must fail with XSI_ERR_CAPACITY before any byte moves."""
+    import gpu_util as G
+    torch = G.torch_mod()
+    L = binding.lib()
+    n_haps, n_lines, bl = 5008, 3000, 512
+    bits = synth.synth_bits(9, 0, n_lines, n_haps)
+    stride = synth.row_stride_bytes(n_haps)
+    packed = synth.pack_rows(bits, stride)
+    p = G.params(n_haps // 2, bl, 5)
+    region, offsets, res = G.encode_packed(packed, n_haps, p)
+    n_blocks = len(offsets)
+    d_region = G.dev_u8(np.frombuffer(region, dtype=np.uint8))
+    d_offs = torch.from_numpy((offsets.astype(np.int64) - 256)).cuda()
+    idb = (ctypes.c_uint8 * 128)()
+    binding.check(L.xsi_hip_comm_unique_id(idb))
+    comm = ctypes.c_void_p()
+    binding.check(L.xsi_hip_comm_create(ctypes.byref(comm), G.ctx().handle, 1, 0, idb))
+    try:
+        assert L.xsi_hip_comm_world(comm) == 1 and L.xsi_hip_comm_rank(comm) == 0
+        d_all = G.dev_empty(len(region) + 64)
+        d_oall = torch.zeros(n_blocks, dtype=torch.int64, device="cuda")
+        per_b = (ctypes.c_uint64 * 1)()
+        per_n = (ctypes.c_uint64 * 1)()
+        binding.check(L.xsi_hip_gather_block_streams(comm, d_region.data_ptr(), len(region), d_offs.data_ptr(), n_blocks, 0,
+                                                     d_all.data_ptr(), d_all.numel(), d_oall.data_ptr(), n_blocks, per_b, per_n))
+        binding.check(L.xsi_hip_comm_wait(comm, 1))
+        assert per_b[0] == len(region) and per_n[0] == n_blocks
+        assert d_all[:len(region)].cpu().numpy().tobytes() == region
+        assert np.array_equal(d_oall.cpu().numpy().astype(np.uint64) + 256, offsets)
+        rc = L.xsi_hip_gather_block_streams(comm, d_region.data_ptr(), len(region), d_offs.data_ptr(), n_blocks, 0,
+                                            d_all.data_ptr(), len(region) - 1, d_oall.data_ptr(), n_blocks, per_b, per_n)
+        assert rc == binding.XSI_ERR_CAPACITY
+        # the file a writer rank assembles from the gathered image equals the oracle's
+        names = ["S%d" % i for i in range(n_haps // 2)]
+        got = G.assemble_file(d_all[:len(region)].cpu().numpy().tobytes(), d_oall.cpu().numpy().astype(np.uint64) + 256, p,
+                              n_lines, n_lines, names)
+        assert got == G.oracle_file_from_bits(bits, p, names)
+    finally:
+        L.xsi_hip_comm_destroy(comm)
+    lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+    L.xsi_hip_shard_blocks(1221, 8, 3, ctypes.byref(lo), ctypes.byref(hi))
+    assert (lo.value, hi.value) == (458, 611)
+
+
+def test_bench_multi_rank_path_with_one_rank():
+    """bench.py --force-dist: process group (nccl), the C-ABI gather inside the timed region and alone, the
+    per-rank report - on blocks the GPU encoded in this run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MASTER_PORT"] = "29577"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--config", "1",
+                        "--sites", "40000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["roundtrip_equal"] and out["n_gpus"] == 1
+    assert out["gather_ms"] > 0 and len(out["ms_per_step_per_rank"]) == 1
+    g = out["gathered"]
+    assert g["ranks"] == 1 and g["own_part_equals_encode_output"] and g["offsets_ascending"]
+    assert g["bytes"] == out["config"]["xsi_bytes_this_gpu"] and g["blocks"] == out["config"]["blocks_this_gpu"]

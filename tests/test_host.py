@@ -288,3 +288,21 @@ def test_file_num_samples_without_a_device(tmp_path):
     (tmp_path / "bad.xsi").write_bytes(b"\0" * 300)
     assert binding.lib().xsi_file_num_samples(str(tmp_path / "bad.xsi").encode()) == -4
     assert binding.lib().xsi_file_num_samples(str(tmp_path / "missing.xsi").encode()) == -6
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (children of
+    torch.distributed.run, started before the parent touches HIP) and print ONE JSON line from rank 0.
+    --dry-launch keeps the ranks off the GPU: rendezvous over gloo, every rank reports in."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_reported"] == [0, 1]
+    assert len(set(out["pids"])) == 2 and os.getpid() not in out["pids"]

@@ -52,7 +52,9 @@ SYMBOLS = [
     "xsi_accessor_set_cache_bytes", "xsi_accessor_cache_stats", "xsi_file_num_samples", "xsi_hip_decode_dot", "xsi_hip_decode_dot_gt",
     "xsi_hip_ctx_set_workspace_budget", "xsi_hip_chain_kernel", "xsi_mac_threshold", "xsi_default_phased",
     "xsi_bm_init", "xsi_bm_next", "xsi_accessor_set_sample_subset", "xsi_accessor_fill_selected_genotypes",
-    "xsi_hip_reencode",
+    "xsi_hip_reencode", "xsi_hip_ctx_chain_fallbacks",
+    "xsi_hip_shard_blocks", "xsi_hip_comm_unique_id", "xsi_hip_comm_create", "xsi_hip_comm_destroy",
+    "xsi_hip_comm_world", "xsi_hip_comm_rank", "xsi_hip_gather_block_streams", "xsi_hip_comm_wait",
 ]
 
 
@@ -97,6 +99,24 @@ def lib():
     L.xsi_hip_ctx_synchronize.argtypes = [vp]
     L.xsi_hip_ctx_workspace_bytes.restype = u64
     L.xsi_hip_ctx_workspace_bytes.argtypes = [vp]
+    L.xsi_hip_shard_blocks.restype = None
+    L.xsi_hip_shard_blocks.argtypes = [u64, c.c_int, c.c_int, c.POINTER(u64), c.POINTER(u64)]
+    L.xsi_hip_comm_unique_id.restype = c.c_int
+    L.xsi_hip_comm_unique_id.argtypes = [vp]
+    L.xsi_hip_comm_create.restype = c.c_int
+    L.xsi_hip_comm_create.argtypes = [c.POINTER(vp), vp, c.c_int, c.c_int, vp]
+    L.xsi_hip_comm_destroy.restype = None
+    L.xsi_hip_comm_destroy.argtypes = [vp]
+    L.xsi_hip_comm_world.restype = c.c_int
+    L.xsi_hip_comm_world.argtypes = [vp]
+    L.xsi_hip_comm_rank.restype = c.c_int
+    L.xsi_hip_comm_rank.argtypes = [vp]
+    L.xsi_hip_comm_wait.restype = c.c_int
+    L.xsi_hip_comm_wait.argtypes = [vp, c.c_int]
+    L.xsi_hip_gather_block_streams.restype = c.c_int
+    L.xsi_hip_gather_block_streams.argtypes = [vp, vp, u64, vp, u64, c.c_int, vp, u64, vp, u64, vp, vp]
+    L.xsi_hip_ctx_chain_fallbacks.restype = u64
+    L.xsi_hip_ctx_chain_fallbacks.argtypes = [vp]
     L.xsi_hip_ctx_set_timing.restype = c.c_int
     L.xsi_hip_ctx_set_timing.argtypes = [vp, c.c_int]
     L.xsi_hip_ctx_get_timing.restype = c.c_int

@@ -116,6 +116,8 @@ uint64_t xsi_hip_ctx_workspace_bytes(const xsi_hip_ctx* c) {
     return t;
 }
 
+uint64_t xsi_hip_ctx_chain_fallbacks(const xsi_hip_ctx* c) { return c ? c->chain_fallbacks : 0; }
+
 int xsi_hip_ctx_set_workspace_budget(xsi_hip_ctx* c, uint64_t bytes) {
     if (!c) return set_error(XSI_ERR_ARG, "null context");
     c->ws_budget = bytes;
@@ -301,6 +303,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     const uint32_t n_blocks = (uint32_t)blocks_h.size();
     const uint32_t n_bin = L.n_bin;
     const uint32_t N = L.N;
+    const EncLines L_in = L;  // as the caller made it: what a second run after an aborted chain launch starts from
 
     EncBlock* d_blocks;
     WS(d_blocks, "enc.blocks", sizeof(EncBlock) * (size_t)n_blocks);
@@ -314,8 +317,9 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     const size_t y_rows = L.y_rows ? L.y_rows : n_bin;  // one per WAH line: exact when the caller counted them
     WS(L.yrows, "enc.yrows", 8ull * L.y_stride64 * y_rows);
     if (N > 65536u && N <= 524288u) {  // the chain over several workgroups per block
-        WS(L.chain_sync, "enc.chain_sync", 4ull * (CHAIN_SYNC_WORDS + CHAIN_MAX_WGS * 2u * 16u));
+        WS(L.chain_sync, "enc.chain_sync", 4ull * CHAIN_SYNC_TOTAL_WORDS);
         WS(L.chain_lists, "enc.chain_lists", 4ull * CHAIN_LIST_WORDS);
+        WS(L.chain_slices, "enc.chain_slices", CHAIN_SLICE_BYTES);
     }
     // WAH16 words per line, worst case ceil(N/15) (+1 for the saturation split): encode once, then copy
     L.wah_scratch_stride = ((N + 14u) / 15u + 3u) & ~1u;  // even: rows stay 4-byte aligned for k_wah_write
@@ -378,11 +382,29 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     stage_mark(ctx, -1);
     uint64_t res[5];
     uint32_t chain_abort = 0;
+    uint64_t chain_prof[8] = {0};  // [0] abort word (+ pad), [1..7] phase ticks of workgroup 0 (XSI_MULTI_PROF)
     HIP_TRY(hipMemcpyAsync(res, d_result, sizeof(res), hipMemcpyDeviceToHost, s));
-    if (chain_rank_enc_multi_supported(L)) HIP_TRY(hipMemcpyAsync(&chain_abort, L.chain_sync, 4, hipMemcpyDeviceToHost, s));
+    if (chain_rank_enc_multi_supported(L)) HIP_TRY(hipMemcpyAsync(chain_prof, L.chain_sync, sizeof(chain_prof), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    chain_abort = (uint32_t)chain_prof[0];
+    if (chain_rank_enc_multi_supported(L) && getenv("XSI_MULTI_PROF")) {
+        static const char* nm[7] = {"main+publish", "barrier+wait lists", "apply lists", "barrier", "slice scan+store+flag", "wait slices", "table copy"};
+        uint64_t tot = 0;
+        for (int i = 1; i < 8; ++i) tot += chain_prof[i];
+        for (int i = 1; i < 8; ++i)
+            fprintf(stderr, "[xsi multi prof] %-24s %9.3f ms  %5.1f %%\n", nm[i - 1], chain_prof[i] * 1e-5, tot ? 100.0 * chain_prof[i] / tot : 0.0);
+    }
     stage_collect(ctx);
-    if (chain_abort) return set_error(XSI_ERR_HIP, "encode: the workgroups of a block failed to meet (chain over several workgroups)");
+    if (chain_abort) {
+        // The workgroups of a block did not all become resident (another process or stream holds CUs) and a wait
+        // ran out: every workgroup has left, the output is incomplete.  Run the batch again, in this call, with the
+        // one-workgroup-per-block streaming chain, which needs no co-residency.
+        if (L_in.no_multi) return set_error(XSI_ERR_HIP, "encode: chain launch aborted");
+        EncLines L2 = L_in;
+        L2.no_multi = 1u;
+        ctx->chain_fallbacks++;
+        return encode_run(ctx, p, L2, S, blocks_h, d_out, out_capacity, d_block_offsets, h_result, region_offset, use_wah_scratch);
+    }
     if (res[3]) return set_error(XSI_ERR_CAPACITY, "encode: output needs %llu bytes, capacity is %llu",
                                  (unsigned long long)res[0], (unsigned long long)out_capacity);
     if (h_result) {

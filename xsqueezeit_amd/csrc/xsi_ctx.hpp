@@ -56,6 +56,7 @@ struct xsi_hip_ctx {
     size_t ev_used = 0;
     double stage_ms[XSI_STAGE_COUNT] = {0};
     uint64_t stage_n[XSI_STAGE_COUNT] = {0};
+    uint64_t chain_fallbacks = 0;     // encode batches run again with the streaming chain after an aborted launch
 };
 
 struct xsi_encode_params;

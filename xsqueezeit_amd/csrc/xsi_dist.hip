@@ -1,0 +1,239 @@
+// xsi_dist.hip — multi-GPU at the C ABI: block sharding and the gather of the compressed block streams to the
+// writer rank over RCCL (xGMI inside a node).
+//
+// Blocks are independent (a fresh GtBlock with a = iota per block, gt_block.hpp:179-180, xsi_factory.hpp:536-537;
+// the decoder resets `a` per block, accessor_internals_new.hpp:144), so the path shards with no data-path
+// collective: rank r of G owns a contiguous block range and runs xsi_hip_encode_* / xsi_hip_decode_* on it.  The
+// one exchange step is what XsiFactoryExt::finalize_file (xsi_factory.hpp:543-605) needs on the writer rank: every
+// rank's blocks region, in rank (= file) order, and the offset of every block.  Sizes travel first (ncclAllGather
+// of four u64 per rank), then exactly each rank's bytes (grouped ncclSend / ncclRecv), on the communicator's own
+// stream, ordered behind what the context's stream held at the call: the caller's next work overlaps with it.
+//
+// librccl is bound at run time (dlopen of librccl.so.1): a single-GPU user needs no RCCL, and a process that has
+// already loaded its own RCCL (PyTorch) gets that same library by its soname.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/xsi_hip.h"
+#include "xsi_ctx.hpp"
+
+using namespace xsi;
+
+namespace {
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+const RcclApi& rccl() {
+    static RcclApi r = [] {
+        RcclApi a;
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return a;
+#define XSI_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name))
+        XSI_SYM(GetUniqueId, "ncclGetUniqueId");
+        XSI_SYM(CommInitRank, "ncclCommInitRank");
+        XSI_SYM(CommDestroy, "ncclCommDestroy");
+        XSI_SYM(AllGather, "ncclAllGather");
+        XSI_SYM(Send, "ncclSend");
+        XSI_SYM(Recv, "ncclRecv");
+        XSI_SYM(GroupStart, "ncclGroupStart");
+        XSI_SYM(GroupEnd, "ncclGroupEnd");
+        XSI_SYM(GetErrorString, "ncclGetErrorString");
+#undef XSI_SYM
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.Send && a.Recv && a.GroupStart &&
+               a.GroupEnd && a.GetErrorString;
+        return a;
+    }();
+    return r;
+}
+
+#define NCCL_TRY(expr)                                                                                           \
+    do {                                                                                                         \
+        ncclResult_t _r = (expr);                                                                                \
+        if (_r != ncclSuccess) return set_error(XSI_ERR_HIP, "%s: %s", #expr, rccl().GetErrorString(_r));        \
+    } while (0)
+#define HIP_TRY(expr)                                                                                             \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess) return set_error(XSI_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                                               __LINE__);                                                         \
+    } while (0)
+
+// offsets of a rank's blocks, relative to its own region -> relative to the concatenated region
+__global__ void k_rebase_offsets(uint64_t* offs, uint64_t n, uint64_t base) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) offs[i] += base;
+}
+}  // namespace
+
+struct xsi_hip_comm {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+    xsi_hip_ctx* ctx = nullptr;
+    hipStream_t cs = nullptr;    // the exchange runs here, ordered behind the context's stream by ev_in, so that
+    hipEvent_t ev_in = nullptr, ev_done = nullptr;  // work the caller enqueues next (the decode) overlaps with it
+    uint64_t* d_meta = nullptr;  // [world + 1][4]: every rank's {bytes, blocks, region capacity, offsets capacity}; the last is this rank's (send buffer)
+};
+
+extern "C" {
+
+void xsi_hip_shard_blocks(uint64_t n_blocks, int world, int rank, uint64_t* lo, uint64_t* hi) {
+    if (world < 1) world = 1;
+    if (rank < 0) rank = 0;
+    if (lo) *lo = ((uint64_t)rank * n_blocks + (uint64_t)world - 1u) / (uint64_t)world;
+    if (hi) *hi = ((uint64_t)(rank + 1) * n_blocks + (uint64_t)world - 1u) / (uint64_t)world;
+}
+
+int xsi_hip_comm_unique_id(uint8_t id[XSI_HIP_COMM_ID_BYTES]) {
+    if (!id) return set_error(XSI_ERR_ARG, "comm_unique_id: null id");
+    if (!rccl().ok) return set_error(XSI_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");
+    static_assert(sizeof(ncclUniqueId) == XSI_HIP_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    NCCL_TRY(rccl().GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return XSI_OK;
+}
+
+int xsi_hip_comm_create(xsi_hip_comm** out, xsi_hip_ctx* ctx, int world, int rank, const uint8_t id[XSI_HIP_COMM_ID_BYTES]) {
+    if (!out || !ctx || !id || world < 1 || rank < 0 || rank >= world) return set_error(XSI_ERR_ARG, "comm_create: bad argument");
+    if (!rccl().ok) return set_error(XSI_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");
+    HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    xsi_hip_comm* c = new (std::nothrow) xsi_hip_comm();
+    if (!c) return set_error(XSI_ERR_ARG, "comm_create: out of memory");
+    ncclResult_t r = rccl().CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return set_error(XSI_ERR_HIP, "ncclCommInitRank: %s", rccl().GetErrorString(r));
+    }
+    c->world = world;
+    c->rank = rank;
+    c->ctx = ctx;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->d_meta), 32ull * ((size_t)world + 1u));
+    if (e != hipSuccess) {
+        rccl().CommDestroy(c->comm);
+        delete c;
+        return set_error(XSI_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    if (hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) {
+        xsi_hip_comm_destroy(c);
+        return set_error(XSI_ERR_HIP, "comm_create: stream / events could not be created");
+    }
+    *out = c;
+    return XSI_OK;
+}
+
+void xsi_hip_comm_destroy(xsi_hip_comm* c) {
+    if (!c) return;
+    if (c->cs) (void)hipStreamSynchronize(c->cs);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->cs) (void)hipStreamDestroy(c->cs);
+    if (c->d_meta) (void)hipFree(c->d_meta);
+    if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
+    delete c;
+}
+
+int xsi_hip_comm_world(const xsi_hip_comm* c) { return c ? c->world : 0; }
+int xsi_hip_comm_rank(const xsi_hip_comm* c) { return c ? c->rank : -1; }
+
+int xsi_hip_gather_block_streams(xsi_hip_comm* c, const void* d_region, uint64_t nbytes, const uint64_t* d_offsets,
+                                 uint64_t n_blocks, int dst, void* d_region_all, uint64_t region_capacity,
+                                 uint64_t* d_offsets_all, uint64_t offsets_capacity, uint64_t* h_bytes_per_rank,
+                                 uint64_t* h_blocks_per_rank) {
+    if (!c || dst < 0 || dst >= c->world) return set_error(XSI_ERR_ARG, "gather_block_streams: bad communicator / dst");
+    if ((nbytes && !d_region) || (n_blocks && !d_offsets)) return set_error(XSI_ERR_ARG, "gather_block_streams: null input");
+    const RcclApi& R = rccl();
+    hipStream_t s = c->cs;
+    const int W = c->world, me = c->rank;
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    HIP_TRY(hipEventRecord(c->ev_in, c->ctx->stream));  // everything the caller has enqueued so far (the encode) comes first
+    HIP_TRY(hipStreamWaitEvent(s, c->ev_in, 0));
+    // 1. sizes: every rank's bytes and blocks, and (from the writer rank) the capacities of its output buffers, so
+    //    that all ranks reach the same verdict before anybody sends
+    if (!d_region_all) region_capacity = 0;  // a writer rank without buffers fails the capacity check on every rank
+    if (!d_offsets_all) offsets_capacity = 0;
+    const uint64_t mine[4] = {nbytes, n_blocks, region_capacity, offsets_capacity};
+    HIP_TRY(hipMemcpyAsync(c->d_meta + 4u * (size_t)W, mine, 32, hipMemcpyHostToDevice, s));
+    NCCL_TRY(R.AllGather(c->d_meta + 4u * (size_t)W, c->d_meta, 4, ncclUint64, c->comm, s));
+    std::vector<uint64_t> meta4(4u * (size_t)W);
+    HIP_TRY(hipMemcpyAsync(meta4.data(), c->d_meta, 32ull * (size_t)W, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<uint64_t> meta(2u * (size_t)W);
+    uint64_t tot_b = 0, tot_n = 0;
+    for (int r = 0; r < W; ++r) {
+        meta[2u * r] = meta4[4u * r];
+        meta[2u * r + 1u] = meta4[4u * r + 1u];
+        if (h_bytes_per_rank) h_bytes_per_rank[r] = meta[2u * r];
+        if (h_blocks_per_rank) h_blocks_per_rank[r] = meta[2u * r + 1u];
+        tot_b += meta[2u * r];
+        tot_n += meta[2u * r + 1u];
+    }
+    if (tot_b > meta4[4u * dst + 2u] || tot_n > meta4[4u * dst + 3u])
+        return set_error(XSI_ERR_CAPACITY, "gather_block_streams: %llu bytes / %llu blocks, the writer rank's capacity is %llu / %llu",
+                         (unsigned long long)tot_b, (unsigned long long)tot_n, (unsigned long long)meta4[4u * dst + 2u],
+                         (unsigned long long)meta4[4u * dst + 3u]);
+    // 2. exactly each rank's bytes and offsets to the writer rank (no padding to the longest region)
+    NCCL_TRY(R.GroupStart());
+    if (me == dst) {
+        uint64_t bb = 0, bn = 0;
+        for (int r = 0; r < W; ++r) {
+            const uint64_t b = meta[2u * r], n = meta[2u * r + 1u];
+            if (r != me) {
+                if (b) NCCL_TRY(R.Recv(static_cast<uint8_t*>(d_region_all) + bb, b, ncclUint8, r, c->comm, s));
+                if (n) NCCL_TRY(R.Recv(d_offsets_all + bn, n, ncclUint64, r, c->comm, s));
+            }
+            bb += b;
+            bn += n;
+        }
+    } else {
+        if (nbytes) NCCL_TRY(R.Send(d_region, nbytes, ncclUint8, dst, c->comm, s));
+        if (n_blocks) NCCL_TRY(R.Send(d_offsets, n_blocks, ncclUint64, dst, c->comm, s));
+    }
+    NCCL_TRY(R.GroupEnd());
+    if (me == dst) {
+        uint64_t bb = 0, bn = 0;
+        for (int r = 0; r < W; ++r) {
+            const uint64_t b = meta[2u * r], n = meta[2u * r + 1u];
+            if (r == me) {
+                if (b) HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(d_region_all) + bb, d_region, b, hipMemcpyDeviceToDevice, s));
+                if (n) HIP_TRY(hipMemcpyAsync(d_offsets_all + bn, d_offsets, 8ull * n, hipMemcpyDeviceToDevice, s));
+            }
+            if (n && bb) {
+                k_rebase_offsets<<<dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, s>>>(d_offsets_all + bn, n, bb);
+                HIP_TRY(hipGetLastError());
+            }
+            bb += b;
+            bn += n;
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev_done, s));
+    return XSI_OK;
+}
+
+int xsi_hip_comm_wait(xsi_hip_comm* c, int host) {
+    if (!c) return set_error(XSI_ERR_ARG, "comm_wait: null communicator");
+    if (host)
+        HIP_TRY(hipEventSynchronize(c->ev_done));
+    else
+        HIP_TRY(hipStreamWaitEvent(c->ctx->stream, c->ev_done, 0));
+    return XSI_OK;
+}
+
+}  // extern "C"

@@ -1406,8 +1406,14 @@ hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n
     bool rank_done = false;
     if (chain_rank_enc_multi_supported(L)) {
         hipError_t e = launch_rank_encode_multi(s, blocks, n_blocks, L);
-        if (e != hipSuccess || !any_haploid) return e;
-        rank_done = true;  // k_chain_global below only takes the blocks with fully haploid lines
+        if (e == hipErrorInvalidValue) {
+            // the device (or the CU mask of this process) cannot hold a whole group of workgroups:
+            // k_chain_stream below takes the blocks
+            (void)hipGetLastError();
+        } else {
+            if (e != hipSuccess || !any_haploid) return e;
+            rank_done = true;  // k_chain_global below only takes the blocks with fully haploid lines
+        }
     } else if (use_rank_encode(L.N, n_blocks)) {
         hipError_t e = launch_rank_encode(s, blocks, n_blocks, L);
         if (e != hipSuccess || !any_haploid) return e;

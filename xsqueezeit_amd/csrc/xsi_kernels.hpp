@@ -37,8 +37,12 @@ struct EncLines {
     // chain over several workgroups per block (N > 65536), nullptr = not available to this call:
     // chain_sync  [0] abort flag, [16 + g] arrivals of group g, [CHAIN_SYNC_WORDS ..] list counts
     // chain_lists per-wave rank lists, CHAIN_LIST_WORDS words
+    // chain_slices the members' finished table slices (owner-computes exchange), CHAIN_SLICE_BYTES
+    // no_multi    this call must not use that chain (it is being run again after an aborted launch)
     uint32_t* chain_sync;
     uint32_t* chain_lists;
+    void* chain_slices;
+    uint32_t no_multi;
     uint16_t* wah_scratch;      // [rank][wah_scratch_stride] WAH16 words of each line (encoded once, copied to place)
     uint32_t wah_scratch_stride;
     uint32_t* flagbits;         // [n_blocks][FV_COUNT][MAX_BIN_PER_BLOCK/32] packed flag vectors
@@ -176,6 +180,11 @@ hipError_t launch_rank_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_
 constexpr uint32_t CHAIN_SYNC_WORDS = 16u + 256u;
 constexpr uint32_t CHAIN_MAX_WGS = 256u;  // workgroups of the launch (one per CU)
 constexpr uint64_t CHAIN_LIST_WORDS = (uint64_t)CHAIN_MAX_WGS * 2u * 16u * 4096u;
+constexpr uint32_t CHAIN_LISTFLAG_WORDS = CHAIN_MAX_WGS * 2u * 16u * 2u;  // 8 bytes per wave and parity
+constexpr uint32_t CHAIN_SLICEFLAG_WORDS = CHAIN_MAX_WGS * 2u * 16u * 2u;  // 8 bytes per wave and parity
+constexpr uint32_t CHAIN_XCC_WORDS = (CHAIN_MAX_WGS / 2u) * 8u;
+constexpr uint32_t CHAIN_SYNC_TOTAL_WORDS = CHAIN_SYNC_WORDS + CHAIN_LISTFLAG_WORDS + CHAIN_SLICEFLAG_WORDS + CHAIN_XCC_WORDS;
+constexpr uint64_t CHAIN_SLICE_BYTES = (uint64_t)CHAIN_MAX_WGS * 2u * 16384u;
 bool chain_rank_enc_multi_supported(const EncLines& L);
 hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L);
 

@@ -6,8 +6,13 @@ is the gather of the compressed block streams to the writer rank: sizes first (t
 then point-to-point sends of exactly each rank's bytes (RCCL grouped send/recv over xGMI).  The cheaper
 alternative, exchanging only the sizes and letting every rank pwrite its own byte range, is
 exchange_region_offsets + write_own_range.
-Works on any torch.distributed backend (RCCL on the GPUs, gloo in the CPU tests).
+The functions taking `dist` work on any torch.distributed backend (gloo in the CPU tests).  On the GPUs the
+product path is the C ABI (`xsi_hip_shard_blocks`, `xsi_hip_comm_*`, `xsi_hip_gather_block_streams`: RCCL called
+from libxsi_hip.so, which is what a C++ host binds); `RcclGather` below drives it from Python and only borrows
+torch.distributed to hand the ncclUniqueId to the other ranks.
 """
+import ctypes
+
 import numpy as np
 
 
@@ -17,6 +22,64 @@ def shard_blocks(n_blocks, world_size, rank):
     lo = (rank * n_blocks + world_size - 1) // world_size
     hi = ((rank + 1) * n_blocks + world_size - 1) // world_size
     return lo, hi
+
+
+class RcclGather:
+    """The writer-rank gather through libxsi_hip.so's own RCCL communicator (include/xsi_hip.h, "multi-GPU").
+
+    ctx: binding.Context of this rank; tdist: an initialised torch.distributed (any backend), used once, to
+    broadcast the ncclUniqueId rank 0 makes.  gather() starts the exchange (own stream, behind the encode) and returns
+    (region_all, offsets_all, bytes_per_rank, blocks_per_rank) on `dst` - views of buffers this object owns and
+    reuses, valid after wait() - and (None, None, bytes_per_rank, blocks_per_rank) elsewhere."""
+
+    def __init__(self, ctx, tdist, device):
+        import torch
+        from . import binding
+        self._b = binding
+        self._L = binding.lib()
+        self.world = tdist.get_world_size()
+        self.rank = tdist.get_rank()
+        self.device = device
+        idbuf = (ctypes.c_uint8 * 128)()
+        if self.rank == 0:
+            binding.check(self._L.xsi_hip_comm_unique_id(idbuf))
+        t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=device if tdist.get_backend() == "nccl" else "cpu")
+        tdist.broadcast(t, 0)
+        idbuf = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
+        self.handle = ctypes.c_void_p()
+        binding.check(self._L.xsi_hip_comm_create(ctypes.byref(self.handle), ctx.handle, self.world, self.rank, idbuf))
+        self._region = self._offs = None
+
+    def gather(self, backing, nbytes, block_offsets_rel, region_capacity, blocks_capacity, dst=0):
+        import torch
+        if self.rank == dst:
+            if self._region is None or self._region.numel() < region_capacity:
+                self._region = torch.empty(max(int(region_capacity), 1), dtype=torch.uint8, device=self.device)
+            if self._offs is None or self._offs.numel() < blocks_capacity:
+                self._offs = torch.empty(max(int(blocks_capacity), 1), dtype=torch.int64, device=self.device)
+        offs = block_offsets_rel.to(torch.int64).contiguous()
+        per_b = (ctypes.c_uint64 * self.world)()
+        per_n = (ctypes.c_uint64 * self.world)()
+        on_dst = self.rank == dst
+        self._b.check(self._L.xsi_hip_gather_block_streams(
+            self.handle, backing.data_ptr(), int(nbytes), offs.data_ptr() if offs.numel() else None, offs.numel(), dst,
+            self._region.data_ptr() if on_dst else None, self._region.numel() if on_dst else 0,
+            self._offs.data_ptr() if on_dst else None, self._offs.numel() if on_dst else 0, per_b, per_n))
+        self._keep = (backing, offs)  # the sends read them until the stream has run
+        per_b, per_n = list(per_b), list(per_n)
+        if not on_dst:
+            return None, None, per_b, per_n
+        return self._region[:sum(per_b)], self._offs[:sum(per_n)], per_b, per_n
+
+    def wait(self, host=True):
+        """Block until the exchange started last is complete (host=False: make the context's stream wait instead)."""
+        self._b.check(self._L.xsi_hip_comm_wait(self.handle, 1 if host else 0))
+        self._keep = None
+
+    def close(self):
+        if self.handle:
+            self._L.xsi_hip_comm_destroy(self.handle)
+            self.handle = None
 
 
 class _GatherHandle:
@@ -47,7 +110,8 @@ def gather_block_streams_async(backing, nbytes, block_offsets, dist, device=None
     and per-rank int64 offsets relative to the start of the concatenated region; None elsewhere.
     One size all-gather, then point-to-point sends of exactly the bytes each rank has (no padding to the
     longest region), issued asynchronously so the caller can overlap them with work that only reads
-    `backing`.  The receive buffers are reused across calls."""
+    `backing`.  The receive buffers are reused across calls; the writer rank's own part is a VIEW of its
+    `backing` (no copy): consume or copy it before the next encode overwrites that buffer."""
     import torch
     world = dist.get_world_size()
     rank = dist.get_rank()
@@ -59,6 +123,8 @@ def gather_block_streams_async(backing, nbytes, block_offsets, dist, device=None
     nblk = [int(m[1]) for m in metas]
     if backing.numel() < sizes[rank]:
         raise ValueError("backing buffer (%d bytes) shorter than its region (%d)" % (backing.numel(), sizes[rank]))
+    if sizes[rank] == 0 and backing.numel() == 0:
+        backing = torch.zeros(1, dtype=torch.uint8, device=device)  # a rank without blocks still posts a 1-byte send
     send = backing[:max(sizes[rank], 1)]
     offs = block_offsets.to(torch.int64).contiguous() if block_offsets.numel() else torch.zeros(1, dtype=torch.int64, device=device)
     bufs = obufs = None
