@@ -8,6 +8,8 @@ encoded to the .xsi blocks region and decoded back to packed bits.  Workloads (B
                         encode+decode configuration and the one BASELINE.json quotes the roofline on.
                         N > 1: every rank runs the same shape on its own site range (weak scaling).
   --config 1            5008 hap x 1 000 000 sites, MAC threshold 5, seed 42 (weak scaling).
+  --config 4            decode-only random access through Accessor::get_genotypes on a mixed-ploidy, multi-allelic
+                        200 000-haplotype file (run_config4).
   --config 3            500 000 hap x 10 000 000 sites IN TOTAL (1221 blocks of 8192 lines), seed 44: the
                         blocks are sharded over the ranks with dist.shard_blocks (strong scaling), every
                         rank generates its own shard on the device; --sites-fraction scales the total
@@ -37,6 +39,7 @@ CONFIGS = {
     1: dict(haps=5008, sites=1_000_000, seed=42, scaling="weak", name="BASELINE.json configs[1]"),
     2: dict(haps=64976, sites=2_000_000, seed=43, scaling="weak", name="BASELINE.json configs[2]"),
     3: dict(haps=500_000, sites=10_000_000, seed=44, scaling="strong", name="BASELINE.json configs[3]"),
+    4: dict(haps=200_000, sites=5_000_000, seed=45, scaling="weak", name="BASELINE.json configs[4]"),
 }
 # Issue-rate model of the chain kernels: the chains are bound by vector-instruction issue.
 # A SIMD sustains one wave64 VALU instruction per 2.8 cycles with four waves resident (tools/microbench2.hip,
@@ -89,6 +92,211 @@ def dry_launch_rank(args, real_stdout):
     return 0
 
 
+def run_config4(args, real_stdout):
+    """BASELINE.json configs[4]: decode-only random access through Accessor::get_genotypes (accessor.hpp:58-67; the
+    replay it replaces: accessor_internals_new.hpp:154-196).  Mixed-ploidy + multi-allelic content at 200 000
+    haplotypes (10 % tri-allelic sites, 5 % "male" samples whose second value is end-of-vector, seed 45), built and
+    encoded on the device through xsi_hip_encode_gt; the file is then served by xsi_accessor_get_genotypes.
+    One step = --queries uniformly random BM positions + --windows windows of --window-len consecutive lines.
+    The file of a rank is --blocks blocks of 8192 lines (the 5 M sites of the config are 611 blocks; decoded
+    blocks stay resident in HBM, so the steady state does not depend on how many there are); N > 1: every rank
+    serves its own block range, queries are routed by block (no exchange), weak scaling."""
+    import tempfile
+    import torch
+    from xsqueezeit_amd import binding, synth
+    cfg = CONFIGS[4]
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    distributed = world > 1 or args.force_dist
+    tdist = None
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        tdist.init_process_group(backend="nccl", device_id=dev)
+    L = binding.lib()
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = binding.Context(local_rank, stream.cuda_stream)
+    N = args.haps if args.haps is not None else cfg["haps"]
+    seed = args.seed if args.seed is not None else cfg["seed"]
+    bl = args.block_len
+    n_blocks = args.blocks
+    S = n_blocks * bl
+    first_line = rank * S
+    n_samples = N // 2
+    thr = int(float(N) * args.maf)
+    steps = args.steps if args.steps is not None else 1
+    warmup = args.warmup if args.warmup is not None else 1
+
+    # ---- build the file on the device ----
+    t0 = time.perf_counter()
+    rows, nal = synth.config4_rows_device(L, ctx, torch, dev, seed, first_line, S, N, 1)
+    torch.cuda.synchronize()
+    t_synth = time.perf_counter() - t0
+    n_bin = int((nal.astype(np.int64) - 1).sum())
+    p = binding.EncodeParams(n_samples, bl, thr, 1, 0, 0)
+    cap = int(L.xsi_hip_encode_gt_bound(ctypes.byref(p), S, n_bin))
+    cap = min(cap, max(2 << 30, int(0.08 * float(N) * S)))
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(n_blocks, dtype=torch.int64, device=dev)
+    res = binding.EncodeResult()
+    ngt = np.full(S, N, dtype=np.uint32)
+    t0 = time.perf_counter()
+    binding.check(L.xsi_hip_encode_gt(ctx.handle, ctypes.byref(p), rows.data_ptr(), N, S, ngt.ctypes.data, nal.ctypes.data,
+                                      d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)))
+    torch.cuda.synchronize()
+    t_encode = time.perf_counter() - t0
+    nb = int(res.blocks_bytes)
+    pad = (-(256 + nb)) % 8
+    io = 256 + nb + pad
+    so = io + 8 * n_blocks
+    hf = binding.HeaderFields(n_samples, 2, bl, thr, 1, 0, n_bin, S, io, so)
+    hdr = (ctypes.c_uint8 * 256)()
+    binding.check(L.xsi_hip_make_header(ctypes.byref(hf), hdr))
+    names = b"".join(b"S%d\0" % i for i in range(n_samples))
+    image = bytes(hdr) + d_out[:nb].cpu().numpy().tobytes() + b"\0" * pad + d_off.cpu().numpy().astype("<u8").tobytes() + names
+    del d_out
+    tmp = tempfile.NamedTemporaryFile(suffix=".xsi", delete=False)
+    tmp.write(image)
+    tmp.close()
+
+    # ---- the queries ----
+    bm = synth.bm_positions(nal, bl)
+    rng = np.random.default_rng(seed + rank)
+    q_lines = rng.integers(0, S, args.queries)
+    starts = rng.integers(0, max(S - args.window_len, 1), args.windows)
+    w_lines = (starts[:, None] + np.arange(args.window_len)[None, :]).reshape(-1) if args.windows else np.zeros(0, dtype=np.int64)
+    all_lines = np.concatenate([q_lines, w_lines]).astype(np.int64)
+    all_bm = bm[all_lines]
+    all_na = nal[all_lines]
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), ctx.handle, tmp.name.encode()))
+    buf = np.zeros(N, dtype=np.int32)
+    pbuf = ctypes.c_void_p(buf.ctypes.data)
+    nout = ctypes.c_int(0)
+    get = L.xsi_accessor_get_genotypes
+    u64 = ctypes.c_uint64
+
+    def one_pass(check_every):
+        """All queries of a step through xsi_accessor_get_genotypes; every check_every-th row is compared with the
+        source row (the comparison's time is taken out)."""
+        ok = True
+        t_chk = 0.0
+        t = time.perf_counter()
+        for k in range(len(all_lines)):
+            r = get(a, int(all_na[k]), int(all_bm[k]), ctypes.byref(pbuf), ctypes.byref(nout))
+            if r != N:
+                raise SystemExit("get_genotypes failed: %s" % L.xsi_hip_last_error())
+            if check_every and k % check_every == 0:
+                tc = time.perf_counter()
+                ok = ok and bool(np.array_equal(buf, rows[int(all_lines[k])].cpu().numpy()))
+                t_chk += time.perf_counter() - tc
+        return time.perf_counter() - t - t_chk, ok
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            tdist.barrier()
+            torch.cuda.synchronize()
+
+    # cold pass: the first touch of a block decodes all its lines on the device (what a seek replays in the reference)
+    t_cold, ok_cold = one_pass(997)
+    cb, cby, hits, misses = u64(0), u64(0), u64(0), u64(0)
+    binding.check(L.xsi_accessor_cache_stats(a, ctypes.byref(cb), ctypes.byref(cby), ctypes.byref(hits), ctypes.byref(misses)))
+    cold_misses = int(misses.value)
+    for _ in range(max(warmup - 1, 0)):
+        one_pass(0)
+    fence()
+    t0 = time.perf_counter()
+    ok_warm = True
+    for _ in range(steps):
+        _, okp = one_pass(0)
+        ok_warm = ok_warm and okp
+    fence()
+    dt = time.perf_counter() - t0
+    _, ok_chk = one_pass(499)  # the same queries again, checked against the source rows (not timed)
+    binding.check(L.xsi_accessor_cache_stats(a, ctypes.byref(cb), ctypes.byref(cby), ctypes.byref(hits), ctypes.byref(misses)))
+    timed_misses = int(misses.value) - cold_misses
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        dt = float(t.item())
+    L.xsi_accessor_close(a)
+    cells_step = float(N) * len(all_lines)
+    out = None
+    if rank == 0:
+        xsi_touched = timed_misses * (nb / n_blocks)
+        alg = (xsi_touched / steps + 4.0 * cells_step)
+        achieved = alg / (dt / steps) / 1e9
+        out = {
+            "metric": "GT cells/sec (hap x site) decode-only random access through Accessor::get_genotypes",
+            "value": cells_step * world / (dt / steps), "unit": "GT cells/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "%s: mixed-ploidy + multi-allelic .xsi (10 %% tri-allelic sites, 5 %% male samples with "
+                                   "end-of-vector second value, seed %d), %d hap, %d blocks of %d lines per GPU resident in HBM; "
+                                   "one step = %d random BM queries + %d windows of %d lines through xsi_accessor_get_genotypes "
+                                   "(int32 rows to host memory)" % (cfg["name"], seed, N, n_blocks, bl, args.queries, args.windows, args.window_len),
+                       "haps": N, "blocks_this_gpu": n_blocks, "block_len": bl, "mac_threshold": thr, "binary_lines": n_bin,
+                       "xsi_bytes_this_gpu": nb, "bytes_per_cell": nb / (float(N) * S),
+                       "queries_per_step": int(len(all_lines)), "us_per_query": dt / steps / len(all_lines) * 1e6,
+                       "parallelism": "queries routed by block to the rank that serves it; no exchange"},
+            "roofline": {"bound": "hbm", "kernel": "k_compose_gt + D2H copy of the row (the get_genotypes boundary returns host memory)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "algorithmic_bytes_per_step": alg,
+                         "what": "SURVEY 8d: xsi_bytes_touched + 4 x cells_returned; blocks first touched inside the timed "
+                                 "region: %d (decoded blocks stay resident, LRU in HBM)" % timed_misses,
+                         "pcie_note": "every row crosses PCIe (800 KB at 200 000 hap): the boundary, not HBM, bounds this path"},
+            "cold_pass": {"seconds": t_cold, "block_decodes": cold_misses, "decoded_bytes_in_hbm": int(cby.value),
+                          "ms_per_block_decode_upper_bound": 1e3 * t_cold / max(cold_misses, 1)},
+            "build": {"synth_s": t_synth, "encode_gt_s": t_encode, "encode_cells_per_s": float(N) * S / t_encode},
+            "rows_match_source": bool(ok_cold and ok_warm and ok_chk),
+        }
+        if not args.no_cpu_baseline:
+            from oracle import oracle
+            rd = oracle.Reader(image)
+            ks = list(range(min(args.cpu_queries, len(q_lines))))
+            t = time.perf_counter()
+            cpu_ok = True
+            for k in ks:
+                gt, _ = rd.fill_genotype_array(int(all_na[k]), int(all_bm[k]))
+                cpu_ok = cpu_ok and bool(np.array_equal(gt, rows[int(all_lines[k])].cpu().numpy()))
+            t_cpu = time.perf_counter() - t
+            out["cpu_baseline"] = {"value": float(N) * len(ks) / t_cpu, "unit": "GT cells/s", "cores": 1, "kind": "port",
+                                   "cpu_model": cpu_model(),
+                                   "sample": "the first %d random queries of the same file through the oracle's reader (every "
+                                             "seek replays the block prefix, accessor_internals_new.hpp:154-196): %.2f s"
+                                             % (len(ks), t_cpu),
+                                   "ms_per_query": 1e3 * t_cpu / max(len(ks), 1), "rows_match_source": cpu_ok}
+        else:
+            out["cpu_baseline"] = None
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.unlink(tmp.name)
+    ctx.close()
+    if distributed:
+        tdist.destroy_process_group()
+    return 0 if (rank != 0 or out["rows_match_source"]) else 1
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     # Libraries (RCCL prints a version banner) write to stdout; the contract is ONE JSON line there.
     # Park the real stdout and point fd 1 at stderr until the line is ready.
@@ -111,6 +319,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (process group + RCCL gather) even with one rank (testing)")
+    ap.add_argument("--blocks", type=int, default=8, help="config 4: 8192-line blocks of the file each rank serves")
+    ap.add_argument("--queries", type=int, default=100000, help="config 4: random BM positions per step")
+    ap.add_argument("--windows", type=int, default=1000, help="config 4: contiguous windows per step")
+    ap.add_argument("--window-len", type=int, default=1000)
+    ap.add_argument("--cpu-queries", type=int, default=12, help="config 4: random queries of the CPU-oracle leg")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check without a GPU: the ranks only form a gloo group and report in (CPU test)")
     args = ap.parse_args()
@@ -122,6 +335,8 @@ def main():
         raise SystemExit(launch_ranks(args.gpus))
     if args.dry_launch:
         raise SystemExit(dry_launch_rank(args, real_stdout))
+    if args.config == 4:
+        raise SystemExit(run_config4(args, real_stdout))
     cfg = CONFIGS[args.config]
     custom = args.haps is not None or args.sites is not None
     N = args.haps if args.haps is not None else cfg["haps"]
@@ -407,6 +622,7 @@ def main():
             ref_region = ref[256:io]
             bit_exact = bool(ref_region[:len(gpu_blocks)] == gpu_blocks and len(ref_region) - len(gpu_blocks) < 8)
         out["cpu_baseline"] = {"value": cpu_cells / (t_enc + t_dec), "unit": "GT cells/s", "cores": 1, "kind": "port",
+                               "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
                                "sample": "first %d sites x %d hap of the same matrix (int32 rows in host memory), "
                                          "oracle encode %.2f s + decode %.2f s" % (cs, N, t_enc, t_dec),
                                "encode_cells_per_s": cpu_cells / t_enc, "decode_cells_per_s": cpu_cells / t_dec,

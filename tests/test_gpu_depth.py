@@ -272,3 +272,69 @@ def test_version4_image_decodes(tmp_path):
         assert L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, 2, bm) == n_haps
         assert np.array_equal(buf, gt_all[line])
     L.xsi_accessor_close(a)
+
+
+def test_config4_shape_against_oracle(tmp_path):
+    """BASELINE configs[4] at its shape: 200 000 haplotypes (u32 A_T), 2048-line blocks, 10 % tri-allelic sites,
+    5 % "male" samples with an end-of-vector second value (bench.py --config 4's content, synth.config4_rows_device).
+    GPU encode == oracle bytes; xsi_hip_decode_gt rows == source; random accessor queries and their allele counts ==
+    the oracle's reader (Accessor::fill_genotype_array with its seek replay, accessor_internals_new.hpp:154-384)."""
+    import gpu_util as G
+    from oracle import oracle
+    torch = G.torch_mod()
+    L = binding.lib()
+    n_haps, block_len, n_lines, thr = 200000, 2048, 4096, 200
+    n = n_haps // 2
+    rows_d, nal = synth.config4_rows_device(L, G.ctx(), torch, torch.device("cuda"), 45, 0, n_lines, n_haps, 1)
+    rows = rows_d.cpu().numpy()
+    assert (nal == 3).sum() == 410 and (rows[:, 2 * 7 + 1] == synth.INT32_VECTOR_END).all()
+    lines = [(rows[i], int(nal[i])) for i in range(n_lines)]
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=thr, default_phased=1)
+    assert ref[14] == 4  # u32 A_T
+    p = G.params(n, block_len, thr, 1)
+    n_bin = int((nal.astype(np.int64) - 1).sum())
+    cap = int(L.xsi_hip_encode_gt_bound(ctypes.byref(p), n_lines, n_bin))
+    d_out = G.dev_empty(cap)
+    d_off = torch.zeros(2, dtype=torch.int64, device="cuda")
+    res = binding.EncodeResult()
+    ngt = np.full(n_lines, n_haps, dtype=np.uint32)
+    binding.check(L.xsi_hip_encode_gt(G.ctx().handle, ctypes.byref(p), rows_d.data_ptr(), n_haps, n_lines, ngt.ctypes.data,
+                                      nal.ctypes.data, d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)))
+    region = d_out[:res.blocks_bytes].cpu().numpy().tobytes()
+    del d_out
+    got = G.assemble_file(region, d_off.cpu().numpy().astype(np.uint64), p, n_lines, n_bin, ["S%d" % i for i in range(n)])
+    io = struct.unpack_from("<Q", ref, 72)[0]
+    assert got[256:io] == ref[256:io], "blocks region differs from the oracle's"
+    assert got == ref
+    # whole-file decode on the device against the source rows (compared on the device)
+    d_file = G.dev_u8(np.frombuffer(got, dtype=np.uint8))
+    d_dec = torch.zeros((n_lines, n_haps), dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros((n_lines, 3), dtype=torch.int64, device="cuda")
+    lngt = np.zeros(n_lines, dtype=np.uint32)
+    binding.check(L.xsi_hip_decode_gt(G.ctx().handle, d_file.data_ptr(), len(got), 0, 2, nal.ctypes.data, n_lines,
+                                      d_dec.data_ptr(), n_haps, lngt.ctypes.data, d_cnt.data_ptr(), 3))
+    assert (lngt == n_haps).all()
+    assert bool(torch.equal(d_dec, rows_d))
+    del d_dec
+    # random access through the accessor against the oracle's reader
+    path = tmp_path / "c4.xsi"
+    path.write_bytes(got)
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
+    bm = synth.bm_positions(nal, block_len)
+    rng = np.random.default_rng(45)
+    rd = oracle.Reader(ref)
+    buf = np.zeros(n_haps, dtype=np.int32)
+    pbuf = ctypes.c_void_p(buf.ctypes.data)
+    nout = ctypes.c_int(0)
+    cnt = np.zeros(4, dtype=np.uint64)
+    picks = [int(x) for x in rng.integers(0, n_lines, 40)] + [3, 13, 2047, 2048, 2061, n_lines - 1]
+    for i in picks:
+        egt, ecnt = rd.fill_genotype_array(int(nal[i]), int(bm[i]))
+        r = L.xsi_accessor_get_genotypes(a, int(nal[i]), int(bm[i]), ctypes.byref(pbuf), ctypes.byref(nout))
+        assert r == n_haps and nout.value == n_haps, "line %d: %s" % (i, L.xsi_hip_last_error())
+        assert np.array_equal(buf, egt), "line %d vs oracle reader" % i
+        assert np.array_equal(buf, rows[i]), "line %d vs source" % i
+        binding.check(L.xsi_accessor_allele_counts(a, cnt.ctypes.data, int(nal[i])))
+        assert np.array_equal(cnt[:int(nal[i])], ecnt)
+    L.xsi_accessor_close(a)

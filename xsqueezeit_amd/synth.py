@@ -84,3 +84,56 @@ def bits_to_gt(bits01, default_phased=1):
     if default_phased:
         gt[:, 1::2] |= 1
     return gt
+
+
+# ---------------- BASELINE configs[4] content (SURVEY.md 8d, config 5 of its table) ----------------
+INT32_VECTOR_END = -2147483647  # bcf_int32_vector_end (0x80000001)
+
+
+def config4_n_allele(first_line, n_lines):
+    """Alleles of each BCF line: every tenth site (site % 10 == 3) is tri-allelic."""
+    site = np.arange(first_line, first_line + n_lines, dtype=np.int64)
+    return np.where(site % 10 == 3, 3, 2).astype(np.uint32)
+
+
+def config4_rows_device(L, ctx, torch, dev, seed, first_line, n_lines, n_haps, default_phased=1, chunk=1024):
+    """htslib int32 genotype rows [n_lines, n_haps] in HBM for the mixed-ploidy / multi-allelic workload:
+    ALT 1 carriers from the synthetic matrix of `seed`, on tri-allelic sites ALT 2 carriers (among the REF
+    haplotypes) from the matrix of seed + 1000; 5 % of the samples (sample % 20 == 7) are "male": their second
+    value is end-of-vector.  No fully haploid lines.  Second values carry `default_phased`.
+    Returns (rows int32 tensor, n_allele uint32 numpy)."""
+    import ctypes
+    from . import binding
+    stride = row_stride_bytes(n_haps)
+    nal = config4_n_allele(first_line, n_lines)
+    rows = torch.empty((n_lines, n_haps), dtype=torch.int32, device=dev)
+    shifts = torch.arange(8, dtype=torch.uint8, device=dev)
+    male = (torch.arange(n_haps // 2, device=dev) % 20) == 7
+    for r0 in range(0, n_lines, chunk):
+        n = min(chunk, n_lines - r0)
+        planes = []
+        for sd in (seed, seed + 1000):
+            pk = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+            binding.check(L.xsi_hip_synth_packed(ctx.handle, sd, first_line + r0, n, n_haps, pk.data_ptr(), stride))
+            planes.append(((pk.view(n, stride, 1) >> shifts) & 1).view(n, stride * 8)[:, :n_haps])
+        tri = torch.from_numpy((nal[r0:r0 + n] == 3)).to(dev)
+        allele = planes[0].to(torch.int32)
+        allele = torch.where(tri[:, None] & (planes[0] == 0) & (planes[1] == 1), torch.full_like(allele, 2), allele)
+        gt = (allele + 1) << 1
+        gt[:, 1::2] |= int(default_phased)
+        gt[:, 1::2] = torch.where(male[None, :], torch.full_like(gt[:, 1::2], INT32_VECTOR_END), gt[:, 1::2])
+        rows[r0:r0 + n] = gt
+        del planes, allele, gt, pk
+    return rows, nal
+
+
+def bm_positions(n_allele, block_len):
+    """BM value of every BCF line (block << 15 | binary-line offset inside the block, xcf.cpp:685-703)."""
+    nal = np.asarray(n_allele, dtype=np.int64)
+    n = len(nal)
+    bm = np.empty(n, dtype=np.int64)
+    for b0 in range(0, n, block_len):
+        k = nal[b0:b0 + block_len] - 1
+        off = np.concatenate(([0], np.cumsum(k)[:-1]))
+        bm[b0:b0 + block_len] = ((b0 // block_len) << 15) | off
+    return bm
