@@ -136,7 +136,9 @@ int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_
  * device: the "-Ox" path of NewDecompressor (include/gt_decompressor_new.hpp:241-273, fill_selected_genotypes
  * :209-238 + XsiFactoryInterface::append).  h_n_allele[l] for every BCF line as for xsi_hip_decode_gt;
  * h_sample_idx (n_sel indices into the file's samples, NULL = all); p_new->n_samples must be the number of
- * samples written.  Output as xsi_hip_encode_gt.
+ * samples written.  Output as xsi_hip_encode_gt.  The int32 rows of the whole file are held in HBM at once
+ * (4 bytes per value, + 8 per selected sample and line); a file too large for that returns XSI_ERR_CAPACITY with
+ * the sizes in the message: re-encode such a file by block ranges (xsi_hip_decode_gt + xsi_hip_encode_gt).
  */
 int xsi_hip_reencode(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, const uint32_t* h_n_allele, uint64_t n_lines,
                      const xsi_encode_params* p_new, const uint32_t* h_sample_idx, uint32_t n_sel, void* d_out,
@@ -384,6 +386,12 @@ uint64_t xsi_accessor_num_samples(const xsi_accessor* a);
 /* Accessor::get_sample_list()[i] */
 const char* xsi_accessor_sample_name(const xsi_accessor* a, uint64_t i);
 void xsi_accessor_close(xsi_accessor* a);
+
+/* 1 when the library was built where htslib is installed and therefore also exports the reference's own C API
+ * over this one - c_xcf_new / c_xcf_add_readers / c_xcf_update_readers / c_xcf_sample_name / c_xcf_nsamples /
+ * __c__xcf__get__genotypes__void / c_xcf_delete (include/c_api.h:38-93) - and xsi_compress_bcf, the -c fill loop
+ * (bcf_traversal.cpp:3-16, xcf.cpp:641-714); 0 otherwise (csrc/xsi_htslib_shim.cpp). */
+int xsi_htslib_shim_available(void);
 
 #ifdef __cplusplus
 }

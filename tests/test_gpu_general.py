@@ -121,7 +121,7 @@ def test_wah_encode_missing_strategy():
         assert np.array_equal(r, gt)
 
 
-def test_unknown_allele_is_an_error():
+def test_allele_above_the_line_alleles_is_an_error():
     import gpu_util as G
     gt = np.full(20, 2, dtype=np.int32)
     gt[3] = (5 + 1) << 1  # allele 5 on a bi-allelic line

@@ -2,13 +2,14 @@
 # Collects the rocprofv3 evidence kept under profiles/ for the default bench line (BASELINE configs[2]):
 # kernel-trace stats, HBM traffic (separate --pmc FETCH_SIZE / WRITE_SIZE passes, as the MI355X guide
 # prescribes) and SQ instruction counters of the chain kernels.  Run on a GPU box:
-#   gpurun -- bash tools/collect_profiles.sh r02
+#   gpurun -- bash tools/collect_profiles.sh r03
 # Output lands in gpurun_out/<tag>_*; tools/summarize_profile.py folds it into profiles/.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?not on a gpurun box}"
 O=gpurun_out
+mkdir -p "$O"
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python3 bench.py --config 1 > $O/${TAG}_bench_config1.json 2> $O/${TAG}_bench_config1.err
 # the 153-block x 500 000-haplotype shard one of 8 GPUs gets of BASELINE configs[3]

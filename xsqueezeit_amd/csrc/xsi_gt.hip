@@ -1278,7 +1278,24 @@ int xsi_hip_reencode(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, co
     if (h_sample_idx)
         for (uint32_t i = 0; i < n_sel; ++i)
             if (h_sample_idx[i] >= n_src) return set_error(XSI_ERR_ARG, "reencode: sample %u of %u", h_sample_idx[i], n_src);
-    // decode every line to int32 rows in HBM, (optionally) gather the selected samples there, encode again
+    // decode every line to int32 rows in HBM, (optionally) gather the selected samples there, encode again.
+    // The rows of the WHOLE file are held at once (4 N bytes per line, + 8 n_sel with a selection): a file whose
+    // rows do not fit the free HBM next to the codec's own workspace is refused, with the numbers, instead of
+    // failing somewhere inside hipMalloc (split such a job by block ranges: decode_gt + encode_gt per range).
+    {
+        const uint64_t need = 4ull * N * n_lines + (h_sample_idx ? 8ull * n_sel * n_lines : 0ull);
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        uint64_t have = free_b;
+        auto it = ctx->bufs.find("reenc.rows");
+        if (it != ctx->bufs.end()) have += it->second.cap;
+        it = ctx->bufs.find("reenc.sub");
+        if (it != ctx->bufs.end()) have += it->second.cap;
+        if (need > have - have / 4)
+            return set_error(XSI_ERR_CAPACITY, "reencode: the int32 rows of %llu lines x %llu values need %.1f GB, %.1f GB of HBM are free "
+                             "(three quarters are usable next to the codec's workspace): re-encode by block ranges",
+                             (unsigned long long)n_lines, (unsigned long long)N, need / 1e9, have / 1e9);
+    }
     int32_t* d_rows;
     WS(d_rows, "reenc.rows", 4ull * N * (size_t)n_lines);
     std::vector<uint32_t> ngt(n_lines);

@@ -37,6 +37,8 @@ using namespace xsi;
 // time (no zstd headers in the build image); without it --zstd files are refused.
 // ------------------------------------------------------------------------------------------
 #include <dlfcn.h>
+#include <exception>
+#include <new>
 namespace {
 struct ZstdApi {
     size_t (*compress)(void*, size_t, const void*, size_t, int) = nullptr;
@@ -203,7 +205,13 @@ static int writer_flush_batch(xsi_writer* w) {
     const uint64_t n_lines = w->lines_in_batch;
     w->worker_active = true;
     w->worker = std::thread([w, b, n_lines] {
-        const int r = writer_encode_batch(w, b, n_lines);
+        // nothing may leave this thread as an exception (std::terminate): an allocation failure is an error code
+        int r;
+        try {
+            r = writer_encode_batch(w, b, n_lines);
+        } catch (const std::exception& e) {
+            r = set_error(XSI_ERR_IO, "writer: %s while encoding a batch", e.what());
+        }
         if (r) {
             w->worker_rc = r;
             w->worker_err = xsi_hip_last_error();
@@ -482,7 +490,11 @@ static int accessor_block_image(xsi_accessor* a, uint64_t block, const uint8_t**
     if (!z.ok) return set_error(XSI_ERR_UNSUPPORTED, "zstd-compressed file but libzstd.so.1 could not be loaded");
     size_t body = (size_t)usize;
     while ((256 + body) % 8) body++;
-    a->mini.assign(256 + body + 8, 0);
+    try {  // usize comes from the file: an absurd value must end as an error, not as std::bad_alloc through extern "C"
+        a->mini.assign(256 + body + 8, 0);
+    } catch (const std::exception&) {
+        return set_error(XSI_ERR_FORMAT, "zstd block header declares %llu bytes: cannot allocate", (unsigned long long)usize);
+    }
     memcpy(a->mini.data(), h, 256);
     a->mini[17] &= (uint8_t)~4u;  // the image handed to the GPU is not compressed
     const size_t r = z.decompress(a->mini.data() + 256, (size_t)usize, h + off + 2 * sz, (size_t)csize);
@@ -713,8 +725,19 @@ int xsi_accessor_open(xsi_accessor** out, xsi_hip_ctx* ctx, const char* path) {
         fclose(f);
         return set_error(XSI_ERR_FORMAT, "Bad magic");
     }
-    xsi_accessor* a = new xsi_accessor();
-    a->file.resize((size_t)sz);
+    xsi_accessor* a = new (std::nothrow) xsi_accessor();
+    if (a) {
+        try {
+            a->file.resize((size_t)sz);
+        } catch (const std::exception&) {
+            delete a;
+            a = nullptr;
+        }
+    }
+    if (!a) {
+        fclose(f);
+        return set_error(XSI_ERR_IO, "accessor_open: cannot hold %ld bytes of %s in memory", sz, path);
+    }
     if (fread(a->file.data(), 1, (size_t)sz, f) != (size_t)sz) {
         fclose(f);
         delete a;
