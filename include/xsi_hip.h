@@ -236,6 +236,12 @@ int xsi_hip_debug_chain_encode(xsi_hip_ctx* ctx, const xsi_encode_params* p, con
                                uint32_t row_stride_bytes, void* d_yrows, uint32_t y_stride_bytes,
                                uint32_t* d_line_kind, uint64_t* h_n_wah);
 
+/* What xsi_writer_append does to a row in the caller's thread: a bi-allelic, fully called diploid row whose second
+ * values carry default_phased becomes one bit per haplotype (h_bits[0 .. ceil(n / 8)), bit h LSB-first = haplotype h
+ * carries ALT) and 1 is returned; 0 = the row needs the int32 form (another allele, missing, end-of-vector, a
+ * second value with the other phase).  Host only. */
+int xsi_debug_pack_bit_row(const int32_t* h_gt, uint32_t n, int32_t default_phased, uint8_t* h_bits);
+
 /* ---- host-only helpers of the fill loops either side of the block path (no device work) ---- */
 /* MINOR_ALLELE_COUNT_THRESHOLD = (size_t)((double)(n_samples * PLOIDY) * MAF), include/gt_compressor_new.hpp:96-99;
  * PLOIDY = ploidy of the first record.  This is xsi_encode_params.mac_threshold. */
@@ -304,7 +310,9 @@ typedef struct xsi_accessor xsi_accessor;
 int xsi_writer_open(xsi_writer** w, xsi_hip_ctx* ctx, const char* path, const xsi_encode_params* p,
                     const char* const* sample_names);
 /* XsiFactoryInterface::append(bcf_fri): one BCF line, host int32 row (bcf_fri.gt_arr), ngt values,
- * n_allele = bcf_fri.line->n_allele.  Lines are batched per block and encoded on the GPU. */
+ * n_allele = bcf_fri.line->n_allele.  Lines are batched per block and encoded on the GPU.  A bi-allelic, fully
+ * called diploid line with default phase is packed to one bit per haplotype right here (4 N bytes read, N / 8
+ * written and shipped); any other line is copied as int32.  The file does not depend on which way a line went. */
 int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t n_allele);
 /* The same without the copy: xsi_writer_row_buffer returns the next row's slot in the writer's pinned staging
  * (room for 2 * n_samples int32 values; NULL on error) for the caller to fill - e.g. as the destination array of

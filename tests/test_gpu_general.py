@@ -772,3 +772,45 @@ def test_unknown_allele_is_an_error(bad):
         assert rc == binding.XSI_ERR_ARG, (bad, pos, rc)
         assert b"Unknown allele" in L.xsi_hip_last_error()
     assert run(m) == 0                   # the context stays usable
+
+
+@pytest.mark.parametrize("every,use_row_buffer", [(0, False), (37, False), (1, False), (37, True), (0, True)])
+def test_writer_packs_on_append_and_mixes_line_kinds(tmp_path, every, use_row_buffer, monkeypatch):
+    """xsi_writer_append packs a simple line (alleles 0 / 1, fully called, default phase) to bits in the caller's
+    thread and ships only those; other lines travel as int32.  A batch without such lines takes xsi_hip_encode_packed,
+    a mixed one has its packed lines expanded on the device and takes xsi_hip_encode_gt.  Whatever the mix
+    (`every`: 0 = none general, k = every k-th line general; through append or through the row buffer), the file
+    is the oracle's, and the same as with packing switched off."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    rng = np.random.default_rng(5)
+    n, n_lines, block_len = 333, 900, 256   # 666 values: a ragged tail for every vector width
+    simple = _random_lines(rng, n, n_lines)
+    general = _random_lines(rng, n, n_lines, multi=True, missing=True, eov=True, phase=True)
+    lines = [general[i] if every and i % every == every // 2 else simple[i] for i in range(n_lines)]
+    dp = 1
+    names = ["s%d" % i for i in range(n)]
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=3, default_phased=dp, sample_names=names)
+    p = G.params(n, block_len, 3, dp)
+    arr = (ctypes.c_char_p * n)(*[s.encode() for s in names])
+
+    def write(path):
+        w = ctypes.c_void_p()
+        binding.check(L.xsi_writer_open(ctypes.byref(w), G.ctx().handle, path, ctypes.byref(p), arr))
+        L.xsi_writer_row_buffer.restype = ctypes.POINTER(ctypes.c_int32)
+        for gt, na in lines:
+            gt = np.ascontiguousarray(gt, dtype=np.int32)
+            if use_row_buffer:
+                dst = L.xsi_writer_row_buffer(w)
+                assert dst
+                ctypes.memmove(dst, gt.ctypes.data, gt.nbytes)
+                binding.check(L.xsi_writer_commit_row(w, gt.size, na))
+            else:
+                binding.check(L.xsi_writer_append(w, gt.ctypes.data, gt.size, na))
+        binding.check(L.xsi_writer_finalize(w, 0))
+        L.xsi_writer_close(w)
+        return open(path, "rb").read()
+
+    got = write(str(tmp_path / "a.xsi").encode())
+    assert got == ref

@@ -306,3 +306,37 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_reported"] == [0, 1]
     assert len(set(out["pids"])) == 2 and os.getpid() not in out["pids"]
+
+
+@pytest.mark.parametrize("isa", ["0", "1"])
+def test_append_packer_other_instruction_sets(isa):
+    """The same checks with the scalar and the AVX2 form forced (the library picks the widest form once per process)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, XSI_PACK_ISA=isa)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(ROOT, "tests", "test_host.py"), "-k",
+                        "test_append_packs_simple_rows_to_bits"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_append_packs_simple_rows_to_bits():
+    """The writer's pack-on-append (host only, AVX-512 / AVX2 / scalar by the CPU): a row of alleles 0 / 1 with the
+    default phase on the second values becomes its ALT-carrier bit row; anything else is left to the int32 path."""
+    L = binding.lib()
+    rng = np.random.default_rng(8)
+    for n in list(range(2, 80, 2)) + [5008, 64976 * 2 // 2]:
+        for dp in (0, 1):
+            al = (rng.random(n) < 0.3).astype(np.int32)
+            gt = ((al + 1) << 1).astype(np.int32)
+            gt[1::2] |= dp
+            gt[0::2] |= rng.integers(0, 2, size=len(gt[0::2])).astype(np.int32)  # the first value's phase bit is not stored
+            out = np.full((n + 7) // 8 + 8, 0xEE, dtype=np.uint8)
+            assert L.xsi_debug_pack_bit_row(gt.ctypes.data, n, dp, out.ctypes.data) == 1
+            want = np.packbits(al.astype(np.uint8), bitorder="little")
+            assert np.array_equal(out[:len(want)], want), (n, dp)
+            assert (out[len(want):] == 0xEE).all()  # nothing written beyond ceil(n / 8)
+            for pos, bad in ((n - 1, ((al[n - 1] + 1) << 1) | (1 - dp)),   # second value with the other phase
+                             (n // 2, 6), (n // 2, 0), (0, -2147483647), (n - 2, 1), (n - 1, -2147483648)):
+                g2 = gt.copy()
+                g2[pos] = bad
+                assert L.xsi_debug_pack_bit_row(g2.ctypes.data, n, dp, out.ctypes.data) == 0, (n, dp, pos, bad)

@@ -54,7 +54,7 @@ SYMBOLS = [
     "xsi_bm_init", "xsi_bm_next", "xsi_accessor_set_sample_subset", "xsi_accessor_fill_selected_genotypes",
     "xsi_hip_reencode", "xsi_hip_ctx_chain_fallbacks",
     "xsi_hip_shard_blocks", "xsi_hip_comm_unique_id", "xsi_hip_comm_create", "xsi_hip_comm_destroy",
-    "xsi_hip_comm_world", "xsi_hip_comm_rank", "xsi_hip_gather_block_streams", "xsi_hip_comm_wait", "xsi_htslib_shim_available",
+    "xsi_hip_comm_world", "xsi_hip_comm_rank", "xsi_hip_gather_block_streams", "xsi_hip_comm_wait", "xsi_htslib_shim_available", "xsi_debug_pack_bit_row",
 ]
 
 
@@ -111,6 +111,8 @@ def lib():
     L.xsi_hip_comm_world.argtypes = [vp]
     L.xsi_hip_comm_rank.restype = c.c_int
     L.xsi_hip_comm_rank.argtypes = [vp]
+    L.xsi_debug_pack_bit_row.restype = c.c_int
+    L.xsi_debug_pack_bit_row.argtypes = [vp, u32, i32, vp]
     L.xsi_hip_comm_wait.restype = c.c_int
     L.xsi_hip_comm_wait.argtypes = [vp, c.c_int]
     L.xsi_hip_gather_block_streams.restype = c.c_int

@@ -111,6 +111,12 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
 int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide S, std::vector<EncBlock>& blocks_h,
                void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result,
                uint64_t region_offset = 0, bool use_wah_scratch = true);
+// xsi_pack.cpp: one htslib row -> one bit per haplotype when the bit form can hold it (see there); out gets ceil(n / 8) bytes
+bool pack_bit_row(const int32_t* gt, uint32_t n, int dp, uint8_t* out);
+// the writer's packed lines back to htslib int32 rows on the device: row l of d_rows (stride N values) is rewritten
+// from bit row l where d_fast[l] != 0; second values carry default_phased
+int expand_bit_rows(xsi_hip_ctx* ctx, const uint8_t* d_bits, uint32_t bit_stride, const uint8_t* d_fast, int32_t* d_rows,
+                    uint64_t N, uint64_t n_lines, int32_t default_phased);
 // bytes of per-line workspace budget in force for a call made now
 uint64_t ws_budget_now(const xsi_hip_ctx* ctx);
 int encode_side_write(xsi_hip_ctx* ctx, const EncBlock* d_blocks, uint32_t n_blocks, const EncLines& L,

@@ -938,6 +938,36 @@ int select_samples(xsi_hip_ctx* ctx, const int32_t* d_rows, uint64_t row_stride,
 
 }  // namespace xsi
 
+namespace xsi {
+// bit row -> (allele + 1) << 1 | phase, four values per thread and step (one 16-byte store)
+__global__ void __launch_bounds__(256) k_expand_bit_rows(const uint8_t* __restrict__ bits, uint32_t bit_stride, const uint8_t* __restrict__ fast,
+                                                         int32_t* __restrict__ rows, uint64_t N, int32_t dp) {
+    const uint64_t l = blockIdx.x;
+    if (!fast[l]) return;
+    const uint8_t* b = bits + l * bit_stride;
+    int32_t* r = rows + l * N;
+    for (uint64_t h = (uint64_t)threadIdx.x * 4u; h < N; h += 1024u) {
+        const uint32_t nib = (uint32_t)(b[h >> 3] >> (h & 7u)) & 15u;
+        int32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (int32_t)((((nib >> k) & 1u) + 1u) << 1) | ((k & 1) ? dp : 0);
+        if (h + 4u <= N && ((reinterpret_cast<uintptr_t>(r + h) & 15u) == 0u)) {
+            *reinterpret_cast<int4*>(r + h) = make_int4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int k = 0; k < 4 && h + (uint64_t)k < N; ++k) r[h + k] = v[k];
+        }
+    }
+}
+
+int expand_bit_rows(xsi_hip_ctx* ctx, const uint8_t* d_bits, uint32_t bit_stride, const uint8_t* d_fast, int32_t* d_rows,
+                    uint64_t N, uint64_t n_lines, int32_t default_phased) {
+    if (!n_lines) return XSI_OK;
+    k_expand_bit_rows<<<dim3((unsigned)n_lines), dim3(256), 0, ctx->stream>>>(d_bits, bit_stride, d_fast, d_rows, N, default_phased ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return XSI_OK;
+}
+}  // namespace xsi
+
 extern "C" {
 
 int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_t* d_gt, uint64_t gt_stride,

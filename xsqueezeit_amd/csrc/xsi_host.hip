@@ -90,6 +90,20 @@ struct xsi_writer {
     uint64_t lines_in_batch = 0, lines_on_device = 0;
     hipStream_t copy_stream = nullptr;
     hipEvent_t batch_copied = nullptr;
+    // Bit rows: a bi-allelic, fully called diploid line whose second values carry the default phase is one bit per
+    // haplotype (what xsi_hip_encode_packed takes).  append packs such a line in the caller's thread (reads 4 N
+    // bytes, writes N / 8 - cheaper than copying the int32 row) and only the bit row crosses PCIe; any other line
+    // is staged as int32.  A batch without such "general" lines is encoded by xsi_hip_encode_packed; otherwise
+    // the packed lines are expanded to int32 rows on the device and the batch goes through xsi_hip_encode_gt.
+    // Same bytes either way (both entry points are byte-equal to the reference on such lines).
+    uint32_t bit_stride = 0;        // bytes of a bit row (a multiple of 128)
+    uint8_t* d_bits[2] = {nullptr, nullptr};
+    uint8_t* d_fast[2] = {nullptr, nullptr};  // per line: 1 = bit row, 0 = int32 row
+    std::vector<uint8_t> fast[2];
+    uint64_t general_in_batch = 0;
+    uint8_t* h_bits_chunks[2] = {nullptr, nullptr};
+    uint8_t* h_bits_chunk = nullptr;
+    uint32_t chunk_general = 0;     // int32 rows in the chunk being filled (0: its int32 half is not shipped)
     // pinned staging chunks: one fills while the other is on its way to HBM
     int32_t* h_chunk = nullptr;
     int32_t* h_chunks[2] = {nullptr, nullptr};
@@ -113,16 +127,23 @@ struct xsi_writer {
     uint64_t file_pos = 0;
 };
 
+
 static int writer_ship_chunk(xsi_writer* w) {
     if (!w->chunk_fill) return XSI_OK;
-    HIP_TRY(hipMemcpyAsync(w->d_rows[w->cur] + (size_t)w->lines_on_device * w->N, w->h_chunk,
-                           (size_t)w->chunk_fill * w->N * sizeof(int32_t), hipMemcpyHostToDevice, w->copy_stream));
+    // the bit rows always go (N / 8 bytes a line); the int32 half only when the chunk holds a line that needs it
+    HIP_TRY(hipMemcpyAsync(w->d_bits[w->cur] + (size_t)w->lines_on_device * w->bit_stride, w->h_bits_chunk,
+                           (size_t)w->chunk_fill * w->bit_stride, hipMemcpyHostToDevice, w->copy_stream));
+    if (w->chunk_general)
+        HIP_TRY(hipMemcpyAsync(w->d_rows[w->cur] + (size_t)w->lines_on_device * w->N, w->h_chunk,
+                               (size_t)w->chunk_fill * w->N * sizeof(int32_t), hipMemcpyHostToDevice, w->copy_stream));
     HIP_TRY(hipEventRecord(w->chunk_done[w->cur_chunk], w->copy_stream));
     w->lines_on_device += w->chunk_fill;
     w->chunk_fill = 0;
+    w->chunk_general = 0;
     // keep filling the other chunk while this one is copied; wait only if that one is still in flight
     w->cur_chunk ^= 1;
     w->h_chunk = w->h_chunks[w->cur_chunk];
+    w->h_bits_chunk = w->h_bits_chunks[w->cur_chunk];
     HIP_TRY(hipEventSynchronize(w->chunk_done[w->cur_chunk]));
     return XSI_OK;
 }
@@ -149,8 +170,20 @@ static int writer_encode_batch(xsi_writer* w, int b, uint64_t n_lines) {
         w->offs_cap = n_blocks;
     }
     xsi_encode_result res{};
-    int rc = xsi_hip_encode_gt(w->ctx, &w->p, w->d_rows[b], w->N, n_lines, w->ngt[b].data(), w->n_allele[b].data(), w->d_out,
+    int rc;
+    uint64_t n_general = 0;
+    for (uint8_t f : w->fast[b]) n_general += f ? 0u : 1u;
+    if (n_general == 0) {
+        rc = xsi_hip_encode_packed(w->ctx, &w->p, w->d_bits[b], n_lines, w->bit_stride, w->d_out, w->out_cap, w->d_offs, &res);
+    } else {
+        if (n_general != n_lines) {  // the packed lines become int32 rows on the device, next to the shipped ones
+            HIP_TRY(hipMemcpyAsync(w->d_fast[b], w->fast[b].data(), n_lines, hipMemcpyHostToDevice, w->ctx->stream));
+            rc = xsi::expand_bit_rows(w->ctx, w->d_bits[b], w->bit_stride, w->d_fast[b], w->d_rows[b], w->N, n_lines, w->p.default_phased);
+            if (rc) return rc;
+        }
+        rc = xsi_hip_encode_gt(w->ctx, &w->p, w->d_rows[b], w->N, n_lines, w->ngt[b].data(), w->n_allele[b].data(), w->d_out,
                                w->out_cap, w->d_offs, &res);
+    }
     if (rc) return rc;
     w->h_out.resize(res.blocks_bytes);
     w->h_offs.resize(n_blocks + 1);
@@ -221,6 +254,7 @@ static int writer_flush_batch(xsi_writer* w) {
     w->lines_in_batch = w->lines_on_device = 0;
     w->ngt[w->cur].clear();
     w->n_allele[w->cur].clear();
+    w->fast[w->cur].clear();
     return XSI_OK;
 }
 
@@ -229,6 +263,9 @@ static void writer_free(xsi_writer* w) {
     if (w->f) fclose(w->f);
     for (int i = 0; i < 2; ++i) {
         if (w->d_rows[i]) (void)hipFree(w->d_rows[i]);
+        if (w->d_bits[i]) (void)hipFree(w->d_bits[i]);
+        if (w->d_fast[i]) (void)hipFree(w->d_fast[i]);
+        if (w->h_bits_chunks[i]) (void)hipHostFree(w->h_bits_chunks[i]);
         if (w->h_chunks[i]) (void)hipHostFree(w->h_chunks[i]);
         if (w->chunk_done[i]) (void)hipEventDestroy(w->chunk_done[i]);
     }
@@ -284,19 +321,31 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
     w->file_pos = 256;
     const size_t row_bytes = (size_t)w->N * sizeof(int32_t);
     const size_t block_bytes = row_bytes * p->block_len;
-    // blocks per batch: enough to give the chain a workgroup per CU where memory allows (two row
-    // batches + the encoder's planes and workspace, about 4x the rows); XSI_WRITER_BATCH_BLOCKS overrides
+    // Blocks per batch.  The device is two orders of magnitude faster than one host thread can feed it, so a batch
+    // is not sized to fill the GPU but to keep append() from ever waiting: while the worker encodes batch k (a
+    // latency of about 20 ms + 0.5 ms per 1000 haplotypes, set by the serial PBWT chain of a block, whatever the
+    // number of blocks) the caller must be busy filling batch k + 1, at ~10 G cells/s of packing: twice that
+    // latency's worth of blocks, at most 64 and at most what a quarter of the free HBM holds twice.  Small batches
+    // also start the overlap early (a file shorter than one batch is encoded only at finalize).
+    // XSI_WRITER_BATCH_BLOCKS overrides.
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-        uint64_t k = free_b / 4 / (block_bytes ? block_bytes : 1) / 2;
+        uint64_t fit = free_b / 4 / (block_bytes ? block_bytes : 1) / 2;
+        const double gpu_ms = 20.0 + 0.5 * (double)w->N / 1000.0;
+        const double host_ms_per_block = (double)p->block_len * (double)w->N / 10e9 * 1e3;
+        uint64_t k = (uint64_t)(2.0 * gpu_ms / (host_ms_per_block > 1e-3 ? host_ms_per_block : 1e-3)) + 1u;
         if (k > 64) k = 64;
+        if (k > fit) k = fit;
         if (const char* e = getenv("XSI_WRITER_BATCH_BLOCKS")) k = strtoull(e, nullptr, 10);
         if (k < 1 || p->zstd_level) k = 1;
         w->batch_blocks = (uint32_t)k;
     }
     hipError_t e = hipSuccess;
+    w->bit_stride = (uint32_t)(((w->N + 1023u) / 1024u) * 128u);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&w->d_rows[i], block_bytes * w->batch_blocks);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&w->d_bits[i], (size_t)w->bit_stride * p->block_len * w->batch_blocks);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&w->d_fast[i], (size_t)p->block_len * w->batch_blocks);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&w->batch_copied, hipEventDisableTiming);
     size_t chunk_bytes = 64ull << 20;
@@ -305,10 +354,13 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
     if (w->chunk_rows > p->block_len) w->chunk_rows = p->block_len;
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipHostMalloc((void**)&w->h_chunks[i], row_bytes * w->chunk_rows, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&w->h_bits_chunks[i], (size_t)w->bit_stride * w->chunk_rows, hipHostMallocDefault);
+        if (e == hipSuccess) memset(w->h_bits_chunks[i], 0, (size_t)w->bit_stride * w->chunk_rows);  // the pad of every row stays zero
         if (e == hipSuccess) e = hipEventCreateWithFlags(&w->chunk_done[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventRecord(w->chunk_done[i], w->copy_stream);  // "free" from the start
     }
     w->h_chunk = w->h_chunks[0];
+    w->h_bits_chunk = w->h_bits_chunks[0];
     if (e != hipSuccess) {
         writer_free(w);
         return set_error(XSI_ERR_HIP, "writer buffers: %s", hipGetErrorString(e));
@@ -329,13 +381,25 @@ int32_t* xsi_writer_row_buffer(xsi_writer* w) {
     return w->h_chunk + (size_t)w->chunk_fill * w->N;
 }
 
-int xsi_writer_commit_row(xsi_writer* w, uint32_t ngt, uint32_t n_allele) {
+static int writer_commit(xsi_writer* w, uint32_t ngt, uint32_t n_allele, bool line_is_packed) {
     if (!w || !w->f) return set_error(XSI_ERR_ARG, "writer_commit_row: null / closed writer");
     if (ngt != w->p.n_samples && ngt != 2u * w->p.n_samples)
         return set_error(XSI_ERR_ARG, "PLOIDY ERROR: %u values for %u samples", ngt, w->p.n_samples);
     if (n_allele < 2) return set_error(XSI_ERR_UNSUPPORTED, "lines without an ALT allele are rejected (see xsi_hip_encode_gt)");
     if (w->lines_in_batch == (uint64_t)w->p.block_len * w->batch_blocks)
         return set_error(XSI_ERR_ARG, "writer_commit_row without xsi_writer_row_buffer");
+    if (!line_is_packed) {
+        // the caller filled the int32 slot (bcf_get_genotypes' destination): pack from it when the line allows, so
+        // that a chunk of such lines still ships bit rows only
+        line_is_packed = ngt == 2u * w->p.n_samples && n_allele == 2 &&
+                         xsi::pack_bit_row(w->h_chunk + (size_t)w->chunk_fill * w->N, ngt, w->p.default_phased,
+                                      w->h_bits_chunk + (size_t)w->chunk_fill * w->bit_stride);
+    }
+    if (!line_is_packed) {
+        w->chunk_general++;
+        w->general_in_batch++;
+    }
+    w->fast[w->cur].push_back(line_is_packed ? 1 : 0);
     w->chunk_fill++;
     w->lines_in_batch++;
     w->ngt[w->cur].push_back(ngt);
@@ -348,6 +412,13 @@ int xsi_writer_commit_row(xsi_writer* w, uint32_t ngt, uint32_t n_allele) {
     return XSI_OK;
 }
 
+int xsi_writer_commit_row(xsi_writer* w, uint32_t ngt, uint32_t n_allele) { return writer_commit(w, ngt, n_allele, false); }
+
+int xsi_debug_pack_bit_row(const int32_t* h_gt, uint32_t n, int32_t default_phased, uint8_t* h_bits) {
+    if (!h_gt || !h_bits) return set_error(XSI_ERR_ARG, "debug_pack_bit_row: null argument");
+    return xsi::pack_bit_row(h_gt, n, default_phased, h_bits) ? 1 : 0;
+}
+
 int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t n_allele) {
     if (!w || !h_gt) return set_error(XSI_ERR_ARG, "writer_append: null argument");
     if (ngt != w->p.n_samples && ngt != 2u * w->p.n_samples)
@@ -355,8 +426,11 @@ int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t
     if (n_allele < 2) return set_error(XSI_ERR_UNSUPPORTED, "lines without an ALT allele are rejected (see xsi_hip_encode_gt)");
     int32_t* dst = xsi_writer_row_buffer(w);
     if (!dst) return XSI_ERR_HIP;  // the flush's own message stands
-    memcpy(dst, h_gt, (size_t)ngt * sizeof(int32_t));
-    return xsi_writer_commit_row(w, ngt, n_allele);
+    // one pass over the caller's row: 4 N bytes read, N / 8 written; only a line the bit form cannot hold is copied
+    const bool packed = ngt == 2u * w->p.n_samples && n_allele == 2 &&
+                        xsi::pack_bit_row(h_gt, ngt, w->p.default_phased, w->h_bits_chunk + (size_t)w->chunk_fill * w->bit_stride);
+    if (!packed) memcpy(dst, h_gt, (size_t)ngt * sizeof(int32_t));
+    return writer_commit(w, ngt, n_allele, packed);
 }
 
 int xsi_writer_finalize(xsi_writer* w, uint32_t max_ploidy) {
