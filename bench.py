@@ -41,14 +41,21 @@ CONFIGS = {
     3: dict(haps=500_000, sites=10_000_000, seed=44, scaling="strong", name="BASELINE.json configs[3]"),
     4: dict(haps=200_000, sites=5_000_000, seed=45, scaling="weak", name="BASELINE.json configs[4]"),
 }
-# Issue-rate model of the chain kernels: the chains are bound by vector-instruction issue.
-# A SIMD sustains one wave64 VALU instruction per 2.8 cycles with four waves resident (tools/microbench2.hip,
-# profiles/r02_microbench2.txt; 4 cycles for a wave alone); VALU instructions per 64-haplotype chunk per WAH
-# line as counted by SQ_INSTS_VALU (profiles/r02_pmc_sq_chains.txt; r01 for the round-1 kernels).
+# Issue model of the chain kernels.  Two pipes bound a chain line, and the slower one is its floor:
+#  * vector issue: a SIMD sustains one wave64 VALU instruction per 2.8 cycles with four waves resident
+#    (tools/microbench2.hip, profiles/r02_microbench2.txt); VALU instructions per 64-haplotype chunk per WAH line as
+#    counted by SQ_INSTS_VALU (profiles/r02_pmc_sq_chains.txt);
+#  * the LDS pipe of the CU: every chunk-line is one random ds_read_b64 gather (7.1 cycles per wave-instruction,
+#    tools/microbench3.hip: its two groups of 32 lanes each wait for the fullest of 32 bank pairs) plus, on encode,
+#    the atomic deposit of the next line's ones (7.4 with all lanes, less with a few) and the table build; LDS
+#    array cycles per chunk-line as counted by SQ_LDS_IDX_ACTIVE / chunk-lines in the same PMC runs
+#    (k_chain_rank_enc 11.84 G / 1.22 G, 61 % of them bank conflicts; k_chain_decode_rank_wg 8.99 G / 1.22 G).
 SIMDS, MODEL_CLOCK_HZ, CYCLES_PER_VALU = 256 * 4, 2.4e9, 2.8
 VALU_PER_CHUNK_LINE = {"k_chain_rank_enc": 9.8, "k_chain_decode_rank_wg": 12.9, "k_chain_lds": 27.0,
                        "k_chain_decode_rank": 14.0, "k_chain_decode_rank_big": 14.0, "k_chain_stream": 40.0,
-                       "k_chain_rank_enc_multi": 15.0}  # _multi: 9.8 of the main phase + the per-line table build
+                       "k_chain_rank_enc_multi": 15.0}  # _multi: 9.8 of the main phase + the per-line exchange
+LDS_CYCLES_PER_CHUNK_LINE = {"k_chain_rank_enc": 9.7, "k_chain_decode_rank_wg": 7.4, "k_chain_decode_rank": 7.4,
+                             "k_chain_decode_rank_big": 7.4, "k_chain_rank_enc_multi": 9.7}
 
 
 def launch_ranks(n):
@@ -520,10 +527,16 @@ def main():
         # per step: a job that runs as several batches of blocks launches a stage several times a step
         stages_step = {k: round(v[0] / steps, 4) for k, v in timing.items() if v[1]}
         launches = {"encode": enc_n / steps, "decode": dec_n / steps}
-        # instruction-issue model of that launch: chunk-lines x VALU per chunk-line x 4 cycles / all SIMDs
+        # issue model of that launch: the slower of the vector-issue pipe (all SIMDs) and the LDS pipe (the CUs that
+        # hold a workgroup: one per block up to the chip's 256)
         chunk_lines = float(res.n_wah_lines) * ((N + 63) // 64) / launches_per_step
         vpc = VALU_PER_CHUNK_LINE.get(kname)
-        model_ms = chunk_lines * vpc * CYCLES_PER_VALU / (SIMDS * MODEL_CLOCK_HZ) * 1e3 if vpc else None
+        lpc = LDS_CYCLES_PER_CHUNK_LINE.get(kname)
+        valu_ms = chunk_lines * vpc * CYCLES_PER_VALU / (SIMDS * MODEL_CLOCK_HZ) * 1e3 if vpc else None
+        wgs_per_block = max(1, (N + 65535) // 65536) if kname == "k_chain_rank_enc_multi" else 1
+        cus_busy = min(256.0, float(int(n_blocks / max(launches_per_step, 1))) * wgs_per_block)
+        lds_ms = chunk_lines * lpc / (cus_busy * MODEL_CLOCK_HZ) * 1e3 if lpc else None
+        model_ms = max(x for x in (valu_ms, lds_ms) if x is not None) if (valu_ms or lds_ms) else None
         # HBM bytes of that kernel from the PMC passes kept under profiles/ (separate --pmc FETCH_SIZE /
         # WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 note in
         # MI355X_MICROARCH.md); labelled with the commit they were taken at, null for other workloads
@@ -559,9 +572,12 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
-                         "issue_model": {"what": "vector-instruction issue bound of this launch: chunk-lines x VALU per "
-                                                 "64-haplotype chunk per line x 4 cycles / (1024 SIMDs x 2.4 GHz)",
-                                         "valu_per_chunk_line": vpc, "model_ms": model_ms,
+                         "issue_model": {"what": "floor of this launch: max(vector issue: chunk-lines x VALU per 64-haplotype chunk "
+                                                 "per line x 2.8 cycles / (1024 SIMDs x 2.4 GHz), LDS pipe: chunk-lines x LDS array "
+                                                 "cycles per chunk-line (random ds_read_b64 gather 7.1 + deposits) / (busy CUs x 2.4 GHz))",
+                                         "valu_per_chunk_line": vpc, "lds_cycles_per_chunk_line": lpc, "busy_cus": cus_busy,
+                                         "valu_ms": valu_ms, "lds_ms": lds_ms, "model_ms": model_ms,
+                                         "bound": ("lds" if (lds_ms or 0) >= (valu_ms or 0) else "valu") if model_ms else None,
                                          "achieved_over_model": (model_ms / kern_ms) if model_ms and kern_ms else None},
                          "chain_encode_ms": enc_ms, "chain_decode_ms": dec_ms,
                          "pipeline_achieved_GBps": pipeline_gbs, "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,

@@ -611,6 +611,7 @@ struct RankEncMulti2Args {
     const uint32_t* wah_lines;
     const uint32_t* src;
     uint32_t src_stride_w;
+    const uint32_t* cnt;    // ones of every binary line (the classification's counts)
     uint32_t* dst;          // permuted rows y by rank
     uint32_t dst_stride_w;  // words per row
     uint32_t N;
@@ -694,7 +695,9 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi2(const EncBlock* 
             t_prof = now;
         }
     };
-    auto exchange = [&](uint32_t rank, uint32_t seq, uint32_t& Zout) -> bool {
+    // `dense`: the lists of this row name its ZEROS (a row with more ones than zeros publishes the shorter list;
+    // the owners complement their slices)
+    auto exchange = [&](uint32_t rank, uint32_t seq, bool dense, uint32_t& Zout) -> bool {
         const uint32_t par = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seq & 1u));
         prof(0);  // main phase + publish
         lds_barrier();  // every wave's list stores have been waited for (publish), its length is in wtot[32 + wave]
@@ -776,16 +779,22 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi2(const EncBlock* 
         prof(3);  // barrier behind the lists
         // ---- B: my slice -> table entries
         uint32_t ones_slice;
+        uint2 row_words;
         uint32_t tid_here = tid;
         asm volatile("" : "+v"(tid_here));  // addresses are formed here, not kept (spilled) across the lines
         {
-            const uint2 v = *reinterpret_cast<const uint2*>(slice + 2u * tid_here);
+            uint2 v = *reinterpret_cast<const uint2*>(slice + 2u * tid_here);
             *reinterpret_cast<uint2*>(slice + 2u * tid_here) = make_uint2(0u, 0u);
+            if (dense) {  // the deposits were the row's zeros: complement, positions at or beyond N stay zero
+                const uint32_t p0 = (member * SL_WORDS + 2u * tid_here) * 32u;
+                const uint32_t m0 = p0 + 32u <= N ? ~0u : (p0 >= N ? 0u : (1u << (N - p0)) - 1u);
+                const uint32_t m1 = p0 + 64u <= N ? ~0u : (p0 + 32u >= N ? 0u : (1u << (N - p0 - 32u)) - 1u);
+                v.x = ~v.x & m0;
+                v.y = ~v.y & m1;
+            }
             const uint32_t c = (uint32_t)__popc(v.x) + (uint32_t)__popc(v.y);
             const uint32_t inc = wave_scan_incl_dpp(c);
             if (lane == 63u) wtot[w] = inc;
-            const uint32_t roww = member * SL_WORDS + 2u * tid_here;  // rows are whole 16-byte units
-            if (roww < A.dst_stride_w) *reinterpret_cast<uint2*>(A.dst + (size_t)rank * A.dst_stride_w + roww) = v;
             lds_barrier();
             const uint32_t sc = row16_scan_incl(lane < W ? wtot[lane] : 0u);
             ones_slice = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
@@ -797,10 +806,15 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi2(const EncBlock* 
             ent[2] = v.y;
             ent[3] = pre0 + (uint32_t)__popc(v.x);
             __builtin_amdgcn_raw_buffer_store_b128(ent, rs_slices, tid_here * 16u, (par * A.S + member) * 16384u, 0);
+            row_words = v;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my entries have left
         __syncthreads();
         if (tid == 0) *reinterpret_cast<volatile uint64_t*>(gsflags + par * 8u + member) = ((uint64_t)seq << 32) | ones_slice;
+        {   // my part of the row for the WAH pass: behind the flag, nobody in the chain waits for this store
+            const uint32_t roww = member * SL_WORDS + 2u * tid_here;  // rows are whole 16-byte units
+            if (roww < A.dst_stride_w) *reinterpret_cast<uint2*>(A.dst + (size_t)rank * A.dst_stride_w + roww) = row_words;
+        }
         prof(4);  // slice scanned, stored, flagged
         // ---- S2: every member's slice
         uint32_t tot_l;
@@ -911,17 +925,34 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi2(const EncBlock* 
             if (lane == 0) wtot[32u + w] = n_out;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
+        // a row with more ones than zeros travels as the list of its zeros: on such a line the flags are the
+        // complement of the input bits, restricted to the haplotypes that exist
+        const uint32_t full_chunks = N >> 6, rem_bits = N & 63u;
+        auto is_dense = [&](uint32_t line) -> bool { return as_const(A.cnt)[line] * 2u > N; };
+        auto complement = [&](uint64_t x, uint32_t chunk) -> uint64_t {
+            uint32_t fc = full_chunks;
+            asm volatile("" : "+s"(fc));  // the mask is formed where it is used (hoisted for all 64 chunks it spills 128 SGPRs)
+            const uint64_t vm = chunk < fc ? ~0ull : (chunk == fc && rem_bits ? (1ull << rem_bits) - 1ull : 0ull);
+            return ~x & vm;
+        };
         uint32_t lane_here = lane;
         asm volatile("" : "+v"(lane_here));  // the identity ranks are formed in this block's code, not kept across the blocks
         // line 0: ranks are the identity, its row is the input row itself
         ++seq;
         open_list(seq);
+        bool dense_next = is_dense(lines[0]);
         {
             const v4u rs0 = in_rsrc(lines[0]);
             static_for<0, E / G>([&](auto gc) {
                 constexpr int g0 = decltype(gc)::value * G;
                 uint64_t x0[G];
                 sbuf_load_chunks<G>(rs0, c0 + (uint32_t)g0, x0);
+                if (dense_next) {
+                    static_for<0, G>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        x0[e] = complement(x0[e], c0 + (uint32_t)(g0 + e));
+                    });
+                }
                 static_for<0, G>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
                     append(x0[e], (c0 + (uint32_t)(g0 + e)) * 64u + lane_here);  // bits at or beyond N are zero
@@ -931,7 +962,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi2(const EncBlock* 
             publish();
         }
         uint32_t Z = 0;
-        if (!exchange(wah_first, seq, Z)) return;
+        if (!exchange(wah_first, seq, dense_next, Z)) return;
         uint32_t r[E];
         static_for<0, E>([&](auto ec) {
             constexpr int e = decltype(ec)::value;
@@ -948,6 +979,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi2(const EncBlock* 
             const v4u rsc = in_rsrc(lines[j]);
             v4u rsn = in_rsrc(lines[more ? j + 1u : j]);
             if (!more) rsn[2] = 0;  // nothing follows the block's last line: an empty range reads as zeros, no appends
+            dense_next = more && is_dense(lines[j + 1u]);
             open_list(seq + 1u);
             static_for<0, E / G>([&](auto gc) {
                 constexpr int g0 = decltype(gc)::value * G;
@@ -959,6 +991,12 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi2(const EncBlock* 
                     constexpr int e = decltype(ec)::value;
                     pr[e] = *reinterpret_cast<const LdsU2*>((uintptr_t)(((r[g0 + e] >> 2) & 0x1FFF8u) + tab_lds));
                 });
+                if (dense_next) {
+                    static_for<0, G>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        xn[e] = complement(xn[e], c0 + (uint32_t)(g0 + e));
+                    });
+                }
                 static_for<0, G>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
                     const uint32_t rr = r[g0 + e];
@@ -973,7 +1011,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi2(const EncBlock* 
             if (more) {
                 publish();
                 ++seq;
-                if (!exchange(wah_first + j + 1u, seq, Z)) return;
+                if (!exchange(wah_first + j + 1u, seq, dense_next, Z)) return;
             }
         }
         __syncthreads();  // the next block's first table must not overtake this block's last gathers
@@ -992,6 +1030,7 @@ static hipError_t launch_rank_encode_multi2(hipStream_t s, const EncBlock* block
     A.wah_lines = L.wah_lines;
     A.src = L.planes;
     A.src_stride_w = L.plane_stride_w;
+    A.cnt = L.cnt;
     A.dst = reinterpret_cast<uint32_t*>(L.yrows);
     A.dst_stride_w = L.y_stride64 * 2u;
     A.N = L.N;
