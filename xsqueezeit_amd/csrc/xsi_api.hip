@@ -616,8 +616,18 @@ int xsi_hip_decode_packed(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_le
         uint64_t max_batch = ws_budget_now(ctx) / (per_block ? per_block : 1);
         if (max_batch < 1) max_batch = 1;
         if (n_blocks64 > max_batch) {
-            const uint64_t n_batches = (n_blocks64 + max_batch - 1) / max_batch;
-            batch_blocks = (n_blocks64 + n_batches - 1) / n_batches;
+            // Long rows are decoded by several workgroups per block (16 at 500 000 haplotypes), one per CU: a batch of
+            // 51 blocks is 3.2 rounds of the chip and costs four.  Batches of whole rounds (multiples of 256 / 16 blocks)
+            // with the remainder last: 64 + 64 + 25 blocks = 10 rounds instead of 3 x 4.
+            const uint32_t yps = (uint32_t)((((N64 + 31u) / 32u) + 1u) & ~1ull);
+            const uint64_t wgs = rank_decode_big_wgs_per_block((uint32_t)N64, yps);
+            const uint64_t quantum = wgs > 1 ? (256u / wgs ? 256u / wgs : 1u) : 1u;
+            if (quantum > 1 && max_batch >= quantum) {
+                batch_blocks = max_batch / quantum * quantum;
+            } else {
+                const uint64_t n_batches = (n_blocks64 + max_batch - 1) / max_batch;
+                batch_blocks = (n_blocks64 + n_batches - 1) / n_batches;
+            }
         }
     }
     uint64_t rows_done = 0;

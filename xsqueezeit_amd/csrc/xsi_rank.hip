@@ -2,6 +2,8 @@
 // Split from xsi_kernels.hip so the two big kernel families compile in parallel.
 #include "xsi_kernels.hpp"
 
+#include <cstdio>
+
 #include <cstdlib>
 #include <type_traits>
 
@@ -56,6 +58,8 @@ struct RankArgs {
     const uint2* yc;            // [rank][yc_stride] chunks
     const uint16_t* ypre;       // [rank][yc_stride]
     uint32_t yc_stride;
+    uint32_t big_splits, big_n_blocks;  // k_chain_decode_rank_big: workgroups per block, blocks of the launch
+    uint32_t big_prof;
 };
 
 constexpr int RANK_RP = 8;  // {bits, prefix} pairs a thread carries while a batch is in flight
@@ -265,21 +269,29 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
 // (up to 160 KB), the next row prefetched into registers (RP pairs per thread) while the current
 // one is used.  A gather from LDS serves 64 lanes in a few cycles; the same gather from L2 is one
 // request per lane (~1 lane per clock per CU), which is what bounded the unstaged path.  Each
-// workgroup covers 16*E chunks of haplotypes; grid = (splits, blocks) so the splits of one block
-// are dispatched together and share the row through L2.
+// workgroup covers 16*E chunks of haplotypes; the splits of one block are dispatched 8 workgroup ids apart, i.e. to
+// the same XCD, and share the row through that XCD's L2 (see the kernel's first lines).
+__device__ unsigned long long g_big_prof[4];  // XSI_BIG_PROF: 100 MHz ticks of workgroup 0, wave 0: main, barrier, row to LDS + stores + barrier
+
 template <int E, int RP>
 __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
     constexpr int T = 1024, W = 16, G = 8;  // G: gathers in flight per wave
     static_assert(E % G == 0, "E must be a multiple of the gather group");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const DecBlock& D = A.blocks[blockIdx.y];
+    // Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has its own L2.  The splits of
+    // a block all stage the same 125 KB row per line: spread over the XCDs (a (splits, blocks) grid does that) each
+    // L2 fetches the row from memory for itself; taken 8 ids apart they share one L2 and the row is fetched once.
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t blk_split = slot % A.big_splits, blk_y = (slot / A.big_splits) * 8u + xcd;
+    if (blk_y >= A.big_n_blocks) return;
+    const DecBlock& D = A.blocks[blk_y];
     if (D.error || D.n_wah == 0 || D.off_line_haploid != VAL_UNDEFINED) return;
     const uint32_t N = A.N;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t cg0 = (blockIdx.x * W + w) * E;  // first chunk of my wave
-    const uint32_t wah_first = A.ph_start ? A.ph_start[blockIdx.y] : D.wah_first;
-    const uint32_t n_wah = A.ph_start ? A.ph_cnt[blockIdx.y] : D.n_wah;
+    const uint32_t cg0 = (blk_split * W + w) * E;  // first chunk of my wave
+    const uint32_t wah_first = A.ph_start ? A.ph_start[blk_y] : D.wah_first;
+    const uint32_t n_wah = A.ph_start ? A.ph_cnt[blk_y] : D.n_wah;
     if (n_wah == 0) return;  // no line of this block in this range: its ranks stay parked
     const uint32_t CWP = A.yp_stride;
     uint2* row = reinterpret_cast<uint2*>(smem);
@@ -287,7 +299,7 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
     using LdsPairBig = __attribute__((address_space(3))) rank_u32x2;
 
     uint32_t r[E];
-    uint32_t* park = A.state + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (uint32_t)E) * T + tid;  // chunk e: park[e * T]
+    uint32_t* park = A.state + (((size_t)blk_y * A.big_splits + blk_split) * (uint32_t)E) * T + tid;  // chunk e: park[e * T]
     // the block's first line is in this range: identity; else the ranks parked by the launch of the range before
     // (a short block has empty ranges: "first" and "last" are the block's own, not the launch's)
     if (!A.ph_start || wah_first == D.wah_first) {
@@ -321,28 +333,42 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
     const bool tail_fits = (A.out_stride_w & 1u) == 0u && row_chunks - tail_cg0 <= 64u;
     const bool store_lane = (lane < (uint32_t)E && cg0 + lane < nch) ||
                             (owns_tail && tail_fits && cg0 + lane >= nch && cg0 + lane < row_chunks);
-    const bool pad_writer = blockIdx.x == 0 && A.out_stride_w > row_words && !tail_fits;
+    const bool pad_writer = blk_split == 0 && A.out_stride_w > row_words && !tail_fits;
 
-    uint2 R[RP];
+    // the row travels as 16-byte pieces (two pairs): 8-byte accesses reach 0.54-0.70 of the 16-byte rate on this chip
+    // (MI355X_MICROARCH.md); rows are whole 16-byte units (yp_stride is even)
+    static_assert(RP % 2 == 0, "pairs are staged two at a time");
+    typedef uint32_t row_u32x4 __attribute__((ext_vector_type(4)));
+    row_u32x4 R[RP / 2];
+    const uint32_t CWP2 = CWP / 2u;
     auto load_row = [&](uint32_t j) {
-        const uint2* src = A.yp + (size_t)(wah_first + j) * CWP;
+        const row_u32x4* src = reinterpret_cast<const row_u32x4*>(A.yp + (size_t)(wah_first + j) * CWP);
 #pragma unroll
-        for (int q = 0; q < RP; ++q) {
+        for (int q = 0; q < RP / 2; ++q) {
             const uint32_t idx = (uint32_t)q * T + tid;
-            R[q] = src[idx < CWP ? idx : 0u];  // unconditional: stays in flight across the line; store_row keeps to the row
+            R[q] = src[idx < CWP2 ? idx : 0u];  // unconditional: stays in flight across the line; store_row keeps to the row
         }
     };
     auto store_row = [&]() {
 #pragma unroll
-        for (int q = 0; q < RP; ++q) {
+        for (int q = 0; q < RP / 2; ++q) {
             const uint32_t idx = (uint32_t)q * T + tid;
-            if (idx < CWP) row[idx] = R[q];
+            if (idx < CWP2) reinterpret_cast<row_u32x4*>(row)[idx] = R[q];
         }
     };
     load_row(0);
     store_row();
     uint32_t line = A.wah_lines[wah_first], Z = A.wah_z[wah_first];
     __syncthreads();
+    const bool prof_on = A.big_prof && blockIdx.x == 0 && w == 0u;
+    uint64_t t_prof = prof_on ? wall_clock64() : 0;
+    auto prof = [&](int i) {
+        if (prof_on) {
+            const uint64_t now = wall_clock64();
+            if (lane == 0) atomicAdd(&g_big_prof[i], (unsigned long long)(now - t_prof));
+            t_prof = now;
+        }
+    };
     for (uint32_t j = 0; j < n_wah; ++j) {
         // unconditional prefetch (the last line fetches its own row again), see k_chain_decode_rank_wg
         const uint32_t jn = j + 1u < n_wah ? j + 1u : j;
@@ -378,7 +404,9 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
         // The single row buffer is rewritten between two barriers; the output stores come after that, so that the
         // wait for the prefetched row does not also wait for them (loads and stores return in order on one counter).
         const size_t orow_w = (size_t)line * A.out_stride_w;
+        prof(0);
         __syncthreads();  // everyone is done with the row
+        prof(1);
         store_row();
         line = (uint32_t)__builtin_amdgcn_readfirstlane((int)line_n);
         Z = (uint32_t)__builtin_amdgcn_readfirstlane((int)Z_n);
@@ -390,6 +418,7 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
         if (pad_writer)
             for (uint32_t i = row_words + tid; i < A.out_stride_w; i += T) A.out[orow_w + i] = 0;
         __syncthreads();
+        prof(2);
     }
     if (A.ph_start && wah_first + n_wah != D.wah_first + D.n_wah) {
         static_for<0, E>([&](auto ecn) {
@@ -656,7 +685,7 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) 
     const uint32_t RP = A.yp_stride <= 8u * 1024u ? 8u : (A.yp_stride <= 16u * 1024u ? 16u : 20u);
     // every workgroup of a block stages the whole rank-select row of each line: the fewer workgroups per block
     // (the more chunks per wave) the less of that, as long as the launch still fills the chip
-    const uint32_t e_max = RP == 20u ? 16u : (RP == 16u ? 32u : 64u);  // <64, 16> spills 60 VGPRs
+    const uint32_t e_max = RP == 20u ? 16u : 64u;  // <64, 16> fits since the row travels as 16-byte pieces (it spilled 60 VGPRs)
     uint32_t E = 8;
     for (uint32_t e : {64u, 32u, 16u})
         if (e <= e_max && (uint64_t)n_blocks * splits_of(e) >= 224u) {
@@ -669,7 +698,17 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) 
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank_big<EE, RR>),  \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
         if (e != hipSuccess) return e;                                                                       \
-        k_chain_decode_rank_big<EE, RR><<<dim3(splits_of(EE), n_blocks), dim3(1024), lds, s>>>(A);           \
+        A.big_splits = splits_of(EE);                                                                        \
+        A.big_n_blocks = n_blocks;                                                                           \
+        A.big_prof = getenv("XSI_BIG_PROF") ? 1u : 0u;                                                       \
+        k_chain_decode_rank_big<EE, RR><<<dim3(splits_of(EE) * ((n_blocks + 7u) & ~7u)), dim3(1024), lds, s>>>(A); \
+        if (A.big_prof) {                                                                                    \
+            unsigned long long pr[4] = {0, 0, 0, 0};                                                         \
+            (void)hipStreamSynchronize(s);                                                                   \
+            (void)hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_big_prof), sizeof(pr));                               \
+            fprintf(stderr, "[xsi big prof] E=%d cumulative: main %.2f ms, barrier %.2f ms, row to LDS + stores + barrier %.2f ms\n", EE, \
+                    pr[0] * 1e-5, pr[1] * 1e-5, pr[2] * 1e-5);                                                \
+        }                                                                                                    \
         return hipGetLastError();                                                                            \
     }
     XSI_BIG_CASE(8, 8)
@@ -679,10 +718,25 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) 
     XSI_BIG_CASE(8, 16)
     XSI_BIG_CASE(16, 16)
     XSI_BIG_CASE(32, 16)
+    XSI_BIG_CASE(64, 16)
     XSI_BIG_CASE(8, 20)
     XSI_BIG_CASE(16, 20)
 #undef XSI_BIG_CASE
     return hipErrorInvalidValue;
+}
+
+// workgroups per block of the long-row kernel at its usual geometry (enough blocks to fill the chip): what a caller
+// that cuts a job into batches of blocks rounds the batches to, so that the last round of a launch is a full one
+uint32_t rank_decode_big_wgs_per_block(uint32_t N, uint32_t yp_stride) {
+    if (N <= 65536u) return 1u;
+    const uint32_t nch = (N + 63u) / 64u;
+    const uint32_t RP = yp_stride <= 8u * 1024u ? 8u : (yp_stride <= 16u * 1024u ? 16u : 20u);
+    uint32_t e_max = RP == 20u ? 16u : 64u;
+    if (const char* e = getenv("XSI_DEC_BIG_E")) {
+        const uint32_t v = (uint32_t)atoi(e);
+        if ((v == 8u || v == 16u || v == 32u || v == 64u) && v <= e_max) e_max = v;
+    }
+    return (nch + 16u * e_max - 1u) / (16u * e_max);
 }
 
 // one workgroup per block: batches with about as many blocks as CUs, rows that fit a 16 KiB LDS slot
