@@ -209,15 +209,24 @@ int xsi_hip_make_header(const xsi_header_fields* f, uint8_t h[256]) {
 
 namespace xsi {
 
-uint64_t ws_budget_now(const xsi_hip_ctx* c) {
+uint64_t ws_budget_now(const xsi_hip_ctx* c, const char* grown) {
     if (c->ws_budget) return c->ws_budget;
     if (const char* e = getenv("XSI_WS_BUDGET_MB")) return (uint64_t)strtoull(e, nullptr, 10) << 20;
-    // what is free now plus what this context already holds and will reuse
+    // half of what is free now plus what this context already holds and will reuse - but never more than the buffer
+    // that takes the per-line rows (`grown`: it is freed before it is allocated again) can actually get
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 8ull << 30;
-    uint64_t held = 0;
-    for (auto& kv : c->bufs) held += kv.second.cap;
-    return (uint64_t)((free_b + held) * 0.5);
+    uint64_t held = 0, own = 0;
+    for (auto& kv : c->bufs) {
+        held += kv.second.cap;
+        if (grown && kv.first == grown) own = kv.second.cap;
+    }
+    uint64_t b = (uint64_t)((free_b + held) * 0.5);
+    if (grown) {
+        const uint64_t reach = (uint64_t)((free_b + own) * 0.85);
+        if (b > reach) b = reach;
+    }
+    return b;
 }
 
 void stage_mark(xsi_hip_ctx* c, int stage) {
@@ -256,7 +265,7 @@ int ws_ensure(xsi_hip_ctx* c, const char* name, size_t bytes, void** out) {
         if (b.p) (void)hipFree(b.p);
         b.p = nullptr;
         b.cap = 0;
-        const size_t want = bytes + bytes / 8 + 256;
+        const size_t want = bytes + (bytes / 8 < (256u << 20) ? bytes / 8 : (size_t)(256u << 20)) + 256;  // room to grow, at most 256 MiB of it
         e = hipMalloc(&b.p, want);
         if (e != hipSuccess) return set_error(XSI_ERR_HIP, "hipMalloc(%zu) for %s: %s", want, name, hipGetErrorString(e));
         b.cap = want;
@@ -315,7 +324,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     WS(L.wah_off, "enc.wah_off", 4ull * n_bin);
     L.y_stride64 = y_stride64_for(N);
     const size_t y_rows = L.y_rows ? L.y_rows : n_bin;  // one per WAH line: exact when the caller counted them
-    WS(L.yrows, "enc.yrows", 8ull * L.y_stride64 * y_rows);
+    WS(L.yrows, "ws.rows", 8ull * L.y_stride64 * y_rows);  // one buffer with the decode's expanded rows: a context runs one call at a time
     if (N > 65536u && N <= 524288u) {  // the chain over several workgroups per block
         WS(L.chain_sync, "enc.chain_sync", 4ull * CHAIN_SYNC_TOTAL_WORDS);
         WS(L.chain_lists, "enc.chain_lists", 4ull * CHAIN_LIST_WORDS);
@@ -465,7 +474,7 @@ int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const vo
     // (gt_block.hpp:179-180, xsi_factory.hpp:527-539), so the bytes are those of a single call.
     const bool units = wah_units_any(y_stride64_for(N));
     const uint64_t y_line = 8ull * y_stride64_for(N), scratch_line = units ? 0 : 2ull * (((N + 14u) / 15u + 3u) & ~1u), misc_line = 40;
-    const uint64_t budget = ws_budget_now(ctx);
+    const uint64_t budget = ws_budget_now(ctx, "ws.rows");
     uint64_t wah_all = 0;
     for (uint32_t c : wah_per_block) wah_all += c;
     const bool use_scratch = (y_line + scratch_line) * wah_all + misc_line * n_lines <= budget;
@@ -601,7 +610,8 @@ int xsi_hip_decode_packed(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_le
     hipStream_t s = ctx->stream;
     // Per-line workspace of the decode is the expanded row of every WAH line ({bits, prefix} pairs, N/4
     // bytes); a block range that needs more than the budget is decoded as batches of whole blocks.
-    uint64_t batch_blocks = n_blocks64;
+    std::vector<uint64_t> cuts;  // batch k = blocks [cuts[k], cuts[k + 1])
+    cuts.push_back(0);
     {
         uint8_t h[256];
         HIP_TRY(hipMemcpyAsync(h, d_file, 256, hipMemcpyDeviceToHost, s));
@@ -612,27 +622,44 @@ int xsi_hip_decode_packed(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_le
             return v;
         };
         const uint64_t ns = get(112, 8), N64 = ns ? ns * 2 : get(32, 8), bl = get(56, 4) ? get(56, 4) : 8192;
-        const uint64_t per_block = (16ull * ((N64 + 63u) / 64u) + 64u) * bl;
-        uint64_t max_batch = ws_budget_now(ctx) / (per_block ? per_block : 1);
-        if (max_batch < 1) max_batch = 1;
-        if (n_blocks64 > max_batch) {
-            // Long rows are decoded by several workgroups per block (16 at 500 000 haplotypes), one per CU: a batch of
-            // 51 blocks is 3.2 rounds of the chip and costs four.  Batches of whole rounds (multiples of 256 / 16 blocks)
-            // with the remainder last: 64 + 64 + 25 blocks = 10 rounds instead of 3 x 4.
+        const uint64_t per_line = 16ull * ((N64 + 63u) / 64u) + 64u;
+        const uint64_t budget = ws_budget_now(ctx, "ws.rows");
+        if (n_blocks64 * per_line * bl > budget && n_blocks64 > 1) {
+            // The worst case (every line a WAH line) does not fit: take the blocks' actual WAH line counts (one parse
+            // of the dictionaries and flag vectors, no expansion) and cut batches that fit.
+            // Long rows are decoded by several workgroups per block (8 at 500 000 haplotypes), one per CU: batches of
+            // whole rounds of the chip (multiples of 256 / 8 blocks) leave no half-empty last round, the remainder
+            // comes last.
+            std::vector<uint32_t> n_wah(n_blocks64);
+            {
+                DecodePlan plan;
+                int rc = decode_prepare(ctx, d_file, file_len, first_block, n_blocks64, &plan);
+                if (rc) return rc;
+                for (uint64_t b = 0; b < n_blocks64; ++b) n_wah[b] = plan.blocks_h[b].n_wah;
+            }
             const uint32_t yps = (uint32_t)((((N64 + 31u) / 32u) + 1u) & ~1ull);
             const uint64_t wgs = rank_decode_big_wgs_per_block((uint32_t)N64, yps);
-            const uint64_t quantum = wgs > 1 ? (256u / wgs ? 256u / wgs : 1u) : 1u;
-            if (quantum > 1 && max_batch >= quantum) {
-                batch_blocks = max_batch / quantum * quantum;
-            } else {
-                const uint64_t n_batches = (n_blocks64 + max_batch - 1) / max_batch;
-                batch_blocks = (n_blocks64 + n_batches - 1) / n_batches;
+            const uint64_t quantum = wgs > 1 && 256u / wgs > 1u ? 256u / wgs : 1u;
+            uint64_t b0 = 0;
+            while (b0 < n_blocks64) {
+                uint64_t need = 0, nb = 0, best = 0;
+                while (b0 + nb < n_blocks64 && need + (uint64_t)n_wah[b0 + nb] * per_line <= budget) {
+                    need += (uint64_t)n_wah[b0 + nb] * per_line;
+                    ++nb;
+                    if (nb % quantum == 0) best = nb;
+                }
+                if (b0 + nb == n_blocks64 || best == 0) best = nb ? nb : 1;  // the tail, or fewer blocks fit than a round holds
+                b0 += best;
+                cuts.push_back(b0);
             }
+        } else {
+            cuts.push_back(n_blocks64);
         }
     }
     uint64_t rows_done = 0;
-    for (uint64_t b0 = 0; b0 < n_blocks64 || b0 == 0; b0 += batch_blocks) {
-        const uint64_t nb = b0 + batch_blocks <= n_blocks64 ? batch_blocks : n_blocks64 - b0;
+    for (size_t k = 0; k + 1 < cuts.size() || k == 0; ++k) {
+        const uint64_t b0 = cuts[k];
+        const uint64_t nb = (k + 1 < cuts.size() ? cuts[k + 1] : n_blocks64) - b0;
         DecodePlan P;
         int rc = decode_prepare(ctx, d_file, file_len, first_block + b0, nb, &P);
         if (rc) return rc;
@@ -817,7 +844,7 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
             P->has_side = true;
     L.y_stride64 = (L.N + 63u) / 64u;
     L.yp_stride = L.y_stride64 * 2u;
-    WS(L.yp, "dec.yp", 8ull * L.yp_stride * (size_t)(P->n_wah ? P->n_wah : 1));
+    WS(L.yp, "ws.rows", 8ull * L.yp_stride * (size_t)(P->n_wah ? P->n_wah : 1));  // shared with the encode's permuted rows
     WS(L.wah_z, "dec.wah_z", 4ull * (P->n_wah ? P->n_wah : 1) + 64);
     {
         // tiles of the boundary scan (2048 WAH words each)

@@ -118,7 +118,7 @@ bool pack_bit_row(const int32_t* gt, uint32_t n, int dp, uint8_t* out);
 int expand_bit_rows(xsi_hip_ctx* ctx, const uint8_t* d_bits, uint32_t bit_stride, const uint8_t* d_fast, int32_t* d_rows,
                     uint64_t N, uint64_t n_lines, int32_t default_phased);
 // bytes of per-line workspace budget in force for a call made now
-uint64_t ws_budget_now(const xsi_hip_ctx* ctx);
+uint64_t ws_budget_now(const xsi_hip_ctx* ctx, const char* prefix = nullptr);
 int encode_side_write(xsi_hip_ctx* ctx, const EncBlock* d_blocks, uint32_t n_blocks, const EncLines& L,
                       const EncSide& S, uint8_t* out, const uint64_t* d_result);
 

@@ -2903,14 +2903,23 @@ __global__ void __launch_bounds__(1024) k_wah_expand_wide(const uint8_t* __restr
         }
     }
     __syncthreads();
-    const uint32_t stripes = (L.yp_stride + 1023u) / 1024u;  // <= WAH_WIDE_STRIPES
-    uint32_t excl[WAH_WIDE_STRIPES];
+    // thread t works on words 2 t, 2 t + 1 of a stripe of 2048 words: its two pairs leave as ONE 16-byte store
+    // (8-byte accesses reach 0.54-0.70 of the 16-byte rate on this chip, MI355X_MICROARCH.md; yp_stride is even)
+    constexpr int STR2 = WAH_WIDE_STRIPES / 2;
+    const uint32_t stripes = (L.yp_stride + 2047u) / 2048u;  // <= STR2
+    uint32_t excl[STR2], w0s[STR2], w1s[STR2];
 #pragma unroll
-    for (int i = 0; i < WAH_WIDE_STRIPES; ++i) {
+    for (int i = 0; i < STR2; ++i) {
         excl[i] = 0;
+        w0s[i] = w1s[i] = 0;
         if ((uint32_t)i < stripes) {  // uniform
-            const uint32_t idx = (uint32_t)i * 1024u + tid;
-            const uint32_t c = (uint32_t)__popc(idx < rw ? row[idx] : 0u);
+            const uint32_t idx = (uint32_t)i * 2048u + 2u * tid;
+            if (idx < rw) {  // rw is even
+                const uint2 v = *reinterpret_cast<const uint2*>(row + idx);
+                w0s[i] = v.x;
+                w1s[i] = v.y;
+            }
+            const uint32_t c = (uint32_t)__popc(w0s[i]) + (uint32_t)__popc(w1s[i]);
             const uint32_t inc = wave_scan_incl_dpp(c);
             excl[i] = inc - c;
             if (lane == 63u) tot[i * 16 + (int)w] = inc;
@@ -2918,7 +2927,7 @@ __global__ void __launch_bounds__(1024) k_wah_expand_wide(const uint8_t* __restr
     }
     __syncthreads();
     if (w == 0) {
-        constexpr int PER = (WAH_WIDE_STRIPES * 16 + 63) / 64;
+        constexpr int PER = (STR2 * 16 + 63) / 64;
         uint32_t a[PER], sum = 0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -2936,12 +2945,13 @@ __global__ void __launch_bounds__(1024) k_wah_expand_wide(const uint8_t* __restr
         if (lane == 63u) L.wah_z[j] = nbits - run;
     }
     __syncthreads();
-    uint2* dst = L.yp + (size_t)j * L.yp_stride;
+    uint4* dst = reinterpret_cast<uint4*>(L.yp + (size_t)j * L.yp_stride);
 #pragma unroll
-    for (int i = 0; i < WAH_WIDE_STRIPES; ++i)
+    for (int i = 0; i < STR2; ++i)
         if ((uint32_t)i < stripes) {
-            const uint32_t idx = (uint32_t)i * 1024u + tid;
-            if (idx < L.yp_stride) dst[idx] = make_uint2(idx < rw ? row[idx] : 0u, tot[i * 16 + (int)w] + excl[i]);
+            const uint32_t idx = (uint32_t)i * 2048u + 2u * tid;
+            const uint32_t pre0 = tot[i * 16 + (int)w] + excl[i];
+            if (idx < L.yp_stride) dst[idx >> 1] = make_uint4(w0s[i], pre0, w1s[i], pre0 + (uint32_t)__popc(w0s[i]));
         }
 }
 

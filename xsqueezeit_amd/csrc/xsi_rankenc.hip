@@ -285,310 +285,18 @@ hipError_t launch_rank_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_
 // of scattered traffic per line and block, one CU per block (696 ms for 153 blocks of 500 000 haplotypes,
 // at the HBM limit of that access pattern).  Element-major, a workgroup keeps 65 536 ranks in registers
 // and holds the rank-select table of ALL N positions in its LDS (8 bytes per 32 positions: 128 KiB at
-// 524 288); what the S workgroups of a block exchange per line is only where the ONES of the next line go:
-//   M  main phase as in k_chain_rank_enc, but a lane whose next-line bit is set APPENDS its new rank to its
-//      wave's list in HBM (sc1 stores; the wave's count follows);
-//      -- the workgroups of the block meet at a counter (one meeting per line) --
-//   A  every workgroup clears the bit words of its table, reads the lists of all 16 S waves (sc1 loads) and
-//      sets the bits (LDS atomic OR): each ends up with the whole permuted row y;
-//   B  popcounts + scan over the 16 K words -> the "ones before" half of the table; workgroup m also stores
-//      its 1/S of the row to HBM for the WAH pass.
-// Depositing with agent-scope atomics straight into the row in HBM (the first version of this kernel) was
-// correct and 3.6x SLOWER than k_chain_stream: 3e10 atomics per launch at the 12 G atomics/s the memory side
-// sustains.  The lists are double-buffered by line parity (a workgroup may be one meeting ahead).
-//
-// Every workgroup of the grid must be resident for the meetings to complete: the grid is at most one
-// workgroup per CU, groups walk the blocks persistently, and a meeting that does not complete within a few
-// seconds raises the abort flag, which ends every workgroup of the launch (the call then fails).
-// Placement (speed only): blocks of the grid are dealt round-robin over the 8 XCDs, so the members of a
-// group are taken 8 apart and share an XCD's L2.
-// ------------------------------------------------------------------------------------------
-constexpr uint32_t MULTI_LIST_CAP = 4096u;  // ranks per wave and line: every one of its 64 x 64 haplotypes
-
-struct RankEncMultiArgs {
-    const uint32_t* wah_lines;
-    const uint32_t* src;
-    uint32_t src_stride_w;
-    uint32_t* dst;          // permuted rows y by rank
-    uint32_t dst_stride_w;  // words per row
-    uint32_t N;
-    uint32_t n_blocks;
-    uint32_t S;             // workgroups per block
-    uint32_t gpx;           // groups per XCD slot: the grid is 8 * gpx * S workgroups
-    uint32_t* sync;         // [0] abort, [16 + g] arrivals of group g
-    uint32_t test_desert;   // testing only: member 1 of every group leaves before its first meeting (the others must time out, not hang)
-    uint32_t* lists;        // [group][parity][S * 16 waves][MULTI_LIST_CAP] ranks, whole 64-entry stores (padding: ~0)
-    uint32_t* counts;       // [group][parity][S * 16] entries of each list
-};
-
-template <int WPT>  // row words per thread when the table is built (a multiple of 4)
-__global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* __restrict__ eblocks, RankEncMultiArgs A) {
-    constexpr uint32_t T = 1024, W = 16;
-    constexpr int E = 64, G = 8;
-    constexpr uint32_t TAB_BYTES = T * (uint32_t)WPT * 8u;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint2* table = reinterpret_cast<uint2*>(smem);
-    uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + TAB_BYTES);  // [16] wave totals, [16] meeting result
-    uint32_t* ring_all = wtot + 64;                                 // [16 waves][128] ranks on their way to the lists
-    const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const uint32_t N = A.N;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
-    const uint32_t group = xcd * A.gpx + q / A.S, member = q % A.S, n_groups = 8u * A.gpx;
-    const uint32_t n_lists = A.S * W;
-    uint32_t* bar = A.sync + 16u + group;
-    uint32_t* glists = A.lists + (size_t)group * 2u * n_lists * MULTI_LIST_CAP;
-    uint32_t* gcounts = A.counts + (size_t)group * 2u * n_lists;
-    uint32_t arrivals = 0;  // what the counter reads once every member has arrived at the current meeting
-    uint32_t parity = 0;
-
-    const uint32_t row_bytes = ((N + 63u) / 64u) * 8u;  // bytes of an input row that hold haplotypes
-    auto in_rsrc = [&](uint32_t line) -> v4u {
-        const uint64_t base = reinterpret_cast<uint64_t>(A.src + (size_t)line * A.src_stride_w);
-        v4u d;
-        d[0] = (uint32_t)base;
-        d[1] = (uint32_t)(base >> 32) & 0xFFFFu;
-        d[2] = row_bytes;
-        d[3] = 0x00020000u;
-        return d;
-    };
-    // all members of the group have published their lists: true; false = the launch is aborting
-    auto meet = [&]() -> bool {
-        if (A.test_desert && member == 1u) return false;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores have left
-        __syncthreads();
-        // every wave is done with the table of the line before: its bit words are cleared here, while lane 0 waits
-        // for the other workgroups (thread t works on entries i * 1024 + t: neighbouring lanes on neighbouring
-        // entries, no bank conflicts; 16 entries in a row per thread put all 64 lanes of an access on two banks)
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) table[(size_t)i * T + tid] = make_uint2(0u, 0u);
-        arrivals += A.S;
-        if (tid == 0) {
-            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t ok = 1u, spins = 0;
-            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals) {
-                if (++spins > (1u << 21) || ((spins & 63u) == 0u && __hip_atomic_load(A.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    __hip_atomic_store(A.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0u;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            wtot[16] = ok;
-        }
-        lds_barrier();
-        return wtot[16] != 0u;
-    };
-    // phases A + B: the lists of parity `par` -> row `rank` in the table (and my share of it in HBM); returns the zeros
-    auto build_table = [&](uint32_t rank, uint32_t par) -> uint32_t {
-        // (the meeting cleared the table's bit words and ended with a barrier)
-        const uint32_t* lst = glists + (size_t)par * n_lists * MULTI_LIST_CAP;
-        // wave w applies lists w * S .. w * S + S - 1.  The loads are sc1 round trips to L2 / memory: the counts of
-        // all of them come in one load, then four 16-byte loads per lane are in flight before any is used.
-        // (Fetching the first KiB of every list blind, with the count in a header, measured no faster: 485 / 468 ms.)
-        constexpr int SMAX = 8;  // N <= 524 288
-        const uint32_t* cnts = gcounts + (size_t)par * n_lists;
-        const uint32_t cnt_l = lane < A.S ? __hip_atomic_load(cnts + w * A.S + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        uint32_t cnt[SMAX], longest = 0;
-#pragma unroll
-        for (int k = 0; k < SMAX; ++k) {
-            cnt[k] = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, k);
-            longest = cnt[k] > longest ? cnt[k] : longest;
-        }
-        for (uint32_t i0 = 0; i0 < longest; i0 += 256u) {
-#pragma unroll
-            for (int h = 0; h < SMAX; h += 4) {
-                v4u rk[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    // lists are whole 64-entry stores; beyond a list the range check returns 0, not used below
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                        (void*)(lst + (size_t)(w * A.S + (uint32_t)(h + k)) * MULTI_LIST_CAP), 0, (int)(cnt[h + k] * 4u), 0x00020000);
-                    rk[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (i0 + lane * 4u) * 4u, 0, 16);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool in = i0 + lane * 4u < cnt[h + k];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (in && rk[k][u] != ~0u) {
-                            LdsU32* p = reinterpret_cast<LdsU32*>((uintptr_t)(((rk[k][u] >> 2) & 0x1FFF8u) + tab_lds));
-                            __hip_atomic_fetch_or(p, 1u << (rk[k][u] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                }
-            }
-        }
-        lds_barrier();
-        // stripe i = entries [1024 i, 1024 i + 1024): a wave scan per stripe, then the 16 x WPT (wave, stripe) totals
-        // are scanned in row order by wave 0
-        uint32_t* tot = ring_all;  // [WPT][16]: the rings are idle between the main phases
-        {
-            uint32_t* row = A.dst + (size_t)rank * A.dst_stride_w;
-            uint32_t tid_here = tid;
-            asm volatile("" : "+v"(tid_here));  // store addresses are formed here, not kept (spilled) across the lines
-#pragma unroll
-            for (int i = 0; i < WPT; ++i) {
-                const uint32_t v = table[(size_t)i * T + tid].x;
-                // my share of the row for the WAH pass: stripes m, m + S, ... (4 KiB each, whole 256-byte stores)
-                if ((uint32_t)i % A.S == member && (uint32_t)i * T + tid_here < A.dst_stride_w) row[(uint32_t)i * T + tid_here] = v;
-                const uint32_t c = (uint32_t)__popc(v);
-                const uint32_t inc = wave_scan_incl_dpp(c);
-                table[(size_t)i * T + tid].y = inc - c;  // ones of my stripe before my entry; the stripe's base follows
-                if (lane == 63u) tot[i * (int)W + (int)w] = inc;
-            }
-        }
-        lds_barrier();
-        if (w == 0) {  // exclusive scan of the WPT * 16 totals, 4 (= WPT * 16 / 64, at most) per lane, in order
-            constexpr int PER = (WPT * (int)W + 63) / 64;
-            uint32_t a[PER], sum = 0;
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const uint32_t idx = lane * (uint32_t)PER + (uint32_t)k;
-                a[k] = idx < (uint32_t)WPT * W ? tot[idx] : 0u;
-                sum += a[k];
-            }
-            uint32_t run = wave_scan_incl_dpp(sum) - sum;
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const uint32_t idx = lane * (uint32_t)PER + (uint32_t)k;
-                if (idx < (uint32_t)WPT * W) tot[idx] = run;
-                run += a[k];
-            }
-            if (lane == 63u) wtot[17] = run;  // ones of the row
-        }
-        lds_barrier();
-#pragma unroll
-        for (int i = 0; i < WPT; ++i)
-            __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>((uintptr_t)(tab_lds + ((uint32_t)i * T + tid) * 8u + 4u)), tot[i * (int)W + (int)w],
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t ones = wtot[17];
-        lds_barrier();
-        return N - ones;
-    };
-
-    const uint32_t c0 = member * 1024u + w * (uint32_t)E;  // my first chunk of the row
-    for (uint32_t blk = group; blk < A.n_blocks; blk += n_groups) {
-        const EncBlock& B = eblocks[blk];
-        if (B.has_haploid) continue;  // the position-major kernels take the blocks with fully haploid lines
-        const uint32_t wah_first = B.wah_first, n_wah = B.n_wah;
-        if (n_wah == 0) continue;
-        const ConstU32* lines = as_const(A.wah_lines) + wah_first;
-        // Ranks on their way to my wave's list pass through a 128-entry ring in LDS, so that they leave as whole
-        // 256-byte stores (a store of one to three lanes per chunk is one fabric write per lane).
-        uint32_t n_app = 0, n_out = 0;  // ranks appended / already stored, for the line in the making (wave-uniform)
-        uint32_t* my_list = glists + ((size_t)parity * n_lists + member * W + w) * MULTI_LIST_CAP;
-        uint32_t* ring = ring_all + w * 128u;
-        auto flush64 = [&]() {
-            __hip_atomic_store(my_list + n_out + lane, ring[(n_out + lane) & 127u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            n_out += 64u;
-        };
-        auto append = [&](uint64_t xm, uint32_t rr) {
-            if (xm) {
-                if (__builtin_amdgcn_inverse_ballot_w64(xm)) {
-                    asm volatile("" : "+v"(rr));  // the slot is formed here, not hoisted for all 64 chunks at once
-                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(xm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)xm, n_app));
-                    ring[slot & 127u] = rr;
-                }
-                n_app += (uint32_t)__popcll(xm);
-                if (n_app - n_out >= 64u) flush64();
-            }
-        };
-        // the rest of the list, padded to whole 64-entry stores with entries that mean nothing (~0), and its length
-        auto publish = [&]() {
-            if (n_app != n_out) {
-                const uint32_t left = n_app - n_out;
-                __hip_atomic_store(my_list + n_out + lane, lane < left ? ring[(n_out + lane) & 127u] : ~0u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                n_out += 64u;
-            }
-            if (lane == 0)
-                __hip_atomic_store(gcounts + (size_t)parity * n_lists + member * W + w, n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        uint32_t lane_here = lane;
-        asm volatile("" : "+v"(lane_here));  // the identity ranks are formed in this block's code, not kept across the blocks
-        // line 0: ranks are the identity, its row is the input row itself
-        {
-            const v4u rs0 = in_rsrc(lines[0]);
-            static_for<0, E / G>([&](auto gc) {
-                constexpr int g0 = decltype(gc)::value * G;
-                uint64_t x0[G];
-                sbuf_load_chunks<G>(rs0, c0 + (uint32_t)g0, x0);
-                static_for<0, G>([&](auto ec) {
-                    constexpr int e = decltype(ec)::value;
-                    append(x0[e], (c0 + (uint32_t)(g0 + e)) * 64u + lane_here);  // bits at or beyond N are zero
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            publish();
-        }
-        if (!meet()) return;
-        uint32_t Z = build_table(wah_first, parity);
-        parity ^= 1u;
-        uint32_t r[E];
-        static_for<0, E>([&](auto ec) {
-            constexpr int e = decltype(ec)::value;
-            const uint32_t h = (c0 + (uint32_t)e) * 64u + lane_here;
-            r[e] = h < N ? h : 0u;
-        });
-        auto prefetch_row = [&](uint32_t line) -> uint2 {  // my workgroup's 8 KiB of the input row, into L2
-            const uint2* rowp = reinterpret_cast<const uint2*>(A.src + (size_t)line * A.src_stride_w) + member * 1024u;
-            return (member * 1024u + tid) * 8u < row_bytes ? rowp[tid] : make_uint2(0u, 0u);
-        };
-        for (uint32_t j = 0; j < n_wah; ++j) {
-            const bool more = j + 1u < n_wah;
-            const uint2 pf = prefetch_row(lines[j + 2u < n_wah ? j + 2u : j]);
-            const v4u rsc = in_rsrc(lines[j]);
-            v4u rsn = in_rsrc(lines[more ? j + 1u : j]);
-            if (!more) rsn[2] = 0;  // nothing follows the block's last line: an empty range reads as zeros, no appends
-            n_app = 0;
-            n_out = 0;
-            my_list = glists + ((size_t)parity * n_lists + member * W + w) * MULTI_LIST_CAP;
-            static_for<0, E / G>([&](auto gc) {
-                constexpr int g0 = decltype(gc)::value * G;
-                uint64_t xc[G], xn[G];
-                u32x2 pr[G];
-                sbuf_load_chunks<G>(rsc, c0 + (uint32_t)g0, xc);
-                sbuf_load_chunks<G>(rsn, c0 + (uint32_t)g0, xn);
-                static_for<0, G>([&](auto ec) {
-                    constexpr int e = decltype(ec)::value;
-                    pr[e] = *reinterpret_cast<const LdsU2*>((uintptr_t)(((r[g0 + e] >> 2) & 0x1FFF8u) + tab_lds));
-                });
-                static_for<0, G>([&](auto ec) {
-                    constexpr int e = decltype(ec)::value;
-                    const uint32_t rr = r[g0 + e];
-                    const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
-                    const uint32_t rn = __builtin_amdgcn_inverse_ballot_w64(xc[e]) ? Z + ob : rr - ob;
-                    r[g0 + e] = rn;
-                    append(xn[e], rn);
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            asm volatile("" ::"v"(pf.x), "v"(pf.y));
-            if (more) {
-                publish();
-                if (!meet()) return;
-                Z = build_table(wah_first + j + 1u, parity);
-                parity ^= 1u;
-            }
-        }
-        __syncthreads();  // the next block's first table must not overtake this block's last gathers
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// The same chain with an OWNER-COMPUTES exchange (round 3).  In the kernel above every workgroup of a block
-// applies every rank list (8 x redundant LDS atomics), scans the whole row and clears the whole table, and
-// the members meet at one counter polled by one lane: per line 7 k cycles of meeting, 18 k of lists and 6 k
-// of scan against 10.6 k for the chain itself.  Here member m OWNS the row positions [65536 m, 65536 m + 65536):
-//   M   main phase as before: a lane whose next-line bit is set appends its new rank to its wave's list;
+// 524 288); what the S workgroups ("members") of a block exchange per line is only where the ONES of the
+// next line go, and member m OWNS the row positions [65536 m, 65536 m + 65536):
+//   M   main phase as in k_chain_rank_enc, but a lane whose next-line bit is set APPENDS its new rank to its
+//       wave's list (through a 128-entry ring in LDS, so that the list leaves as whole 256-byte stores).  A row
+//       with more ones than zeros travels as the list of its ZEROS (half of all list entries come from such
+//       rows: 72 k -> 50 k entries per line on average at 500 000 haplotypes);
 //   S1  the workgroup signals its lists (one flag record per member: sequence number + the 16 list lengths,
 //       16-byte stores by one wave behind a workgroup barrier; every wave polls the records it needs);
 //   A   every workgroup reads all lists but deposits only the ranks in ITS slice (LDS atomic OR into an
-//       8 KiB slice buffer): one eighth of the atomics;
+//       8 KiB slice buffer): one eighth of the atomics of "everybody builds the whole row";
 //   B   popcounts + scan of the slice alone (two words per thread, as in k_chain_rank_enc): the slice leaves
-//       as finished {bits, ones before (inside the slice)} table entries (16 KiB, sc1) plus its ones in a flag;
+//       as finished {bits, ones before (inside the slice)} table entries (16 KiB) plus its ones in a flag;
 //   S2  every wave polls the S slice flags (8-byte sc1 loads);
 //   C   every workgroup copies the S slices into its table, adding each slice's base (ones of the slices
 //       before it): 16 bytes per thread and slice, no clear, no scan over the whole row.
@@ -599,15 +307,24 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
 // loaded with sc1 loads (past L1, served by that L2): 128 KiB written by one workgroup and read by 7 others takes
 // 1.36 us this way against 4.06 us with sc1 stores, which drop the line from L2 (profiles/r03_microbench4.txt).
 // Every storing wave waits for its stores (vmcnt(0)) in front of the workgroup barrier behind which the flag is
-// stored; a polling wave loads the bytes only after its own poll has matched.  (Per-wave flags without those
-// barriers were measured: 421 -> 576 ms at the configs[3] shard; the waves of a workgroup are better off in step.)  Sequence numbers grow by one per exchange and never repeat inside a
-// launch; lists, slices and flags are double-buffered by the sequence number's parity (a member can be at most
-// one exchange ahead of another: it needs that member's lists / slice of the exchange before).
-// A wait that does not complete within `timeout_ticks` of the 100 MHz clock raises the abort flag; every poll
-// loop looks at it, the waves leave (a barrier only waits for the waves that are left) and the host runs the
-// batch again with k_chain_stream.
+// stored; a polling wave loads the bytes only after its own poll has matched.  Sequence numbers grow by one per
+// exchange and never repeat inside a launch; lists, slices and flags are double-buffered by the sequence number's
+// parity (a member can be at most one exchange ahead of another: it needs that member's lists / slice of the
+// exchange before).
+// Every workgroup of the grid must be resident for the exchanges to complete: the grid is at most one workgroup
+// per CU and groups walk the blocks persistently.  A wait that does not complete within `timeout_ticks` of the
+// 100 MHz clock raises the abort flag; every poll loop looks at it, the waves leave (a barrier only waits for the
+// waves that are left) and the host runs the batch again with k_chain_stream (xsi_api.hip, encode_run).
+// Measured and dropped on the way (configs[3] shard, chain ms): every workgroup applying every list, scanning the
+// whole row, one counter meeting per line (round 2's form) 430; owner-computes with sc1 stores 462; plain stores
+// through the XCD's L2 421; per-WAVE flags without the two workgroup barriers 576; global atomic ORs into a row
+// bitmap in L2 instead of lists: 27 G atomics/s chip-wide whatever the scope (tools/microbench4.hip), a factor 40
+// short; lists bucketed by owner at the writer: about one instruction per entry, no fewer than the filter costs the
+// readers (6 per 64 entries x 8 readers).
 // ------------------------------------------------------------------------------------------
-struct RankEncMulti2Args {
+constexpr uint32_t MULTI_LIST_CAP = 4096u;  // ranks per wave and line: every one of its 64 x 64 haplotypes
+
+struct RankEncMultiArgs {
     const uint32_t* wah_lines;
     const uint32_t* src;
     uint32_t src_stride_w;
@@ -629,7 +346,7 @@ struct RankEncMulti2Args {
     uint64_t timeout_ticks;
 };
 
-__global__ void __launch_bounds__(1024) k_chain_rank_enc_multi2(const EncBlock* __restrict__ eblocks, RankEncMulti2Args A) {
+__global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* __restrict__ eblocks, RankEncMultiArgs A) {
     constexpr uint32_t T = 1024, W = 16;
     constexpr int E = 64, G = 8, SMAX = 8;
     constexpr uint32_t SL_WORDS = 2048u;  // row words of a slice: two per thread
@@ -1024,9 +741,8 @@ bool chain_rank_enc_multi_supported(const EncLines& L) {
            (L.y_stride64 % 2u) == 0u;
 }
 
-// Owner-computes exchange (k_chain_rank_enc_multi2); XSI_MULTI_V1 selects the first form of the kernel (A/B runs).
-static hipError_t launch_rank_encode_multi2(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L, int cus) {
-    RankEncMulti2Args A{};
+static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L, int cus) {
+    RankEncMultiArgs A{};
     A.wah_lines = L.wah_lines;
     A.src = L.planes;
     A.src_stride_w = L.plane_stride_w;
@@ -1054,9 +770,9 @@ static hipError_t launch_rank_encode_multi2(hipStream_t s, const EncBlock* block
     hipError_t e = hipMemsetAsync(L.chain_sync, 0, 4ull * CHAIN_SYNC_TOTAL_WORDS, s);
     if (e != hipSuccess) return e;
     const uint32_t lds = A.S * 16384u + 8192u + 256u + 16u * 128u * 4u;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_rank_enc_multi2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_rank_enc_multi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_chain_rank_enc_multi2<<<dim3(8u * A.gpx * A.S), dim3(1024), lds, s>>>(blocks, A);
+    k_chain_rank_enc_multi<<<dim3(8u * A.gpx * A.S), dim3(1024), lds, s>>>(blocks, A);
     return hipGetLastError();
 }
 
@@ -1067,43 +783,7 @@ hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint3
     if (e != hipSuccess) return e;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
-    if (!getenv("XSI_MULTI_V1")) return launch_rank_encode_multi2(s, blocks, n_blocks, L, cus);
-    RankEncMultiArgs A{};
-    A.wah_lines = L.wah_lines;
-    A.src = L.planes;
-    A.src_stride_w = L.plane_stride_w;
-    A.dst = reinterpret_cast<uint32_t*>(L.yrows);
-    A.dst_stride_w = L.y_stride64 * 2u;
-    A.N = L.N;
-    A.n_blocks = n_blocks;
-    A.S = (L.N + 65535u) / 65536u;
-    A.gpx = (uint32_t)cus / 8u / A.S;
-    if (A.gpx < 1u || 8u * A.gpx > CHAIN_SYNC_WORDS - 16u) return hipErrorInvalidValue;
-    while (A.gpx > 1u && 8u * (A.gpx - 1u) >= n_blocks) --A.gpx;  // no more groups than blocks need
-    A.sync = L.chain_sync;
-    A.test_desert = getenv("XSI_MULTI_TEST_DESERT") ? 1u : 0u;
-    A.counts = L.chain_sync + CHAIN_SYNC_WORDS;
-    A.lists = L.chain_lists;
-    if (8u * A.gpx * A.S > CHAIN_MAX_WGS) return hipErrorInvalidValue;
-    const uint32_t wpt = ((A.dst_stride_w + 1023u) / 1024u + 3u) & ~3u;  // 4, 8, 12 or 16
-    e = hipMemsetAsync(L.chain_sync, 0, 4ull * CHAIN_SYNC_WORDS, s);
-    if (e != hipSuccess) return e;
-    const dim3 grid(8u * A.gpx * A.S);
-#define XSI_REM_CASE(WW)                                                                                  \
-    if (wpt == WW) {                                                                                      \
-        const uint32_t lds = 1024u * WW * 8u + 256u + 16u * 128u * 4u;                                    \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_rank_enc_multi<WW>),               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
-        if (e != hipSuccess) return e;                                                                    \
-        k_chain_rank_enc_multi<WW><<<grid, dim3(1024), lds, s>>>(blocks, A);                              \
-        return hipGetLastError();                                                                         \
-    }
-    XSI_REM_CASE(4)
-    XSI_REM_CASE(8)
-    XSI_REM_CASE(12)
-    XSI_REM_CASE(16)
-#undef XSI_REM_CASE
-    return hipErrorInvalidValue;
+    return launch_rank_encode_multi_grid(s, blocks, n_blocks, L, cus);
 }
 
 }  // namespace xsi
