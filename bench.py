@@ -565,6 +565,7 @@ def main():
                                       cfg["name"] + (" x %.4g of the sites" % args.sites_fraction if strong and args.sites_fraction != 1.0 else "")),
                        "haps": N, "sites_this_gpu": S, "blocks_this_gpu": n_blocks, "block_len": bl, "mac_threshold": thr,
                        "seed": seed, "xsi_bytes_this_gpu": xsi_bytes, "bytes_per_cell": c,
+                       "wah_lines_this_gpu": int(res.n_wah_lines), "row_stride_bytes": stride,
                        "launches_per_step": launches_per_step,
                        "parallelism": "blocks sharded over %d GPU(s); RCCL gather of block streams" % world
                        if distributed else "1 GPU"},

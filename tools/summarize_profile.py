@@ -5,8 +5,10 @@ WRITE_SIZE and two SQ counter passes, all CSV) into the files kept under profile
 usage: python tools/summarize_profile.py gpurun_out r02 profiles "commit abc1234, 2026-10-04"
 
 HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB (x1024); on gfx950
-FETCH_SIZE reports half of the bytes of a coalesced streaming read, so the read side is doubled (check:
-k_count_rows, which streams the 16.25 GB input matrix once, reads 16.38 GB after the correction);
+FETCH_SIZE reports half of the bytes of a wide coalesced streaming read, so the read side is doubled - and,
+because the guide calls other access widths uncalibrated, the doubled figure of every kernel that moves
+gigabytes is set against a byte count known from the workload (KNOWN_READS below: the input matrix, the WAH
+lines' share of it, the permuted rows the chain wrote, the .xsi bytes); the ratio is printed per kernel.
 WRITE_SIZE is taken as is.  The two counters come from separate passes.  Values are per launch.
 """
 import collections
@@ -34,6 +36,27 @@ def per_kernel(counter_csv):
     return {k: (v[0] / v[1], v[1]) for k, v in agg.items()}
 
 
+def known_reads(bench):
+    """Bytes each heavy kernel must read per LAUNCH at the bench workload, from quantities the bench line states."""
+    c = bench["config"]
+    lines, stride = c["sites_this_gpu"], c.get("row_stride_bytes", ((c["haps"] + 1023) // 1024) * 128)
+    wah = c.get("wah_lines_this_gpu", 0)
+    inp = float(lines) * stride
+    f = wah / float(lines) if lines else 0.0
+    y_row = ((c["haps"] + 63) // 64) * 8.0
+    return {
+        "k_count_rows_wide": (inp, "the packed input matrix, streamed once with 16-byte loads"),
+        "k_count_rows": (inp, "the packed input matrix, streamed once"),
+        "k_chain_rank_enc": (f * inp, "the input rows of the WAH lines (row prefetch, 8 bytes per lane, + scalar loads)"),
+        "k_sparse_write": ((1.0 - f) * inp, "the input rows of the sparse lines"),
+        "k_wah_units": (wah * y_row, "the permuted rows the chain wrote (each pass reads them once)"),
+        # per STEP: the caller divides by the launches a step makes (the phased decode runs the chain range by range)
+        "k_chain_decode_rank_wg": (wah * (y_row * 1.25), "the compact rank-select rows (10 bytes per 64 positions), all ranges of a step"),
+        "k_wah_tile_sums": (c["xsi_bytes_this_gpu"] * 0.97, "the WAH matrices of the file image"),
+        "k_wah_boundaries": (c["xsi_bytes_this_gpu"] * 0.97, "the WAH matrices of the file image"),
+    }
+
+
 def main():
     src, tag, dst, when = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
     os.makedirs(dst, exist_ok=True)
@@ -50,18 +73,26 @@ def main():
         f, w = per_kernel(fetch), per_kernel(write)
         kernels = {}
         rows = []
+        bj = p("%s_bench.json" % tag)
+        known = known_reads(json.loads(open(bj).read().strip().splitlines()[-1])) if os.path.exists(bj) else {}
         for name in sorted({k[0] for k in f} | {k[0] for k in w}):
             if not name.startswith("k_"):
                 continue
-            fk = f.get((name, "FETCH_SIZE"), (0.0, 0))[0] * 1024.0
+            fk, launches = f.get((name, "FETCH_SIZE"), (0.0, 0))
+            fk *= 1024.0
             wk = w.get((name, "WRITE_SIZE"), (0.0, 0))[0] * 1024.0
+            kb, why = known.get(name, (None, ""))
+            if kb and name == "k_chain_decode_rank_wg":
+                kb /= max(1.0, launches / 2.0)  # the profiled command runs two steps (--steps 1 --warmup 1)
             kernels[name] = {"fetch_size_bytes_raw": fk, "read_bytes_corrected": 2.0 * fk, "write_bytes": wk,
-                             "hbm_bytes_per_launch": 2.0 * fk + wk}
-            rows.append((name, fk, 2.0 * fk, wk, 2.0 * fk + wk))
+                             "hbm_bytes_per_launch": 2.0 * fk + wk, "launches_in_the_profiled_run": launches,
+                             "known_read_bytes": kb, "x2_over_known": (2.0 * fk / kb) if kb else None, "known_read_is": why}
+            rows.append((name, launches, fk, 2.0 * fk, wk, 2.0 * fk + wk, kb or 0.0, (2.0 * fk / kb) if kb else 0.0, why))
         with open(os.path.join(dst, "%s_hbm_traffic.csv" % tag), "w") as out:
-            out.write("kernel,FETCH_SIZE_bytes_raw,read_bytes_x2_gfx950,WRITE_SIZE_bytes,hbm_bytes_per_launch\n")
-            for r in sorted(rows, key=lambda x: -x[4]):
-                out.write("%s,%.0f,%.0f,%.0f,%.0f\n" % r)
+            out.write("kernel,launches,FETCH_SIZE_bytes_raw,read_bytes_x2_gfx950,WRITE_SIZE_bytes,hbm_bytes_per_launch,"
+                      "known_read_bytes_per_launch,x2_over_known,known_read_is\n")
+            for r in sorted(rows, key=lambda x: -x[5] * max(x[1], 1)):
+                out.write("%s,%d,%.0f,%.0f,%.0f,%.0f,%.0f,%.3f,%s\n" % r)
         tpath = os.path.join(dst, "hbm_traffic.json")
         tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
         if "config2" not in tj and "config1" not in tj:
