@@ -438,13 +438,30 @@ def main():
 
     # the writer rank's buffers for the gathered streams: sized like the per-rank output (every rank has the same
     # share of the job, +1 block of slack for the rounding of the shards)
-    gat = xdist.RcclGather(ctx, tdist, dev) if distributed else None
+    gat = None
+    gat_error = None
+    if distributed:
+        try:
+            if os.environ.get("XSI_BENCH_TORCH_GATHER"):
+                raise RuntimeError("XSI_BENCH_TORCH_GATHER is set")
+            gat = xdist.RcclGather(ctx, tdist, dev)
+        except Exception as e:  # the library's own communicator could not be made: gather through torch.distributed
+            gat_error = "%s: %s" % (type(e).__name__, e)
+        # every rank must take the same path
+        flag = torch.tensor([1 if gat is None else 0], dtype=torch.int32, device=dev)
+        tdist.all_reduce(flag)
+        if int(flag.item()) and gat is not None:
+            gat.close()
+            gat = None
+            gat_error = gat_error or "another rank could not create its communicator"
     gat_blocks = (n_blocks + 1) * world
 
     def exchange():
         """The path's one exchange step: compressed block streams -> writer rank over RCCL / xGMI, through the
         library's own communicator (xsi_hip_gather_block_streams).  It runs on the communicator's stream behind the
         encode and overlaps with the decode that follows (both only read d_out)."""
+        if gat is None:
+            return xdist.gather_block_streams_async(d_out, res.blocks_bytes, d_off - 256, tdist, dev)
         if "gat_cap" not in state:
             # the writer rank's receive buffer: the sum of the ranks' regions (the same in every step), learnt once
             t = torch.tensor([int(res.blocks_bytes)], dtype=torch.int64, device=dev)
@@ -460,8 +477,14 @@ def main():
         binding.check(L.xsi_hip_decode_packed(ctx.handle, d_file.data_ptr(), flen, 0, n_blocks, d_dec.data_ptr(),
                                               stride, S, ctypes.byref(rows), None))
         if got is not None:
-            gat.wait()
-            state["gathered"] = got
+            if gat is None:
+                parts = got.wait()
+                if parts is not None:
+                    state["gathered"] = (torch.cat(parts[0]), torch.cat(parts[1]), [int(x.numel()) for x in parts[0]],
+                                         [int(x.numel()) for x in parts[1]])
+            else:
+                gat.wait()
+                state["gathered"] = got
 
     def fence():
         torch.cuda.synchronize()
@@ -493,8 +516,11 @@ def main():
         # the exchange step alone, not overlapped with anything
         fence()
         tg = time.perf_counter()
-        exchange()
-        gat.wait()
+        h = exchange()
+        if gat is None:
+            h.wait()
+        else:
+            gat.wait()
         fence()
         gather_ms = (time.perf_counter() - tg) * 1e3
 
@@ -594,7 +620,8 @@ def main():
                                "bytes_per_rank": [int(x) for x in per_b],
                                "offsets_ascending": bool(np.all(np.diff(offs_np) > 0)) if offs_np.size > 1 else True,
                                "own_part_equals_encode_output": bool(torch.equal(region_all[:xsi_bytes], d_out[:xsi_bytes])),
-                               "via": "xsi_hip_gather_block_streams (RCCL from libxsi_hip.so)"}
+                               "via": "xsi_hip_gather_block_streams (RCCL from libxsi_hip.so)" if gat is not None
+                               else "torch.distributed point-to-point (the library's communicator failed: %s)" % gat_error}
 
     # ---- CPU baseline: the oracle (parity-pinned restatement of the reference), 1 thread ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

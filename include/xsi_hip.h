@@ -66,8 +66,8 @@ uint64_t xsi_hip_ctx_chain_fallbacks(const xsi_hip_ctx* ctx);
 
 /* Bytes of per-line device workspace one block-level call may hold.  A job that needs more (e.g. 153 blocks
  * of 500 000 haplotypes) is run as several batches of whole blocks inside the call; the bytes written are
- * those of a single pass, since blocks are independent.  0 (default) = 40 % of the HBM that is free at
- * the call; the environment variable XSI_WS_BUDGET_MB overrides the default. */
+ * those of a single pass, since blocks are independent.  0 (default) = half of the HBM that is free at the call plus what the context already holds and will reuse (never
+ * more than the one buffer that takes the per-line rows can get); the environment variable XSI_WS_BUDGET_MB overrides the default. */
 int xsi_hip_ctx_set_workspace_budget(xsi_hip_ctx* ctx, uint64_t bytes);
 
 /* Per-stage device timing with HIP events recorded on the context's stream (used by bench.py for

@@ -68,11 +68,15 @@ def test_c_abi_gather_world_one_on_gpu_encoded_blocks():
     assert (lo.value, hi.value) == (458, 611)
 
 
-def test_bench_multi_rank_path_with_one_rank():
+@pytest.mark.parametrize("torch_gather", [False, True])
+def test_bench_multi_rank_path_with_one_rank(torch_gather):
     """bench.py --force-dist: process group (nccl), the C-ABI gather inside the timed region and alone, the
-    per-rank report - on blocks the GPU encoded in this run."""
+    per-rank report - on blocks the GPU encoded in this run.  Second case: the fallback bench.py takes when the
+    library's communicator cannot be created (gather through torch.distributed)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env["MASTER_PORT"] = "29577"
+    env["MASTER_PORT"] = "29578" if torch_gather else "29577"
+    if torch_gather:
+        env["XSI_BENCH_TORCH_GATHER"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--config", "1",
                         "--sites", "40000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=600, env=env)
@@ -85,3 +89,4 @@ def test_bench_multi_rank_path_with_one_rank():
     g = out["gathered"]
     assert g["ranks"] == 1 and g["own_part_equals_encode_output"] and g["offsets_ascending"]
     assert g["bytes"] == out["config"]["xsi_bytes_this_gpu"] and g["blocks"] == out["config"]["blocks_this_gpu"]
+    assert ("torch.distributed" in g["via"]) == torch_gather

@@ -44,7 +44,7 @@ struct xsi_hip_ctx {
         size_t cap = 0;
     };
     std::map<std::string, Buf> bufs;  // named device workspace, grown on demand, reused across calls
-    // Bytes of per-line workspace one encode / decode call may hold (0 = 40 % of the free HBM at the call).
+    // Bytes of per-line workspace one encode / decode call may hold (0 = half of free + held HBM at the call, see ws_budget_now).
     // A job that needs more runs as several batches of whole blocks (blocks are independent).
     uint64_t ws_budget = 0;
     void* pinned = nullptr;           // pinned host staging
