@@ -271,6 +271,9 @@ typedef struct xsi_hip_comm xsi_hip_comm;
 /* Contiguous block range [*lo, *hi) of `rank`: block b goes to rank floor(b * world / n_blocks), so the gathered
  * streams concatenate in file order. */
 void xsi_hip_shard_blocks(uint64_t n_blocks, int world, int rank, uint64_t* lo, uint64_t* hi);
+/* The rank that owns `block` under that partition (decode side: every rank opens the file, or just its block range,
+ * read-only, and a query for BM position p is served by the owner of block p >> 15; no exchange).  -1 on bad arguments. */
+int xsi_hip_shard_of_block(uint64_t n_blocks, int world, uint64_t block);
 /* ncclGetUniqueId: made by one rank, handed to the others by whatever the host program has (MPI, a file, a socket). */
 int xsi_hip_comm_unique_id(uint8_t id[XSI_HIP_COMM_ID_BYTES]);
 /* ncclCommInitRank on the context's device; collective over all `world` ranks. */

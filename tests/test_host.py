@@ -158,6 +158,20 @@ def test_shard_blocks_partition():
             assert seen == list(range(nb))
 
 
+def test_queries_are_routed_to_the_rank_that_owns_their_block():
+    L = binding.lib()
+    for nb in (1, 7, 123, 611, 1221):
+        for w in (1, 2, 3, 8):
+            owner = np.empty(nb, dtype=np.int64)
+            for r in range(w):
+                lo, hi = xdist.shard_blocks(nb, w, r)
+                owner[lo:hi] = r
+            bm = (np.arange(nb, dtype=np.int64) << 15) | 17
+            assert np.array_equal(xdist.route_queries(bm, nb, w), owner)
+            assert [L.xsi_hip_shard_of_block(nb, w, b) for b in range(nb)] == owner.tolist()
+    assert L.xsi_hip_shard_of_block(5, 2, 5) == -1
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

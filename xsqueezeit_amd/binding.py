@@ -53,7 +53,7 @@ SYMBOLS = [
     "xsi_hip_ctx_set_workspace_budget", "xsi_hip_chain_kernel", "xsi_mac_threshold", "xsi_default_phased",
     "xsi_bm_init", "xsi_bm_next", "xsi_accessor_set_sample_subset", "xsi_accessor_fill_selected_genotypes",
     "xsi_hip_reencode", "xsi_hip_ctx_chain_fallbacks",
-    "xsi_hip_shard_blocks", "xsi_hip_comm_unique_id", "xsi_hip_comm_create", "xsi_hip_comm_destroy",
+    "xsi_hip_shard_blocks", "xsi_hip_shard_of_block", "xsi_hip_comm_unique_id", "xsi_hip_comm_create", "xsi_hip_comm_destroy",
     "xsi_hip_comm_world", "xsi_hip_comm_rank", "xsi_hip_gather_block_streams", "xsi_hip_comm_wait", "xsi_htslib_shim_available", "xsi_debug_pack_bit_row",
 ]
 
@@ -101,6 +101,8 @@ def lib():
     L.xsi_hip_ctx_workspace_bytes.argtypes = [vp]
     L.xsi_hip_shard_blocks.restype = None
     L.xsi_hip_shard_blocks.argtypes = [u64, c.c_int, c.c_int, c.POINTER(u64), c.POINTER(u64)]
+    L.xsi_hip_shard_of_block.restype = c.c_int
+    L.xsi_hip_shard_of_block.argtypes = [u64, c.c_int, u64]
     L.xsi_hip_comm_unique_id.restype = c.c_int
     L.xsi_hip_comm_unique_id.argtypes = [vp]
     L.xsi_hip_comm_create.restype = c.c_int

@@ -97,6 +97,11 @@ void xsi_hip_shard_blocks(uint64_t n_blocks, int world, int rank, uint64_t* lo, 
     if (hi) *hi = ((uint64_t)(rank + 1) * n_blocks + (uint64_t)world - 1u) / (uint64_t)world;
 }
 
+int xsi_hip_shard_of_block(uint64_t n_blocks, int world, uint64_t block) {
+    if (world < 1 || block >= n_blocks) return -1;
+    return (int)(block * (uint64_t)world / n_blocks);  // the inverse of xsi_hip_shard_blocks: lo(r) = ceil(r B / G) <= b < lo(r + 1)
+}
+
 int xsi_hip_comm_unique_id(uint8_t id[XSI_HIP_COMM_ID_BYTES]) {
     if (!id) return set_error(XSI_ERR_ARG, "comm_unique_id: null id");
     if (!rccl().ok) return set_error(XSI_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");

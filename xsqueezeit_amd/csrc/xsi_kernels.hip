@@ -2755,6 +2755,41 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
             uint2* dc = reinterpret_cast<uint2*>(L.yp) + (size_t)j * L.y_stride64;
             uint16_t* dp = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(L.yp) + 8ull * L.y_stride64 * L.yp_rows) +
                            (size_t)j * L.y_stride64;
+            // two chunks per lane and step: one 16-byte LDS read / write and one 16-byte store of the chunks, one
+            // 4-byte store of their two prefixes (8-byte accesses reach 0.54-0.70 of the 16-byte rate on this chip);
+            // rows of an odd number of chunks end with a single one
+            const uint32_t pairs = L.y_stride64 >> 1;
+            const bool odd = (L.y_stride64 & 1u) != 0u;
+            const bool al16 = ((reinterpret_cast<uintptr_t>(dc) | reinterpret_cast<uintptr_t>(dp)) & 15u) == 0u || !odd;
+            if (al16 && (reinterpret_cast<uintptr_t>(dc) & 15u) == 0u && (reinterpret_cast<uintptr_t>(dp) & 3u) == 0u) {
+                for (uint32_t i0 = 0; i0 < pairs + (odd ? 1u : 0u); i0 += 64u) {
+                    const uint32_t i = i0 + lane;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (i < pairs) {
+                        uint4* rp = reinterpret_cast<uint4*>(row) + i;
+                        v = *rp;
+                        *rp = make_uint4(0u, 0u, 0u, 0u);  // ready for the next line
+                    } else if (odd && i == pairs) {
+                        uint2* rp = reinterpret_cast<uint2*>(row) + 2u * i;
+                        const uint2 t = *rp;
+                        *rp = make_uint2(0u, 0u);
+                        v.x = t.x;
+                        v.y = t.y;
+                    }
+                    const uint32_t c0 = (uint32_t)__popc(v.x) + (uint32_t)__popc(v.y);
+                    const uint32_t c = c0 + (uint32_t)__popc(v.z) + (uint32_t)__popc(v.w);
+                    const uint32_t inc = wave_scan_incl_dpp(c);
+                    const uint32_t p0 = base + inc - c;
+                    if (i < pairs) {
+                        reinterpret_cast<uint4*>(dc)[i] = v;
+                        reinterpret_cast<uint32_t*>(dp)[i] = (p0 & 0xFFFFu) | ((p0 + c0) << 16);
+                    } else if (odd && i == pairs) {
+                        dc[2u * i] = make_uint2(v.x, v.y);
+                        dp[2u * i] = (uint16_t)p0;
+                    }
+                    base += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                }
+            } else {
             for (uint32_t i0 = 0; i0 < L.y_stride64; i0 += 64u) {
                 const uint32_t i = i0 + lane;
                 uint2 v = make_uint2(0u, 0u);
@@ -2770,6 +2805,7 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
                     dp[i] = (uint16_t)(base + inc - c);
                 }
                 base += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            }
             }
             if (lane == 0) {
                 L.ones[l] = ones;

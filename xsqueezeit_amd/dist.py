@@ -24,6 +24,15 @@ def shard_blocks(n_blocks, world_size, rank):
     return lo, hi
 
 
+def route_queries(bm_positions, n_blocks, world_size):
+    """Decode-side sharding (BASELINE configs[4]): the rank that serves each BM position = the owner
+    of its block (position >> 15) under shard_blocks.  Returns an int array of ranks; no exchange is involved: every
+    rank opens the file (or its block range) read-only and answers the queries routed to it."""
+    blocks = np.asarray(bm_positions, dtype=np.int64) >> 15
+    # shard_blocks: rank r owns [ceil(r B / G), ceil((r + 1) B / G)), i.e. block b -> rank floor(b G / B)
+    return (blocks * world_size // n_blocks).astype(np.int64)
+
+
 class RcclGather:
     """The writer-rank gather through libxsi_hip.so's own RCCL communicator (include/xsi_hip.h, "multi-GPU").
 
