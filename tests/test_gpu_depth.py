@@ -337,4 +337,15 @@ def test_config4_shape_against_oracle(tmp_path):
         assert np.array_equal(buf, rows[i]), "line %d vs source" % i
         binding.check(L.xsi_accessor_allele_counts(a, cnt.ctypes.data, int(nal[i])))
         assert np.array_equal(cnt[:int(nal[i])], ecnt)
+    # the same caller array again and again is page-locked and filled by the copy engine directly: the same line
+    # twice, a sequential run (which goes back through the window), another array in between, then the first again
+    buf2 = np.zeros(n_haps, dtype=np.int32)
+    seq = [77, 77, 78, 79, 80, 81, 77, 3000, 3000]
+    for k, i in enumerate(seq):
+        dst = buf2 if k == 4 else buf
+        dst[:] = -5
+        assert L.xsi_accessor_fill_genotype_array(a, dst.ctypes.data, dst.size, int(nal[i]), int(bm[i])) == n_haps
+        assert np.array_equal(dst, rows[i]), "step %d line %d" % (k, i)
     L.xsi_accessor_close(a)
+    buf[:] = 1  # the array is unlocked again and ordinary memory
+    assert int(buf.sum()) == n_haps

@@ -520,6 +520,16 @@ struct xsi_accessor {
     // composed window of a bi-allelic block, or the single last composed line
     int32_t* d_rows = nullptr;
     int32_t* h_rows = nullptr;  // pinned
+    // A caller that hands the SAME array to fill_genotype_array / get_genotypes call after call (the reference's
+    // Accessor::get_genotypes mallocs it once, accessor.hpp:59-62) gets it page-locked on its second appearance: a
+    // single-line request is then copied from HBM straight into it, without the stop in the pinned window (at 200 000
+    // haplotypes that memcpy is a third of a warm random query).  Unregistered when another array shows up and at close.
+    void* seen_dst = nullptr;       // the array of the call before
+    void* reg_dst = nullptr;        // the array that is registered now
+    size_t reg_bytes = 0;
+    int32_t* direct_dst = nullptr;  // set for the duration of one call: where a single composed line should land
+    bool direct_done = false;       // this call's line went there (not into h_rows)
+    bool win_in_rows = true;        // the window's lines are in h_rows (false after a direct single-line copy)
     uint64_t* h_counts = nullptr;  // pinned [win][2] or [1][max]
     uint32_t* h_meta = nullptr;    // pinned
     uint32_t win_rows = 0, win_first = 0, win_n = 0, win_target = 1;
@@ -719,7 +729,10 @@ static int accessor_compose(xsi_accessor* a, uint32_t first, uint32_t n, uint32_
     int rc = compose_lines(a->ctx, a->P, a->D, a->h_meta, a->h_meta + a->win_rows, n, a->d_rows, N,
                            a->h_meta + 2ull * a->win_rows, a->h_counts, max_al);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(a->h_rows, a->d_rows, (size_t)n * N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    int32_t* const dst = (n == 1u && a->direct_dst) ? a->direct_dst : a->h_rows;
+    a->direct_done = dst != a->h_rows;  // tells the caller where the line went
+    a->win_in_rows = !a->direct_done;
+    HIP_TRY(hipMemcpyAsync(dst, a->d_rows, (size_t)n * N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     // latency path of a random-access query: poll instead of sleeping on the completion interrupt
     hipError_t q;
     while ((q = hipStreamQuery(s)) == hipErrorNotReady) {
@@ -931,16 +944,37 @@ static int64_t accessor_line_view(xsi_accessor* a, uint32_t n_alleles, uint64_t 
 int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_t gt_size, uint32_t n_alleles,
                                          uint64_t position) {
     if (!a || !h_gt) return set_error(XSI_ERR_ARG, "fill_genotype_array: null argument");
+    const size_t line_bytes = (size_t)a->hap_samples * sizeof(int32_t);
+    a->direct_dst = nullptr;
+    a->direct_done = false;
+    if (gt_size >= a->hap_samples && line_bytes >= (64u << 10) && !getenv("XSI_ACCESSOR_NO_REGISTER")) {
+        if (h_gt == a->reg_dst) {
+            a->direct_dst = h_gt;
+        } else if (h_gt == a->seen_dst) {  // second call in a row with this array: page-lock it
+            if (a->reg_dst) (void)hipHostUnregister(a->reg_dst);
+            a->reg_dst = nullptr;
+            if (hipHostRegister(h_gt, line_bytes, hipHostRegisterDefault) == hipSuccess) {
+                a->reg_dst = h_gt;
+                a->reg_bytes = line_bytes;
+                a->direct_dst = h_gt;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
+    a->seen_dst = h_gt;
     const int32_t* view = nullptr;
     const int64_t ngt = accessor_line_view(a, n_alleles, position, &view);
     if (ngt < 0) return ngt;
     if (gt_size < (uint64_t)ngt) return set_error(XSI_ERR_CAPACITY, "gt array holds %llu values, line has %lld", (unsigned long long)gt_size, (long long)ngt);
-    memcpy(h_gt, view, (size_t)ngt * sizeof(int32_t));
+    if (view != h_gt) memcpy(h_gt, view, (size_t)ngt * sizeof(int32_t));
     return ngt;
 }
 
 int64_t xsi_accessor_genotypes_view(xsi_accessor* a, uint32_t n_alleles, uint64_t position, const int32_t** h_gt) {
     if (!a || !h_gt) return set_error(XSI_ERR_ARG, "genotypes_view: null argument");
+    a->direct_dst = nullptr;
+    a->direct_done = false;
     return accessor_line_view(a, n_alleles, position, h_gt);
 }
 
@@ -959,7 +993,7 @@ static int64_t accessor_line_view(xsi_accessor* a, uint32_t n_alleles, uint64_t 
     const uint32_t N = a->P.L.N;
     uint32_t row = 0;
     if (a->biallelic && n_alleles == 2) {
-        if (!(a->win_n && offset >= a->win_first && offset < a->win_first + a->win_n)) {
+        if (!(a->win_n && a->win_in_rows && offset >= a->win_first && offset < a->win_first + a->win_n)) {
             // window length follows the access pattern: a request that continues the previous window
             // doubles it (sequential scan -> few large compose + copy steps), a jump resets it to one
             // line (random access -> no composing / copying of lines nobody asked for)
@@ -981,7 +1015,7 @@ static int64_t accessor_line_view(xsi_accessor* a, uint32_t n_alleles, uint64_t 
         row = 0;
     }
     const uint32_t ngt = a->h_meta[2ull * a->win_rows + row];
-    *view = a->h_rows + (size_t)row * N;
+    *view = a->direct_done ? a->direct_dst : a->h_rows + (size_t)row * N;
     a->last_counts.assign(a->h_counts + (size_t)row * n_alleles, a->h_counts + (size_t)(row + 1) * n_alleles);
     return (int64_t)ngt;
 }
@@ -1258,6 +1292,7 @@ const char* xsi_accessor_sample_name(const xsi_accessor* a, uint64_t i) {
 void xsi_accessor_close(xsi_accessor* a) {
     if (!a) return;
     if (a->ctx) (void)hipStreamSynchronize(a->ctx->stream);
+    if (a->reg_dst && hipHostUnregister(a->reg_dst) != hipSuccess) (void)hipGetLastError();  // (the caller may have freed it already)
     for (auto& e : a->cache) (void)hipFree(e.mem);
     if (a->d_file) (void)hipFree(a->d_file);
     if (a->d_mini) (void)hipFree(a->d_mini);
