@@ -324,6 +324,8 @@ def main():
     ap.add_argument("--cpu-sample-cells", type=float, default=3.2e9, help="cells of the CPU-oracle baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the block-parallel CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--count-on-device", action="store_true",
+                    help="count the ALT alleles of every row inside the step instead of taking the counts from the producer")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (process group + RCCL gather) even with one rank (testing)")
     ap.add_argument("--blocks", type=int, default=8, help="config 4: 8192-line blocks of the file each rank serves")
@@ -404,6 +406,17 @@ def main():
 
     d_bits = torch.empty(S * stride, dtype=torch.uint8, device=dev)
     binding.check(L.xsi_hip_synth_packed(ctx.handle, seed, first_site, S, N, d_bits.data_ptr(), stride))
+    # The producer of the rows hands over their ALT counts with them (xsi_hip_encode_packed_counted), as the file
+    # writer does, whose packer counts while it packs: the 16.4 GB pass that only counts is then not part of the step.
+    # --count-on-device puts it back (xsi_hip_encode_packed); its time is reported either way (count_rows_ms).
+    d_cnt = torch.empty(S, dtype=torch.int32, device=dev)
+    binding.check(L.xsi_hip_count_packed_rows(ctx.handle, d_bits.data_ptr(), S, stride, N, d_cnt.data_ptr()))
+    torch.cuda.synchronize()
+    _t = time.perf_counter()
+    binding.check(L.xsi_hip_count_packed_rows(ctx.handle, d_bits.data_ptr(), S, stride, N, d_cnt.data_ptr()))
+    ctx.synchronize()
+    count_rows_ms = (time.perf_counter() - _t) * 1e3
+    cnt_ptr = None if args.count_on_device else d_cnt.data_ptr()
     bound = int(L.xsi_hip_encode_bound(ctypes.byref(p), S, S))
     # the worst-case bound (every line incompressible) is ~N/7.5 bytes per line; this generator needs
     # < 0.03 B per cell, so large jobs get 8 GiB or 0.04 B per cell instead of the bound (the encoder
@@ -470,8 +483,8 @@ def main():
         return gat.gather(d_out, res.blocks_bytes, d_off - 256, state["gat_cap"], gat_blocks)
 
     def step():
-        binding.check(L.xsi_hip_encode_packed(ctx.handle, ctypes.byref(p), d_bits.data_ptr(), S, stride,
-                                              d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)))
+        binding.check(L.xsi_hip_encode_packed_counted(ctx.handle, ctypes.byref(p), d_bits.data_ptr(), S, stride, cnt_ptr,
+                                                      d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)))
         got = exchange() if distributed else None
         flen = make_file_image()
         binding.check(L.xsi_hip_decode_packed(ctx.handle, d_file.data_ptr(), flen, 0, n_blocks, d_dec.data_ptr(),
@@ -593,6 +606,10 @@ def main():
                        "seed": seed, "xsi_bytes_this_gpu": xsi_bytes, "bytes_per_cell": c,
                        "wah_lines_this_gpu": int(res.n_wah_lines), "row_stride_bytes": stride,
                        "launches_per_step": launches_per_step,
+                       "row_counts": ("counted on the device inside the step (xsi_hip_encode_packed)" if args.count_on_device else
+                                      "handed over with the rows by their producer (xsi_hip_encode_packed_counted), as the file "
+                                      "writer's packer does; the counting pass alone takes count_rows_ms"),
+                       "count_rows_ms": count_rows_ms,
                        "parallelism": "blocks sharded over %d GPU(s); RCCL gather of block streams" % world
                        if distributed else "1 GPU"},
             "roofline": {"bound": "hbm", "kernel": "%s (PBWT chain, %s)" % (kname, "decode" if dom_decode else "encode"),

@@ -121,6 +121,22 @@ int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const vo
                           uint64_t* d_block_offsets, xsi_encode_result* h_result);
 
 /*
+ * The same with the ALT count of every row supplied by whoever produced the rows (d_row_counts[l] = number of set
+ * bits of row l, in HBM): the pass over the matrix that only counts (GtBlock::scan_genotypes' allele histogram,
+ * gt_block.hpp:207-269; 16.4 GB of reads at 64 976 haplotypes x 2 M sites) is then not made again.  The counts decide
+ * WAH against sparse and the sparse side (gt_block.hpp:298-327): wrong counts give a wrong file, not an error -
+ * XSI_CHECK_ROW_COUNTS=1 in the environment recounts and returns XSI_ERR_ARG on a difference.  d_row_counts == NULL is
+ * xsi_hip_encode_packed.  xsi_hip_count_packed_rows is that counting pass by itself (stream-ordered on the context),
+ * for a producer that has no cheaper way; xsi_writer_* counts while it packs (one popcount per mask).
+ */
+int xsi_hip_encode_packed_counted(xsi_hip_ctx* ctx, const xsi_encode_params* p, const void* d_bits,
+                                  uint64_t n_lines, uint32_t row_stride_bytes, const uint32_t* d_row_counts,
+                                  void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets,
+                                  xsi_encode_result* h_result);
+int xsi_hip_count_packed_rows(xsi_hip_ctx* ctx, const void* d_bits, uint64_t n_lines, uint32_t row_stride_bytes,
+                              uint32_t n_haps, uint32_t* d_row_counts);
+
+/*
  * General encode from htslib-encoded int32 genotype rows resident in HBM (what
  * bcf_get_genotypes hands GtBlock::encode_line): row l at d_gt + l*gt_stride (int32 units),
  * h_ngt[l] values used (n_samples or 2*n_samples), h_n_allele[l] alleles (>= 2).

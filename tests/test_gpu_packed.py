@@ -462,3 +462,73 @@ def test_sparse_lists_on_the_main_stream(monkeypatch):
         assert res.n_wah_lines < n_lines            # there are sparse lines
         got = G.assemble_file(region, offsets, p, n_lines, n_lines, names)
         assert got == ref, "sparse overlap %s" % ("off" if env else "on")
+
+
+@pytest.mark.parametrize("n_haps,n_lines,block_len,thr", [(5008, 600, 256, 5), (64976, 40, 16, 64), (200000, 48, 24, 200)])
+def test_counts_from_the_producer(n_haps, n_lines, block_len, thr, monkeypatch):
+    """xsi_hip_encode_packed_counted: with the rows' ALT counts supplied (xsi_hip_count_packed_rows here, the packer's
+    popcounts in the writer) the bytes are those of xsi_hip_encode_packed; XSI_CHECK_ROW_COUNTS=1 recounts and
+    refuses counts that do not belong to the rows."""
+    import gpu_util as G
+    torch = G.torch_mod()
+    L = binding.lib()
+    bits, packed, stride = _mk(n_haps, n_lines, 900 + n_haps)
+    p = G.params(n_haps // 2, block_len, thr)
+    ref_region, ref_off, ref_res = G.encode_packed(packed, n_haps, p)
+    d_bits = G.dev_u8(packed)
+    d_cnt = torch.zeros(n_lines, dtype=torch.int32, device="cuda")
+    binding.check(L.xsi_hip_count_packed_rows(G.ctx().handle, d_bits.data_ptr(), n_lines, stride, n_haps, d_cnt.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_cnt.cpu().numpy(), bits.sum(axis=1).astype(np.int32))
+    cap = int(L.xsi_hip_encode_bound(ctypes.byref(p), n_lines, n_lines))
+    d_out = G.dev_empty(cap)
+    n_blocks = (n_lines + block_len - 1) // block_len
+    d_off = torch.zeros(n_blocks, dtype=torch.int64, device="cuda")
+    res = binding.EncodeResult()
+
+    def run(cnt):
+        return L.xsi_hip_encode_packed_counted(G.ctx().handle, ctypes.byref(p), d_bits.data_ptr(), n_lines, stride,
+                                               cnt.data_ptr(), d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res))
+
+    monkeypatch.setenv("XSI_CHECK_ROW_COUNTS", "1")
+    binding.check(run(d_cnt))
+    assert d_out[:res.blocks_bytes].cpu().numpy().tobytes() == ref_region
+    assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), ref_off)
+    assert res.n_wah_lines == ref_res.n_wah_lines
+    monkeypatch.delenv("XSI_CHECK_ROW_COUNTS")
+    d_out.zero_()
+    binding.check(run(d_cnt))
+    assert d_out[:res.blocks_bytes].cpu().numpy().tobytes() == ref_region
+    wrong = d_cnt.clone()
+    wrong[n_lines // 2] += 1
+    monkeypatch.setenv("XSI_CHECK_ROW_COUNTS", "1")
+    assert run(wrong) == binding.XSI_ERR_ARG
+    assert b"row counts" in L.xsi_hip_last_error()
+
+
+@pytest.mark.parametrize("n_haps,n_lines,block_len", [(64976, 24, 12), (20000, 40, 20), (131074, 12, 6), (300000, 8, 4)])
+@pytest.mark.parametrize("two_pass", [False, True])
+def test_incompressible_lines_and_words_kept_in_the_row(n_haps, n_lines, block_len, two_pass, monkeypatch):
+    """The WAH sizing pass leaves a line's words in the line's own permuted row when they fit (the writing pass then
+    only moves them); a line of (almost) only literal groups takes more bytes than its row (16/15) and is encoded from
+    the row again.  Half the lines here are coin flips (every group a literal), the others synthetic; bytes against
+    the oracle, with the in-place words and with XSI_WAH_TWO_PASS=1 (classify twice, as before)."""
+    import gpu_util as G
+    if two_pass:
+        monkeypatch.setenv("XSI_WAH_TWO_PASS", "1")
+    rng = np.random.default_rng(n_haps)
+    bits = synth.synth_bits(5, 0, n_lines, n_haps)
+    for l in range(0, n_lines, 2):
+        bits[l] = rng.integers(0, 2, n_haps, dtype=np.uint8)
+    bits[3] = 0
+    bits[3, ::15] = 1  # every group a literal with one bit: WAH lines of 2 bytes per 15 bits exactly
+    stride = synth.row_stride_bytes(n_haps)
+    packed = synth.pack_rows(bits, stride)
+    p = G.params(n_haps // 2, block_len, n_haps // 1000)
+    names = ["S%d" % i for i in range(n_haps // 2)]
+    ref = G.oracle_file_from_bits(bits, p, names)
+    region, offsets, res = G.encode_packed(packed, n_haps, p)
+    got = G.assemble_file(region, offsets, p, n_lines, n_lines, names)
+    assert got == ref
+    out, _ = G.decode_packed(got, n_haps, stride)
+    assert np.array_equal(out, packed)

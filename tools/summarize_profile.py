@@ -49,7 +49,7 @@ def known_reads(bench):
         "k_count_rows": (inp, "the packed input matrix, streamed once"),
         "k_chain_rank_enc": (f * inp, "the input rows of the WAH lines (row prefetch, 8 bytes per lane, + scalar loads)"),
         "k_sparse_write": ((1.0 - f) * inp, "the input rows of the sparse lines"),
-        "k_wah_units": (wah * y_row, "the permuted rows the chain wrote (each pass reads them once)"),
+        "k_wah_units": (wah * y_row, "the permuted rows the chain wrote, read once by the sizing pass (which leaves the words in the rows)"),
         # per STEP: the caller divides by the launches a step makes (the phased decode runs the chain range by range)
         "k_chain_decode_rank_wg": (wah * (y_row * 1.25), "the compact rank-select rows (10 bytes per 64 positions), all ranges of a step"),
         "k_wah_tile_sums": (c["xsi_bytes_this_gpu"] * 0.97, "the WAH matrices of the file image"),

@@ -55,6 +55,7 @@ SYMBOLS = [
     "xsi_hip_reencode", "xsi_hip_ctx_chain_fallbacks",
     "xsi_hip_shard_blocks", "xsi_hip_shard_of_block", "xsi_hip_comm_unique_id", "xsi_hip_comm_create", "xsi_hip_comm_destroy",
     "xsi_hip_comm_world", "xsi_hip_comm_rank", "xsi_hip_gather_block_streams", "xsi_hip_comm_wait", "xsi_htslib_shim_available", "xsi_debug_pack_bit_row",
+    "xsi_hip_encode_packed_counted", "xsi_hip_count_packed_rows",
 ]
 
 
@@ -153,6 +154,11 @@ def lib():
     L.xsi_hip_encode_packed.restype = c.c_int
     L.xsi_hip_encode_packed.argtypes = [vp, c.POINTER(EncodeParams), vp, u64, u32, vp, u64, vp,
                                         c.POINTER(EncodeResult)]
+    L.xsi_hip_encode_packed_counted.restype = c.c_int
+    L.xsi_hip_encode_packed_counted.argtypes = [vp, c.POINTER(EncodeParams), vp, u64, u32, vp, vp, u64, vp,
+                                                c.POINTER(EncodeResult)]
+    L.xsi_hip_count_packed_rows.restype = c.c_int
+    L.xsi_hip_count_packed_rows.argtypes = [vp, vp, u64, u32, u32, vp]
     L.xsi_hip_encode_gt.restype = c.c_int
     L.xsi_hip_encode_gt.argtypes = [vp, c.POINTER(EncodeParams), vp, u64, u64, vp, vp, vp, u64, vp,
                                     c.POINTER(EncodeResult)]

@@ -334,6 +334,8 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     L.wah_scratch_stride = ((N + 14u) / 15u + 3u) & ~1u;  // even: rows stay 4-byte aligned for k_wah_write
     L.wah_scratch = nullptr;  // without it the lines are sized first and encoded again straight into place
     if (use_wah_scratch && !wah_units_any(L.y_stride64)) WS(L.wah_scratch, "enc.wah_scratch", 2ull * L.wah_scratch_stride * y_rows);
+    // the unit encoders read a row into LDS whole: the sizing pass can leave the words in the row's place (read per call: testing)
+    L.wah_inplace = (wah_units_any(L.y_stride64) && !getenv("XSI_WAH_TWO_PASS")) ? 1u : 0u;
     WS(L.flagbits, "enc.flagbits", 4ull * (MAX_BIN_PER_BLOCK / 32) * FV_COUNT * (size_t)n_blocks);
     WS(L.flagwah, "enc.flagwah", 2ull * FLAG_WORDS_MAX * FV_COUNT * (size_t)n_blocks);
     uint32_t* d_totals;
@@ -434,6 +436,25 @@ extern "C" {
 int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const void* d_bits, uint64_t n_lines,
                           uint32_t row_stride_bytes, void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets,
                           xsi_encode_result* h_result) {
+    return xsi_hip_encode_packed_counted(ctx, p, d_bits, n_lines, row_stride_bytes, nullptr, d_out, out_capacity, d_block_offsets,
+                                         h_result);
+}
+
+int xsi_hip_count_packed_rows(xsi_hip_ctx* ctx, const void* d_bits, uint64_t n_lines, uint32_t row_stride_bytes, uint32_t n_haps,
+                              uint32_t* d_row_counts) {
+    if (!ctx || !d_bits || !d_row_counts) return set_error(XSI_ERR_ARG, "count_packed_rows: null argument");
+    if (row_stride_bytes % 8u || (uint64_t)row_stride_bytes * 8u < n_haps || n_lines > 0x7FFFFFFFull)
+        return set_error(XSI_ERR_ARG, "count_packed_rows: bad stride or line count");
+    if (!n_lines) return XSI_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_count_rows(ctx->stream, reinterpret_cast<const uint32_t*>(d_bits), row_stride_bytes / 4u, n_haps, (uint32_t)n_lines,
+                              d_row_counts));
+    return XSI_OK;
+}
+
+int xsi_hip_encode_packed_counted(xsi_hip_ctx* ctx, const xsi_encode_params* p, const void* d_bits, uint64_t n_lines,
+                                  uint32_t row_stride_bytes, const uint32_t* d_row_counts, void* d_out, uint64_t out_capacity,
+                                  uint64_t* d_block_offsets, xsi_encode_result* h_result) {
     if (!ctx || !p || !d_bits || !d_out) return set_error(XSI_ERR_ARG, "encode_packed: null argument");
     if (!p->n_samples || !p->block_len) return set_error(XSI_ERR_ARG, "encode_packed: n_samples and block_len must be > 0");
     if (p->block_len > MAX_BIN_PER_BLOCK)
@@ -462,7 +483,24 @@ int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const vo
     WS(d_wah_per_block, "enc.wah_per_block", 4ull * n_blocks_all);
     HIP_TRY(hipMemsetAsync(kind_all, 0, n_lines, s));
     stage_mark(ctx, XSI_ST_COUNT);
-    HIP_TRY(launch_count_rows(s, reinterpret_cast<const uint32_t*>(d_bits), row_stride_bytes / 4u, N, (uint32_t)n_lines, cnt_all));
+    if (d_row_counts) {
+        // the producer of the rows counted them (the writer's packer does, one popcount per mask): the pass over the
+        // matrix that GtBlock::scan_genotypes stands for (gt_block.hpp:207-269) has been made already
+        if (getenv("XSI_CHECK_ROW_COUNTS")) {
+            HIP_TRY(launch_count_rows(s, reinterpret_cast<const uint32_t*>(d_bits), row_stride_bytes / 4u, N, (uint32_t)n_lines, cnt_all));
+            uint32_t* d_bad;
+            WS(d_bad, "enc.cnt_check", 4);
+            HIP_TRY(hipMemsetAsync(d_bad, 0, 4, s));
+            HIP_TRY(launch_compare_u32(s, cnt_all, d_row_counts, n_lines, d_bad));
+            uint32_t bad = 0;
+            HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (bad) return set_error(XSI_ERR_ARG, "encode_packed_counted: %u of the supplied row counts differ from the rows", bad);
+        }
+        HIP_TRY(hipMemcpyAsync(cnt_all, d_row_counts, 4ull * n_lines, hipMemcpyDeviceToDevice, s));
+    } else {
+        HIP_TRY(launch_count_rows(s, reinterpret_cast<const uint32_t*>(d_bits), row_stride_bytes / 4u, N, (uint32_t)n_lines, cnt_all));
+    }
     HIP_TRY(launch_wah_lines_per_block(s, cnt_all, n_lines, p->block_len, N, p->mac_threshold, d_wah_per_block));
     stage_mark(ctx, -1);
     std::vector<uint32_t> wah_per_block((size_t)n_blocks_all);

@@ -100,6 +100,8 @@ struct xsi_writer {
     uint8_t* d_bits[2] = {nullptr, nullptr};
     uint8_t* d_fast[2] = {nullptr, nullptr};  // per line: 1 = bit row, 0 = int32 row
     std::vector<uint8_t> fast[2];
+    std::vector<uint32_t> ones[2];  // set bits of every bit row, counted when it is packed (xsi_hip_encode_packed_counted)
+    uint32_t* d_ones[2] = {nullptr, nullptr};
     uint64_t general_in_batch = 0;
     uint8_t* h_bits_chunks[2] = {nullptr, nullptr};
     uint8_t* h_bits_chunk = nullptr;
@@ -174,7 +176,9 @@ static int writer_encode_batch(xsi_writer* w, int b, uint64_t n_lines) {
     uint64_t n_general = 0;
     for (uint8_t f : w->fast[b]) n_general += f ? 0u : 1u;
     if (n_general == 0) {
-        rc = xsi_hip_encode_packed(w->ctx, &w->p, w->d_bits[b], n_lines, w->bit_stride, w->d_out, w->out_cap, w->d_offs, &res);
+        HIP_TRY(hipMemcpyAsync(w->d_ones[b], w->ones[b].data(), 4ull * n_lines, hipMemcpyHostToDevice, w->ctx->stream));
+        rc = xsi_hip_encode_packed_counted(w->ctx, &w->p, w->d_bits[b], n_lines, w->bit_stride, w->d_ones[b], w->d_out, w->out_cap,
+                                           w->d_offs, &res);
     } else {
         if (n_general != n_lines) {  // the packed lines become int32 rows on the device, next to the shipped ones
             HIP_TRY(hipMemcpyAsync(w->d_fast[b], w->fast[b].data(), n_lines, hipMemcpyHostToDevice, w->ctx->stream));
@@ -255,6 +259,7 @@ static int writer_flush_batch(xsi_writer* w) {
     w->ngt[w->cur].clear();
     w->n_allele[w->cur].clear();
     w->fast[w->cur].clear();
+    w->ones[w->cur].clear();
     return XSI_OK;
 }
 
@@ -265,6 +270,7 @@ static void writer_free(xsi_writer* w) {
         if (w->d_rows[i]) (void)hipFree(w->d_rows[i]);
         if (w->d_bits[i]) (void)hipFree(w->d_bits[i]);
         if (w->d_fast[i]) (void)hipFree(w->d_fast[i]);
+        if (w->d_ones[i]) (void)hipFree(w->d_ones[i]);
         if (w->h_bits_chunks[i]) (void)hipHostFree(w->h_bits_chunks[i]);
         if (w->h_chunks[i]) (void)hipHostFree(w->h_chunks[i]);
         if (w->chunk_done[i]) (void)hipEventDestroy(w->chunk_done[i]);
@@ -346,6 +352,7 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&w->d_rows[i], block_bytes * w->batch_blocks);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&w->d_bits[i], (size_t)w->bit_stride * p->block_len * w->batch_blocks);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&w->d_fast[i], (size_t)p->block_len * w->batch_blocks);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&w->d_ones[i], 4ull * p->block_len * w->batch_blocks);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&w->batch_copied, hipEventDisableTiming);
     size_t chunk_bytes = 64ull << 20;
@@ -400,6 +407,14 @@ static int writer_commit(xsi_writer* w, uint32_t ngt, uint32_t n_allele, bool li
         w->general_in_batch++;
     }
     w->fast[w->cur].push_back(line_is_packed ? 1 : 0);
+    {  // the line's ALT count, from the bit row just packed (N / 64 popcounts against the 4 N bytes the packer read)
+        uint32_t c = 0;
+        if (line_is_packed) {
+            const uint64_t* q = reinterpret_cast<const uint64_t*>(w->h_bits_chunk + (size_t)w->chunk_fill * w->bit_stride);
+            for (uint32_t i = 0, n64 = (ngt + 63u) / 64u; i < n64; ++i) c += (uint32_t)__builtin_popcountll(q[i]);
+        }
+        w->ones[w->cur].push_back(c);
+    }
     w->chunk_fill++;
     w->lines_in_batch++;
     w->ngt[w->cur].push_back(ngt);

@@ -181,6 +181,19 @@ hipError_t launch_wah_lines_per_block(hipStream_t s, const uint32_t* cnt, uint64
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) k_compare_u32(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint64_t n,
+                                                     uint32_t* __restrict__ n_diff) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t m = __ballot(i < n && a[i] != b[i]);
+    if (m && lane_id() == 0) atomicAdd(n_diff, (uint32_t)__popcll(m));
+}
+
+hipError_t launch_compare_u32(hipStream_t s, const uint32_t* a, const uint32_t* b, uint64_t n, uint32_t* n_diff) {
+    if (!n) return hipSuccess;
+    k_compare_u32<<<dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, s>>>(a, b, n, n_diff);
+    return hipGetLastError();
+}
+
 hipError_t launch_count_rows(hipStream_t s, const uint32_t* planes, uint32_t stride_w, uint32_t nbits,
                              uint32_t n_rows, uint32_t* cnt) {
     if (!n_rows) return hipSuccess;
@@ -1461,6 +1474,9 @@ hipError_t launch_chain_decode(hipStream_t s, const DecBlock* blocks, uint32_t n
 // One wave per WAH line; the sizing pass and the writing pass run the same encoder.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t WAH_LINES_PER_WAVE = 4;  // amortises the dependent metadata loads of a line
+// the words of a line (n of them) may be kept in its own row of y_stride64 8-byte pairs: 4 bytes to spare, because
+// k_wah_write's re-pairing copy reads one 4-byte word past the last
+__device__ __forceinline__ bool wah_fits_row(uint32_t n, uint32_t y_stride64) { return 2u * n + 4u <= 8u * y_stride64; }
 
 __global__ void __launch_bounds__(256) k_wah_sizes(EncLines L, const uint32_t* __restrict__ d_total_wah) {
     const uint32_t lane = lane_id();
@@ -1582,10 +1598,15 @@ static uint32_t wah_units_small_upl(const EncLines& L) {
 // again and stores the words straight into the file image: no scratch copy of the words (10 GB at 64 976 x 2 M).
 constexpr int WAH_STAGE_Q = 16;  // 16 x 64 lanes x 8 bytes = 8 KiB
 constexpr uint32_t WAH_UNIT_WAVE_WORDS = WAH_UNIT_ROW_WORDS + 64u * (uint32_t)WAH_UNIT_ROUNDS + 16u;  // row, fh, 64-byte strip
-template <bool WRITE_PASS>
+// MODE 0: sizing pass; 1: writing pass (classifies again, words straight into the file image); 2: sizing pass that also
+// leaves the line's words IN THE LINE'S OWN ROW (the row is in LDS by then, and a line whose words would not fit its
+// row - less than one line in 16 literal groups short of incompressible - is left alone): k_wah_write then moves the
+// words into place and the rows are read once, not twice (10 GB at 64 976 haplotypes x 2 M sites).
+template <int MODE>
 __global__ void __launch_bounds__(256) k_wah_units(const EncBlock* __restrict__ blocks, EncLines L,
                                                    const uint32_t* __restrict__ d_total_wah, uint32_t max_wah,
                                                    uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result) {
+    constexpr bool WRITE_PASS = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char wah_smem[];
     if (WRITE_PASS && d_result[3]) return;  // capacity error: nothing may be written
     const uint32_t lane = lane_id();
@@ -1650,6 +1671,10 @@ __global__ void __launch_bounds__(256) k_wah_units(const EncBlock* __restrict__ 
             wah_units_emit_line(lrow, fh, G, m, reinterpret_cast<uint16_t*>(((uint64_t)hi << 32) | lo));
         } else {
             if (lane == 0) L.wah_len[j] = n;
+            if (MODE == 2 && wah_fits_row(n, np)) {
+                const uint64_t ja = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)j) * np;
+                wah_units_emit_line(lrow, fh, G, m, reinterpret_cast<uint16_t*>(L.yrows + ja));
+            }
         }
     }
 }
@@ -1662,11 +1687,12 @@ __global__ void __launch_bounds__(256) k_wah_units(const EncBlock* __restrict__ 
 // ceil(len / 16383) words (counts of 16383, then the rest - as the serial encoder does it).
 constexpr int WAH_WIDE_ROUNDS = 2;
 constexpr uint32_t WAH_WIDE_UNITS = 1024u * (uint32_t)WAH_WIDE_ROUNDS;
-template <bool WRITE_PASS>
+template <int MODE>  // as k_wah_units
 __global__ void __launch_bounds__(1024) k_wah_units_wide(const EncBlock* __restrict__ blocks, EncLines L,
                                                          const uint32_t* __restrict__ d_total_wah, uint32_t max_wah,
                                                          uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result,
                                                          uint32_t row_words_lds) {
+    constexpr bool WRITE_PASS = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char wah_smem[];
     if (WRITE_PASS && d_result[3]) return;  // capacity error: nothing may be written
     const uint32_t j = blockIdx.x;
@@ -1750,12 +1776,16 @@ __global__ void __launch_bounds__(1024) k_wah_units_wide(const EncBlock* __restr
         if (lane == 63u) sc[16u * (uint32_t)WAH_WIDE_ROUNDS] = inc;
     }
     __syncthreads();
+    uint16_t* dst;
     if (!WRITE_PASS) {
-        if (tid == 0) L.wah_len[j] = sc[16u * (uint32_t)WAH_WIDE_ROUNDS];
-        return;
+        const uint32_t n_words = sc[16u * (uint32_t)WAH_WIDE_ROUNDS];
+        if (tid == 0) L.wah_len[j] = n_words;
+        if (MODE != 2 || !wah_fits_row(n_words, L.y_stride64)) return;
+        dst = reinterpret_cast<uint16_t*>(L.yrows + (size_t)j * L.y_stride64);  // the row is in LDS: its words take its place
+    } else {
+        const EncBlock& Bk = blocks[L.line_block[l]];
+        dst = reinterpret_cast<uint16_t*>(out + Bk.out_off + 16u + Bk.off_wah) + L.wah_off[j];
     }
-    const EncBlock& Bk = blocks[L.line_block[l]];
-    uint16_t* dst = reinterpret_cast<uint16_t*>(out + Bk.out_off + 16u + Bk.off_wah) + L.wah_off[j];
 #pragma unroll
     for (int r = 0; r < WAH_WIDE_ROUNDS; ++r) {
         const uint32_t gb = ((uint32_t)r * 1024u + tid) * 32u;
@@ -1791,17 +1821,17 @@ static bool wah_units_wide_ok(uint32_t y_stride64) {
            (uint64_t)y_stride64 * 64u <= (uint64_t)WAH_WIDE_UNITS * 32u * WAH_BITS;
 }
 
-template <bool WRITE_PASS>
+template <int MODE>
 static hipError_t launch_wah_units_wide(hipStream_t s, const EncBlock* blocks, const EncLines& L, const uint32_t* d_total_wah,
                                         uint32_t max_wah, uint8_t* out, const uint64_t* d_result) {
     const uint32_t rw = L.y_stride64 * 2u;
     const uint32_t units = ((rw * 32u + WAH_BITS - 1u) / WAH_BITS + 31u) / 32u;
     const uint32_t row_words = ((units * 15u + 1u) > rw ? (units * 15u + 1u) : rw) + 3u & ~3u;  // every unit's 15 words (+ the literal read)
     const uint32_t lds = 4u * (row_words + WAH_WIDE_UNITS + 2u * 16u * WAH_WIDE_ROUNDS + 16u * WAH_WIDE_ROUNDS + 2u);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units_wide<WRITE_PASS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units_wide<MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_wah_units_wide<WRITE_PASS><<<dim3(max_wah), dim3(1024), lds, s>>>(blocks, L, d_total_wah, max_wah, out, d_result, row_words);
+    k_wah_units_wide<MODE><<<dim3(max_wah), dim3(1024), lds, s>>>(blocks, L, d_total_wah, max_wah, out, d_result, row_words);
     return hipGetLastError();
 }
 
@@ -1817,14 +1847,19 @@ bool wah_units_any(uint32_t y_stride64) { return wah_units_ok(y_stride64) || wah
 hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_total_wah, uint32_t max_wah) {
     if (!max_wah) return hipSuccess;
     const uint32_t per_wg = 4u * WAH_LINES_PER_WAVE;
-    if (wah_units_wide_ok(L.y_stride64)) return launch_wah_units_wide<false>(s, nullptr, L, d_total_wah, max_wah, nullptr, nullptr);
+    if (wah_units_wide_ok(L.y_stride64))
+        return L.wah_inplace ? launch_wah_units_wide<2>(s, nullptr, L, d_total_wah, max_wah, nullptr, nullptr)
+                             : launch_wah_units_wide<0>(s, nullptr, L, d_total_wah, max_wah, nullptr, nullptr);
     if (wah_units_ok(L.y_stride64)) {
         const uint32_t lds = 4u * 4u * WAH_UNIT_WAVE_WORDS;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const void* fn = L.wah_inplace ? reinterpret_cast<const void*>(&k_wah_units<2>) : reinterpret_cast<const void*>(&k_wah_units<0>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        k_wah_units<false><<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), lds, s>>>(nullptr, L, d_total_wah, max_wah,
-                                                                                         nullptr, nullptr);
+        const dim3 grid((max_wah + per_wg - 1u) / per_wg);
+        if (L.wah_inplace)
+            k_wah_units<2><<<grid, dim3(256), lds, s>>>(nullptr, L, d_total_wah, max_wah, nullptr, nullptr);
+        else
+            k_wah_units<0><<<grid, dim3(256), lds, s>>>(nullptr, L, d_total_wah, max_wah, nullptr, nullptr);
         return hipGetLastError();
     }
     if (const uint32_t upl = wah_units_small_upl(L)) {
@@ -1861,7 +1896,9 @@ __global__ void __launch_bounds__(256) k_wah_write(const EncBlock* __restrict__ 
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m_dst, (int)k);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m_dst >> 32), (int)k);
         uint16_t* dst = reinterpret_cast<uint16_t*>(((uint64_t)hi << 32) | lo);
-        if (!L.wah_scratch) {
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)m_n, (int)k);
+        // no words kept by the sizing pass (none at all, or this line's did not fit its row): encode from the row
+        if (L.wah_inplace ? !wah_fits_row(n, L.y_stride64) : !L.wah_scratch) {
             const uint32_t* row = reinterpret_cast<const uint32_t*>(L.yrows + (size_t)j * L.y_stride64);
             (void)wave_wah_encode_row<true>(row, (uint32_t)__builtin_amdgcn_readlane((int)m_nbits, (int)k), dst);
             continue;
@@ -1869,8 +1906,8 @@ __global__ void __launch_bounds__(256) k_wah_write(const EncBlock* __restrict__ 
         // the sizing pass already produced the words: move them to their final place, 4 bytes per
         // store (the destination is only 2-byte aligned: an odd start takes one word by itself, the
         // source words are then re-paired)
-        const uint16_t* src = L.wah_scratch + (size_t)j * L.wah_scratch_stride;  // 4-byte aligned rows
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)m_n, (int)k);
+        const uint16_t* src = L.wah_inplace ? reinterpret_cast<const uint16_t*>(L.yrows + (size_t)j * L.y_stride64)
+                                            : L.wah_scratch + (size_t)j * L.wah_scratch_stride;  // 4-byte aligned rows
         const uint32_t head = (uint32_t)((reinterpret_cast<uint64_t>(dst) >> 1) & 1ull);
         if (head && n && lane == 0) dst[0] = src[0];
         if (n <= head) continue;
@@ -1893,14 +1930,15 @@ hipError_t launch_wah_write(hipStream_t s, const EncBlock* blocks, const EncLine
                             uint8_t* out, const uint64_t* d_result) {
     if (!max_wah) return hipSuccess;
     const uint32_t per_wg = 4u * WAH_LINES_PER_WAVE;
-    if (!L.wah_scratch && wah_units_wide_ok(L.y_stride64)) return launch_wah_units_wide<true>(s, blocks, L, nullptr, max_wah, out, d_result);
-    if (!L.wah_scratch && wah_units_ok(L.y_stride64)) {  // classify again, words straight into place
+    if (!L.wah_scratch && !L.wah_inplace && wah_units_wide_ok(L.y_stride64))
+        return launch_wah_units_wide<1>(s, blocks, L, nullptr, max_wah, out, d_result);
+    if (!L.wah_scratch && !L.wah_inplace && wah_units_ok(L.y_stride64)) {  // classify again, words straight into place
         const uint32_t lds = 4u * 4u * WAH_UNIT_WAVE_WORDS;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units<true>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units<1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        k_wah_units<true><<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), lds, s>>>(blocks, L, nullptr, max_wah, out,
-                                                                                        d_result);
+        k_wah_units<1><<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), lds, s>>>(blocks, L, nullptr, max_wah, out,
+                                                                                     d_result);
         return hipGetLastError();
     }
     k_wah_write<<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), 0, s>>>(blocks, L, max_wah, out, d_result);

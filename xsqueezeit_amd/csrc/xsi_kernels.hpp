@@ -45,6 +45,7 @@ struct EncLines {
     uint32_t no_multi;
     uint16_t* wah_scratch;      // [rank][wah_scratch_stride] WAH16 words of each line (encoded once, copied to place)
     uint32_t wah_scratch_stride;
+    uint32_t wah_inplace;       // the sizing pass leaves a line's words in the line's own y row (k_wah_units / _wide MODE 2)
     uint32_t* flagbits;         // [n_blocks][FV_COUNT][MAX_BIN_PER_BLOCK/32] packed flag vectors
     uint16_t* flagwah;          // [n_blocks][FV_COUNT][FLAG_WORDS_MAX] encoded flag vectors
 };
@@ -74,6 +75,7 @@ struct EncSide {
 // WAH lines (minor allele count above the threshold) of every block_len lines, from the per-line counts
 hipError_t launch_wah_lines_per_block(hipStream_t s, const uint32_t* cnt, uint64_t n_lines, uint32_t block_len, uint32_t nbits,
                                       uint32_t thr, uint32_t* out);
+hipError_t launch_compare_u32(hipStream_t s, const uint32_t* a, const uint32_t* b, uint64_t n, uint32_t* n_diff);
 hipError_t launch_count_rows(hipStream_t s, const uint32_t* planes, uint32_t stride_w, uint32_t nbits,
                              uint32_t n_rows, uint32_t* cnt);
 hipError_t launch_classify(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, const EncLines& L);
