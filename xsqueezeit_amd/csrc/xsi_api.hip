@@ -361,16 +361,27 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
         for (auto& b : blocks_h) max_bin = b.n_bin > max_bin ? b.n_bin : max_bin;
         const uint64_t per_line = (1ull + (p->mac_threshold < N / 2u ? p->mac_threshold : N / 2u)) * L.aet;
         sp_stride = (max_bin * per_line + 255u) & ~255ull;
-        if (sp_stride * n_blocks <= (1ull << 30) && !getenv("XSI_NO_SPARSE_OVERLAP")) WS(sp_scratch, "enc.sparse_scratch", sp_stride * n_blocks);
+        // (worst-case regions: 2.5 GB for the 153 blocks of a configs[3] shard, where the sparse lists take 19 ms if they wait for the chain)
+        if (sp_stride * n_blocks <= (4ull << 30) && !getenv("XSI_NO_SPARSE_OVERLAP")) WS(sp_scratch, "enc.sparse_scratch", sp_stride * n_blocks);
     }
-    if (sp_scratch) {
+    // The chain over several workgroups per block fills every CU's registers with workgroups that wait for one
+    // another: sparse work started first holds CUs back from it for as long as it runs (+18 ms of chain for 19 ms of
+    // sparse lists at the configs[3] shard, and a group that stays incomplete long enough aborts the launch).  There
+    // the sparse lists start behind the chain and run beside the WAH sizing pass.
+    const bool sparse_behind_chain = chain_rank_enc_multi_supported(L);
+    auto fork_sparse = [&]() -> int {
         HIP_TRY(hipEventRecord(ctx->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
         HIP_TRY(launch_sparse_write(ctx->side, d_blocks, L, nullptr, nullptr, sp_scratch, sp_stride));
         HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
-    }
+        return XSI_OK;
+    };
+    if (sp_scratch && !sparse_behind_chain)
+        if (int rc = fork_sparse()) return rc;
     stage_mark(ctx, XSI_ST_CHAIN_ENC);
     HIP_TRY(launch_chain_encode(s, d_blocks, n_blocks, L, scratch_a, L.bin_nbits != nullptr));
+    if (sp_scratch && sparse_behind_chain)
+        if (int rc = fork_sparse()) return rc;
     stage_mark(ctx, XSI_ST_WAH_SIZE);
     HIP_TRY(launch_wah_sizes(s, L, d_totals, n_bin));
     stage_mark(ctx, XSI_ST_LAYOUT);
