@@ -3225,11 +3225,73 @@ __global__ void __launch_bounds__(T) k_sparse_fill(const uint8_t* __restrict__ f
     }
 }
 
+// Long rows (above 16 KiB): no copy of the row in LDS.  The workgroup stores the row's background (zeros, or ones up to
+// nbits for a negated line that is to be complemented) with 16-byte stores, and behind a barrier the thread that holds
+// the FIRST list entry of a 32-bit word stores that word whole (the list is ascending, block.hpp:59-65: the entries of
+// a word are neighbours).  The LDS form held two 1024-thread workgroups per CU: 38.6 ms per launch at 500 000
+// haplotypes, 0.4 TB/s of row stores.  Rows are whole 16-byte units on 16-byte addresses (checked by the launcher).
+__global__ void __launch_bounds__(256) k_sparse_fill_direct(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
+                                                            DecLines L, const uint32_t* __restrict__ d_totals,
+                                                            uint32_t* __restrict__ out_rows, uint32_t out_stride_w,
+                                                            int apply_negation) {
+    const uint32_t k = blockIdx.x;
+    if (k >= d_totals[2] || d_totals[3]) return;
+    const uint32_t l = L.sparse_lines[k];
+    const DecBlock& D = blocks[L.line_block[l]];
+    const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
+    const uint32_t nw = (nbits + 31u) >> 5;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t at = D.gt_off + D.off_sparse + L.sparse_start[k];
+    const uint8_t* p = file + at;
+    const bool in_file = at <= L.file_len && L.file_len - at >= L.aet;  // corrupt image: never read past it
+    uint32_t num = in_file ? rd_at(p, L.aet) : 0u;
+    const uint32_t msb = (L.aet == 2u) ? 0x8000u : 0x80000000u;
+    const bool neg = (num & msb) != 0u;
+    num &= ~msb;
+    {
+        const uint64_t room = in_file ? (L.file_len - at) / L.aet - 1u : 0u;
+        if (num > room) num = (uint32_t)room;
+    }
+    const bool ones_bg = neg && apply_negation;
+    const uint32_t last_mask = (nbits & 31u) ? (1u << (nbits & 31u)) - 1u : ~0u;
+    auto background = [&](uint32_t w) -> uint32_t { return !ones_bg || w >= nw ? 0u : (w == nw - 1u ? last_mask : ~0u); };
+    uint32_t* dst = out_rows + (size_t)l * out_stride_w;
+    {
+        uint4* dst4 = reinterpret_cast<uint4*>(dst);
+        for (uint32_t q = tid; q < out_stride_w / 4u; q += 256u)
+            dst4[q] = make_uint4(background(4u * q), background(4u * q + 1u), background(4u * q + 2u), background(4u * q + 3u));
+    }
+    __syncthreads();  // the background stores have been waited for: a word stored below lands behind them
+    for (uint32_t i = tid; i < num; i += 256u) {
+        const uint32_t idx = rd_at(p + (size_t)(1u + i) * L.aet, L.aet);
+        const uint32_t w = idx >> 5;
+        if (i && (rd_at(p + (size_t)i * L.aet, L.aet) >> 5) == w) continue;  // not the first entry of its word
+        if (w >= nw) continue;  // corrupt image: positions at or beyond nbits are dropped
+        uint32_t v = 1u << (idx & 31u);
+        for (uint32_t j = i + 1u; j < num; ++j) {
+            const uint32_t nx = rd_at(p + (size_t)(1u + j) * L.aet, L.aet);
+            if ((nx >> 5) != w) break;
+            v |= 1u << (nx & 31u);
+        }
+        if (w == nw - 1u) v &= last_mask;
+        dst[w] = ones_bg ? (background(w) & ~v) : v;
+    }
+    if (tid == 0) {
+        L.ones[l] = neg ? nbits - num : num;  // sparse_extract: ones = negated ? N - num : num
+        if (neg) L.kind[l] |= KIND_NEGATED;
+    }
+}
+
 hipError_t launch_sparse_fill(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
                               uint32_t max_sparse, const uint32_t* d_totals, uint32_t* out_rows,
                               uint32_t out_stride_w, int apply_negation) {
     if (!max_sparse) return hipSuccess;
     const uint32_t lds = out_stride_w * 4u;
+    if (lds > 16384u && (out_stride_w & 3u) == 0u && (reinterpret_cast<uintptr_t>(out_rows) & 15u) == 0u &&
+        !getenv("XSI_SPARSE_FILL_LDS")) {
+        k_sparse_fill_direct<<<dim3(max_sparse), dim3(256), 0, s>>>(file, blocks, L, d_totals, out_rows, out_stride_w, apply_negation);
+        return hipGetLastError();
+    }
     if (lds > 16384u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sparse_fill<1024>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
