@@ -950,9 +950,11 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
     // ranges; the expansion of range p+1 (side stream) runs underneath the chain of range p, which parks its
     // ranks in HBM between the launches (4 N bytes per block: 64 MB at 245 blocks of 64 976 haplotypes).  A whole second expansion
     // next to the chain costs the chain 1 ms of its 23.4 (measured): the expansion is almost free this way.
-    const uint32_t n_phases = [] {  // read per call (tests switch it); 12: 74.6 -> 71.0 ms per step at configs[2] (4: 72.2)
+    // Cutting the chain into launches costs nothing (24 launches behind a finished expansion: 23.5 ms, as one launch);
+    // the expansion beside it costs the chain 3.5 ms and hides 5.2 of its own 5.9.
+    const uint32_t n_phases = [] {  // read per call (tests switch it); ms per step at configs[2]: 1: 65.5, 12: 64.1, 24: 63.8, 32: 63.75
         const char* e = getenv("XSI_DEC_PHASES");
-        const int v = e ? atoi(e) : 12;
+        const int v = e ? atoi(e) : 24;
         return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
     }();
     if (n_phases > 1u && !any_haploid && P.n_wah >= 256u * P.n_blocks && rank_decode_phased_ok(L.N, L.yp_stride, P.n_blocks)) {
@@ -993,7 +995,9 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
             HIP_TRY(hipEventRecord(ctx->ev_phase[p], ctx->side2));
         }
         stage_mark(ctx, XSI_ST_DEC_EXPAND);  // what shows of the expansion: the wait for its first range
-        HIP_TRY(hipStreamWaitEvent(s, ctx->ev_phase[0], 0));
+        // (measurement: XSI_DEC_PHASES_SERIAL=1 lets every range expand before the first chain launch, which leaves
+        // the chain's launches by themselves: their time minus the unphased chain's is the cost of cutting it up)
+        HIP_TRY(hipStreamWaitEvent(s, ctx->ev_phase[getenv("XSI_DEC_PHASES_SERIAL") ? K - 1u : 0u], 0));
         stage_mark(ctx, XSI_ST_CHAIN_DEC);
         for (uint32_t p = 0; p < K; ++p) {
             const uint32_t* tab = d_tab + (size_t)p * (3u * nb + 1u);
