@@ -353,9 +353,10 @@ int xsi_accessor_open(xsi_accessor** a, xsi_hip_ctx* ctx, const char* path);
  * position = BM value (block<<15 | binary-line offset).  Returns the number of values written
  * (N_HAPS or N_SAMPLES) or <0.
  * An array handed in twice in a row (lines of 64 KiB and more) is page-locked by the accessor until it is closed
- * or another array takes its place, and filled by the copy engine directly; free such an array only after
+ * or another array takes its place, and the device stores the line into it directly; free such an array only after
  * xsi_accessor_close or after other arrays have been used.  XSI_ACCESSOR_NO_REGISTER=1 in the environment turns
- * this off (every line then goes through the accessor's own pinned window and a memcpy). */
+ * this off (every line then goes through the accessor's own pinned window and a memcpy); XSI_ACCESSOR_NO_ZEROCOPY=1
+ * keeps the page-locking but fills the array with a device-to-host copy instead of stores from the kernel. */
 int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_t gt_size, uint32_t n_alleles,
                                          uint64_t position);
 /* Accessor::get_genotypes without the htslib record: mallocs *h_gt when NULL (hap_samples ints),

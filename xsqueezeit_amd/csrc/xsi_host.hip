@@ -542,6 +542,7 @@ struct xsi_accessor {
     void* seen_dst = nullptr;       // the array of the call before
     void* reg_dst = nullptr;        // the array that is registered now
     size_t reg_bytes = 0;
+    int32_t* reg_dev = nullptr;     // the device's address of that array (the compose kernel may store into it)
     int32_t* direct_dst = nullptr;  // set for the duration of one call: where a single composed line should land
     bool direct_done = false;       // this call's line went there (not into h_rows)
     bool win_in_rows = true;        // the window's lines are in h_rows (false after a direct single-line copy)
@@ -741,13 +742,18 @@ static int accessor_compose(xsi_accessor* a, uint32_t first, uint32_t n, uint32_
     }
     // line metadata, per-line value counts and allele counts live in pinned host memory that the
     // kernel reads / writes directly (a few hundred bytes over PCIe): the only copy per call is the rows
-    int rc = compose_lines(a->ctx, a->P, a->D, a->h_meta, a->h_meta + a->win_rows, n, a->d_rows, N,
+    // A single line for a page-locked caller array: the compose kernel stores it there itself (the array's device
+    // address; posted writes over PCIe) - one submission and one completion less than kernel + copy.
+    static const bool zero_copy = getenv("XSI_ACCESSOR_NO_ZEROCOPY") == nullptr;
+    const bool direct = n == 1u && a->direct_dst;
+    const bool stores_direct = direct && zero_copy && a->reg_dev && a->direct_dst == a->reg_dst;
+    int rc = compose_lines(a->ctx, a->P, a->D, a->h_meta, a->h_meta + a->win_rows, n, stores_direct ? a->reg_dev : a->d_rows, N,
                            a->h_meta + 2ull * a->win_rows, a->h_counts, max_al);
     if (rc) return rc;
-    int32_t* const dst = (n == 1u && a->direct_dst) ? a->direct_dst : a->h_rows;
-    a->direct_done = dst != a->h_rows;  // tells the caller where the line went
+    int32_t* const dst = direct ? a->direct_dst : a->h_rows;
+    a->direct_done = direct;  // tells the caller where the line went
     a->win_in_rows = !a->direct_done;
-    HIP_TRY(hipMemcpyAsync(dst, a->d_rows, (size_t)n * N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (!stores_direct) HIP_TRY(hipMemcpyAsync(dst, a->d_rows, (size_t)n * N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     // latency path of a random-access query: poll instead of sleeping on the completion interrupt
     hipError_t q;
     while ((q = hipStreamQuery(s)) == hipErrorNotReady) {
@@ -968,9 +974,13 @@ int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_
         } else if (h_gt == a->seen_dst) {  // second call in a row with this array: page-lock it
             if (a->reg_dst) (void)hipHostUnregister(a->reg_dst);
             a->reg_dst = nullptr;
+            a->reg_dev = nullptr;
             if (hipHostRegister(h_gt, line_bytes, hipHostRegisterDefault) == hipSuccess) {
                 a->reg_dst = h_gt;
                 a->reg_bytes = line_bytes;
+                void* dev = nullptr;
+                if (hipHostGetDevicePointer(&dev, h_gt, 0) == hipSuccess) a->reg_dev = static_cast<int32_t*>(dev);
+                else (void)hipGetLastError();
                 a->direct_dst = h_gt;
             } else {
                 (void)hipGetLastError();
