@@ -2936,9 +2936,10 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
 
 // Rows above 16 KiB: one 1024-thread workgroup per WAH line.  The one-wave-per-line kernel above keeps the row in
 // LDS, so at 500 000 haplotypes (62.5 KB) only two of its one-wave workgroups fit a CU: 46 ms per launch.  Here
-// wave 0 expands the words into the LDS row as before, and all 16 waves turn the row into {bits, ones before}
-// pairs: thread t works on words i * 1024 + t (neighbouring lanes on neighbouring words), a wave scan per
-// stripe of 1024 words, the 16 x stripes totals scanned in row order by wave 0.
+// all 16 waves expand the words into the LDS row, 1024 words a round (group counts scanned per wave, the 16 wave
+// totals scanned in LDS), and all 16 waves turn the row into {bits, ones before} pairs: thread t works on words
+// 2 t, 2 t + 1 of a stripe of 2048 words, a wave scan per stripe, the 16 x stripes totals scanned in row order by
+// wave 0.  39 ms for the 750 k lines of a configs[3] shard by itself (94 GB of pairs: 2.4 TB/s).
 constexpr int WAH_WIDE_STRIPES = 20;  // 20 x 1024 words: rows up to 655 360 bits
 __global__ void __launch_bounds__(1024) k_wah_expand_wide(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
                                                           DecLines L, const uint32_t* __restrict__ d_totals,
