@@ -367,7 +367,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     // The chain over several workgroups per block fills every CU's registers with workgroups that wait for one
     // another: sparse work started first holds CUs back from it for as long as it runs (+18 ms of chain for 19 ms of
     // sparse lists at the configs[3] shard, and a group that stays incomplete long enough aborts the launch).  There
-    // the sparse lists start behind the chain and run beside the WAH sizing pass.
+    // the sparse lists start behind the chain and the WAH sizing pass.
     const bool sparse_behind_chain = chain_rank_enc_multi_supported(L);
     auto fork_sparse = [&]() -> int {
         HIP_TRY(hipEventRecord(ctx->ev_fork, s));
@@ -380,10 +380,12 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
         if (int rc = fork_sparse()) return rc;
     stage_mark(ctx, XSI_ST_CHAIN_ENC);
     HIP_TRY(launch_chain_encode(s, d_blocks, n_blocks, L, scratch_a, L.bin_nbits != nullptr));
-    if (sp_scratch && sparse_behind_chain)
-        if (int rc = fork_sparse()) return rc;
     stage_mark(ctx, XSI_ST_WAH_SIZE);
     HIP_TRY(launch_wah_sizes(s, L, d_totals, n_bin));
+    // (behind the sizing pass too: its 1024-thread workgroups take every wave slot, the lists would only queue up
+    // with it; they run beside the layout and the writing of the WAH words instead)
+    if (sp_scratch && sparse_behind_chain)
+        if (int rc = fork_sparse()) return rc;
     stage_mark(ctx, XSI_ST_LAYOUT);
     HIP_TRY(launch_block_layout(s, d_blocks, n_blocks, L, S, p->default_phased));
     HIP_TRY(launch_scan_blocks_out(s, d_blocks, n_blocks, out_capacity, d_block_offsets, d_result, 256u + region_offset));
