@@ -426,10 +426,13 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
             rec[3] = 3u * lane + 2u < W ? wtot[34u + 3u * lane] : 0u;
             __builtin_amdgcn_raw_buffer_store_b128(rec, rs_lflags, lane * 16u, (par * A.S + member) * 128u, 0);
         }
-        // ---- S1: the flag records of the lists my wave applies (lists w S .. w S + S - 1)
+        // ---- S1: the flag records of the lists my wave applies: list w of EVERY member (wave w of each member covers the
+        // same stretch of its member's haplotypes, so the 16 waves get lists of about equal length; S consecutive
+        // lists = eight waves of one member measured 8 ms slower over the configs[3] shard: the waves of a workgroup
+        // finish their main phase in issue order and the late ones' lists were also the long-waited ones)
         uint32_t cnt_l = 0;
         {
-            const uint32_t l = w * A.S + (lane < A.S ? lane : 0u), ml = l >> 4, wl = l & 15u, rq = wl / 3u, rc = wl - 3u * rq;
+            const uint32_t ml = lane < A.S ? lane : 0u, wl = w, rq = wl / 3u, rc = wl - 3u * rq;  // list w of member `lane`
             uint32_t spins = 0;
             t_start = 0;
             for (;;) {
@@ -439,7 +442,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                     break;
                 }
                 if (give_up(spins)) return false;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(0);  // (s_sleep 1 between polls: 4 ms slower over the configs[3] shard)
             }
         }
         prof(1);  // barrier + wait for the lists
@@ -447,7 +450,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
         {
             uint32_t member_v = member, slice_lds_v = slice_lds;
             asm volatile("" : "+v"(member_v), "+v"(slice_lds_v));  // operands of the hand-written entry step below
-            const uint32_t* lst = glists + (size_t)(par * n_lists + w * A.S) * MULTI_LIST_CAP;
+            const uint32_t* lst = glists + (size_t)(par * n_lists + w) * MULTI_LIST_CAP;  // + k * 16 lists: member k's
             uint32_t cnt[SMAX], longest = 0;
 #pragma unroll
             for (int k = 0; k < SMAX; ++k) {
@@ -461,7 +464,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                 for (int k = 0; k < SMAX; ++k) {
                     // lists are whole 64-entry stores; beyond a list the range check returns 0, masked below
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                        (void*)(lst + (size_t)k * MULTI_LIST_CAP), 0, (int)(cnt[k] * 4u), 0x00020000);
+                        (void*)(lst + (size_t)k * 16u * MULTI_LIST_CAP), 0, (int)(cnt[k] * 4u), 0x00020000);
                     rk[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (i0 + lane * 4u) * 4u, 0, 16);
                 }
 #pragma unroll
@@ -546,7 +549,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                     break;
                 }
                 if (give_up(spins)) return false;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(0);
             }
         }
         prof(5);  // wait for the slices
