@@ -2961,24 +2961,30 @@ __global__ void __launch_bounds__(1024) k_wah_expand_wide(const uint8_t* __restr
     }
     if (j >= d_totals[1] || d_totals[3]) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    for (uint32_t i = tid; i < rw; i += 1024u) row[i] = 0;
+    // The line's metadata is a chain of three dependent loads and its first words a fourth: with two workgroups per CU
+    // nothing else covers them, so they are issued before the row is cleared, and every round of 1024 words fetches
+    // the next round's words before it works on its own (38.5 -> 36.1 ms for the WAH lines of a configs[3] shard).
     const uint32_t l = L.wah_lines[j];
     const DecBlock& D = blocks[L.line_block[l]];
     const uint32_t start = L.wah_start[j];
     const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
+    using GlobU16W = const __attribute__((address_space(1))) uint16_t;
+    GlobU16W* src = (GlobU16W*)(reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah) + start);  // global, not flat
+    const uint32_t max_words = D.wah_words - start;
+    uint32_t nxt_word = (uint32_t)src[tid < max_words ? tid : 0u];
+    for (uint32_t i = tid; i < rw; i += 1024u) row[i] = 0;
     __syncthreads();
     {
         // all 16 waves expand the line's words, 1024 at a time (wave_wah_expand_row's logic with the first group of
         // a word taken from a workgroup scan): a line of 500 000 bits has some 2500 words
-        const uint16_t* src = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah) + start;
-        const uint32_t max_words = D.wah_words - start;
         const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
         const uint32_t row_bits = ((nbits + 31u) >> 5) << 5;
         uint32_t gbase = 0, cnt1 = 0;
         for (uint32_t wbase = 0; wbase < max_words && gbase < G; wbase += 1024u) {
             const uint32_t wi = wbase + tid;
             const bool have = wi < max_words;
-            const uint32_t word = have ? (uint32_t)src[wi] : 0u;
+            const uint32_t word = have ? nxt_word : 0u;
+            nxt_word = (uint32_t)src[wi + 1024u < max_words ? wi + 1024u : 0u];  // unconditional: in flight across this round
             const bool fill = (word & 0x8000u) != 0u;
             const uint32_t ng = have ? (fill ? (word & WAH_MAXC) : 1u) : 0u;
             const uint32_t inc = wave_scan_incl_dpp(ng);
