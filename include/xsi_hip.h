@@ -399,8 +399,9 @@ int xsi_accessor_allele_counts(xsi_accessor* a, uint64_t* h_counts, uint32_t n_a
  * the file's A_T: a_bytes reports 4) receives the PBWT arrangement in force at the LAST of those lines, as the
  * reference's `a` pointer shows it after its seeks: a[i] = haplotype at position i of the permuted rows.  It is
  * rebuilt on the device from the block's decoded lines (the decode kernels track ranks, never `a`), one stable
- * partition per earlier WAH line of the block: a replay, as in the reference.  Blocks with fully haploid lines:
- * XSI_ERR_UNSUPPORTED.  default_allele as in the reference: 1 when the first line is a negated sparse line.
+ * partition per earlier WAH line of the block: a replay, as in the reference (a fully haploid line partitions the
+ * haplotypes by their sample's bit, internal_gt_record.hpp:50-59; its words are the sample bits gathered through the
+ * even members of `a`, halved).  default_allele as in the reference: 1 when the first line is a negated sparse line.
  */
 typedef struct xsi_internal_access {
     uint64_t position;

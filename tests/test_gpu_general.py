@@ -814,3 +814,70 @@ def test_writer_packs_on_append_and_mixes_line_kinds(tmp_path, every, use_row_bu
 
     got = write(str(tmp_path / "a.xsi").encode())
     assert got == ref
+
+
+def test_accessor_internal_access_with_haploid_lines(tmp_path):
+    """get_internal_access in blocks that hold fully haploid lines (one value per sample): such a line partitions the
+    diploid arrangement by its sample's bit (pbwt_sort1, internal_gt_record.hpp:50-59) and its WAH words are the
+    sample bits gathered through the even members of `a`, halved (haploid_rearrangement_from_diploid,
+    interfaces.hpp:318-333).  Checked by recomputation in numpy, as test_accessor_internal_access."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    rng = np.random.default_rng(777)
+    n, block_len, thr = 400, 50, 6
+    N = 2 * n
+    lines = []
+    for i in range(2 * block_len + 9):
+        if i % 4 == 2:
+            al = (rng.random(n) < float(rng.random()) * 0.6).astype(np.int32)
+            lines.append((((al + 1) << 1).astype(np.int32), 2))   # haploid: n values
+        else:
+            lines.extend(_random_lines(rng, n, 1))
+    dp = oracle.default_phased_of(lines, n)
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=thr, default_phased=dp)
+    path = tmp_path / "iah.xsi"
+    path.write_bytes(ref)
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
+
+    def bits_of(i):
+        return (((lines[i][0] >> 1) - 1) == 1).astype(np.uint8)
+
+    def is_wah(x):
+        c = int(x.sum())
+        return min(c, x.size - c) > thr
+
+    checked_hap = checked_dip = 0
+    for i in list(range(0, len(lines), 7)) + [2, 6, block_len + 2, len(lines) - 1]:
+        info = binding.InternalAccess()
+        sp = np.zeros(1, dtype=np.uint8)
+        offs = np.zeros(1, dtype=np.uint64)
+        arr = np.zeros(N, dtype=np.uint32)
+        bm = ((i // block_len) << 15) | (i % block_len)
+        binding.check(L.xsi_accessor_get_internal_access(a, 2, bm, ctypes.byref(info), sp.ctypes.data, offs.ctypes.data,
+                                                         arr.ctypes.data))
+        exp_a = np.arange(N, dtype=np.uint32)
+        for j in range((i // block_len) * block_len, i):
+            x = bits_of(j)
+            if is_wah(x):
+                key = x[exp_a // 2] if x.size == n else x[exp_a]
+                exp_a = np.concatenate([exp_a[key == 0], exp_a[key == 1]])
+        assert np.array_equal(arr, exp_a), "line %d" % i
+        x = bits_of(i)
+        assert sp[0] == (0 if is_wah(x) else 1), "line %d" % i
+        if not sp[0]:
+            img = np.frombuffer((ctypes.c_uint8 * info.image_len).from_address(info.image), dtype=np.uint8)
+            o = int(offs[0])
+            words = img[o:o + 2 * (N // 15 + 2)].view(np.uint16)
+            if x.size == n:
+                a1 = arr[arr % 2 == 0] // 2
+                y, _, _ = oracle.wah_extract(words, n)
+                assert np.array_equal(y, x[a1]), "haploid line %d" % i
+                checked_hap += 1
+            else:
+                y, _, _ = oracle.wah_extract(words, N)
+                assert np.array_equal(y, x[arr]), "line %d" % i
+                checked_dip += 1
+    assert checked_hap >= 3 and checked_dip >= 3
+    L.xsi_accessor_close(a)

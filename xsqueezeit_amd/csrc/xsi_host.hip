@@ -1185,17 +1185,20 @@ __global__ void __launch_bounds__(1024) k_arrangement_at(const uint32_t* __restr
     for (uint32_t l = 0; l < n_before; ++l) {
         if (!(kind[l] & KIND_WAH)) continue;  // sparse lines never touch a (gt_block.hpp:299-326)
         const uint32_t* row = planes + (size_t)l * stride_w;
+        // a fully haploid line has one bit per SAMPLE: haplotype h goes by its sample's bit (pbwt_sort1,
+        // internal_gt_record.hpp:50-59; PBWTSorter::bool_pbwt_sort_two, gt_block.hpp:137-151)
+        const uint32_t hs = (kind[l] & KIND_HAPLOID) ? 1u : 0u;
         uint32_t zc = 0;
         for (uint32_t i = lo; i < hi; ++i) {
-            const uint32_t h = cur[i];
+            const uint32_t h = cur[i] >> hs;
             zc += 1u - ((row[h >> 5] >> (h & 31u)) & 1u);
         }
         uint64_t Z;
         const uint32_t zbase = (uint32_t)block_scan_excl64(zc, scan_lds, &Z);
         uint32_t zpos = zbase, opos = (uint32_t)Z + (lo - zbase);
         for (uint32_t i = lo; i < hi; ++i) {
-            const uint32_t h = cur[i];
-            if ((row[h >> 5] >> (h & 31u)) & 1u) nxt[opos++] = h;
+            const uint32_t h = cur[i], k = h >> hs;
+            if ((row[k >> 5] >> (k & 31u)) & 1u) nxt[opos++] = h;
             else nxt[zpos++] = h;
         }
         __threadfence_block();
@@ -1233,8 +1236,7 @@ int xsi_accessor_get_internal_access(xsi_accessor* a, uint32_t n_alleles, uint64
     if (offset + n_lines > a->P.n_bin)
         return set_error(XSI_ERR_ARG, "position offset %u (+%u alleles) beyond the %u binary lines of block %llu", offset, n_lines,
                          a->P.n_bin, (unsigned long long)block);
-    if (a->P.blocks_h.empty() || a->P.blocks_h[0].off_line_haploid != VAL_UNDEFINED)
-        return set_error(XSI_ERR_UNSUPPORTED, "get_internal_access: block %llu has fully haploid lines", (unsigned long long)block);
+    if (a->P.blocks_h.empty()) return set_error(XSI_ERR_FORMAT, "get_internal_access: block %llu not decoded", (unsigned long long)block);
     if (h_a) {
         const uint32_t N = a->P.L.N;
         uint32_t *d_a0, *d_a1, *d_which;
