@@ -881,3 +881,38 @@ def test_accessor_internal_access_with_haploid_lines(tmp_path):
                 checked_dip += 1
     assert checked_hap >= 3 and checked_dip >= 3
     L.xsi_accessor_close(a)
+
+
+def test_accessor_fills_a_caller_pinned_array(tmp_path):
+    """fill_genotype_array into an array the CALLER has page-locked (torch pinned memory): hipHostRegister refuses it
+    as already registered, the accessor uses it as it is (the kernel stores into it) and leaves it locked at close."""
+    import gpu_util as G
+    from oracle import oracle
+    torch = G.torch_mod()
+    L = binding.lib()
+    rng = np.random.default_rng(99)
+    n = 12000   # 96 KB lines: above the 64 KiB threshold of the direct path
+    lines = _random_lines(rng, n, 12, multi=True, missing=True)
+    dp = oracle.default_phased_of(lines, n)
+    ref = oracle.encode_file(lines, n, block_len=8, mac_thr=12, default_phased=dp)
+    path = tmp_path / "pinned.xsi"
+    path.write_bytes(ref)
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
+    t = torch.empty(2 * n, dtype=torch.int32, pin_memory=True)
+    buf = t.numpy()
+    bms, block, off = [], 0, 0
+    for i, (_, na) in enumerate(lines):
+        if i and i % 8 == 0:
+            block, off = block + 1, 0
+        bms.append((block << 15) | off)
+        off += na - 1
+    for i in (3, 3, 9, 0, 11, 5, 5):
+        buf[:] = -7
+        assert L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, lines[i][1], bms[i]) == 2 * n
+        assert np.array_equal(buf, lines[i][0]), "line %d" % i
+    L.xsi_accessor_close(a)
+    t.fill_(5)   # still the caller's pinned tensor
+    d = t.cuda(non_blocking=True)
+    torch.cuda.synchronize()
+    assert int(d.sum().item()) == 10 * n

@@ -543,6 +543,8 @@ struct xsi_accessor {
     void* reg_dst = nullptr;        // the array that is registered now
     size_t reg_bytes = 0;
     int32_t* reg_dev = nullptr;     // the device's address of that array (the compose kernel may store into it)
+    bool reg_owned = false;         // this accessor page-locked it (false: the caller had: it stays locked at close)
+    void* reg_failed = nullptr;     // an array that could not be page-locked: not tried again call after call
     int32_t* direct_dst = nullptr;  // set for the duration of one call: where a single composed line should land
     bool direct_done = false;       // this call's line went there (not into h_rows)
     bool win_in_rows = true;        // the window's lines are in h_rows (false after a direct single-line copy)
@@ -971,11 +973,15 @@ int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_
     if (gt_size >= a->hap_samples && line_bytes >= (64u << 10) && !getenv("XSI_ACCESSOR_NO_REGISTER")) {
         if (h_gt == a->reg_dst) {
             a->direct_dst = h_gt;
-        } else if (h_gt == a->seen_dst) {  // second call in a row with this array: page-lock it
-            if (a->reg_dst) (void)hipHostUnregister(a->reg_dst);
+        } else if (h_gt == a->seen_dst && h_gt != a->reg_failed) {  // second call in a row with this array: page-lock it
+            if (a->reg_dst && a->reg_owned && hipHostUnregister(a->reg_dst) != hipSuccess) (void)hipGetLastError();
             a->reg_dst = nullptr;
             a->reg_dev = nullptr;
-            if (hipHostRegister(h_gt, line_bytes, hipHostRegisterDefault) == hipSuccess) {
+            const hipError_t re = hipHostRegister(h_gt, line_bytes, hipHostRegisterDefault);
+            // an array the caller has page-locked already (hipHostMalloc, its own hipHostRegister) serves as it is
+            if (re == hipSuccess || re == hipErrorHostMemoryAlreadyRegistered) {
+                if (re != hipSuccess) (void)hipGetLastError();
+                a->reg_owned = re == hipSuccess;
                 a->reg_dst = h_gt;
                 a->reg_bytes = line_bytes;
                 void* dev = nullptr;
@@ -984,6 +990,7 @@ int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_
                 a->direct_dst = h_gt;
             } else {
                 (void)hipGetLastError();
+                a->reg_failed = h_gt;
             }
         }
     }
@@ -1319,7 +1326,7 @@ const char* xsi_accessor_sample_name(const xsi_accessor* a, uint64_t i) {
 void xsi_accessor_close(xsi_accessor* a) {
     if (!a) return;
     if (a->ctx) (void)hipStreamSynchronize(a->ctx->stream);
-    if (a->reg_dst && hipHostUnregister(a->reg_dst) != hipSuccess) (void)hipGetLastError();  // (the caller may have freed it already)
+    if (a->reg_dst && a->reg_owned && hipHostUnregister(a->reg_dst) != hipSuccess) (void)hipGetLastError();  // (the caller may have freed it already)
     for (auto& e : a->cache) (void)hipFree(e.mem);
     if (a->d_file) (void)hipFree(a->d_file);
     if (a->d_mini) (void)hipFree(a->d_mini);
