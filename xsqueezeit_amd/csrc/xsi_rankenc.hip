@@ -457,16 +457,19 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                 cnt[k] = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, k);
                 longest = cnt[k] > longest ? cnt[k] : longest;
             }
-            // all S lists of a step in flight together (the loop is bound by the round trips to L2, not by bytes)
-            for (uint32_t i0 = 0; i0 < longest; i0 += 256u) {
-                v4u rk[SMAX];
+            // All S lists of a step in flight together (the loop is bound by the round trips to L2, not by bytes), and a
+            // list's next piece is requested as soon as its current one has been worked on: the pieces of step i + 1
+            // travel while the rest of step i is applied.
+            v4u rk[SMAX];
+            auto load_piece = [&](int k, uint32_t i0) {
+                // lists are whole 64-entry stores; beyond a list the range check returns 0 (no memory request), masked below
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(lst + (size_t)k * 16u * MULTI_LIST_CAP), 0, (int)(cnt[k] * 4u), 0x00020000);
+                rk[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (i0 + lane * 4u) * 4u, 0, 16);
+            };
 #pragma unroll
-                for (int k = 0; k < SMAX; ++k) {
-                    // lists are whole 64-entry stores; beyond a list the range check returns 0, masked below
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                        (void*)(lst + (size_t)k * 16u * MULTI_LIST_CAP), 0, (int)(cnt[k] * 4u), 0x00020000);
-                    rk[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (i0 + lane * 4u) * 4u, 0, 16);
-                }
+            for (int k = 0; k < SMAX; ++k) load_piece(k, 0u);
+            for (uint32_t i0 = 0; i0 < longest; i0 += 256u) {
 #pragma unroll
                 for (int k = 0; k < SMAX; ++k) {
                     if (i0 + lane * 4u < cnt[k]) {
@@ -491,6 +494,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                                 : "memory", "vcc");
                         }
                     }
+                    load_piece(k, i0 + 256u);  // (behind the work on the current piece: its registers are free now)
                 }
             }
         }
