@@ -628,6 +628,11 @@ def main():
                          "stage_ms": stages, "stage_ms_per_step": stages_step, "chain_launches_per_step": launches},
             "roundtrip_equal": roundtrip_ok,
         }
+        if not args.count_on_device:
+            # the same step with the counting pass made on the device as well (measured by itself, outside the timed
+            # region, added here): what xsi_hip_encode_packed without producer counts costs
+            out["with_device_row_count"] = {"ms_per_step": ms_per_step + count_rows_ms,
+                                            "value": cells_job / ((dt / steps) + count_rows_ms * 1e-3)}
         if gather_ms is not None:
             out["gather_ms"] = gather_ms
             out["ms_per_step_per_rank"] = per_rank_ms
