@@ -107,7 +107,7 @@ class Writer:
         assert len(names) == n_samples
         arr = (ctypes.c_char_p * max(n_samples, 1))(*[s.encode() for s in names])
         self._h = lib().xo_writer_new(n_samples, block_len, mac_thr, default_phased,
-                                      1 if wah_encode_missing else 0, arr)
+                                      (2 if wah_encode_missing == 2 else (1 if wah_encode_missing else 0)), arr)
         if not self._h:
             raise MemoryError("xo_writer_new")
 

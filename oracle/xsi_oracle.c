@@ -306,6 +306,7 @@ struct xo_writer {
     uint32_t bcf_lines, binary_lines, max_vector_length;
     int missing_found, eov_found, phase_found, haploid_found;
     uint32_t *a, *b, *a1;
+    uint32_t* a_weird;  /* a_weirdness, gt_block.hpp:171,180: sorted by WS_PBWT_WAH only */
     buf_t is_wah;       /* one byte per binary line */
     buf_t has_missing;  /* one byte per BCF line */
     buf_t has_eov;      /* one byte per BCF line */
@@ -322,6 +323,7 @@ static void block_reset(xo_writer* w) {
     w->max_vector_length = 1; /* gt_block.hpp:168 */
     w->missing_found = w->eov_found = w->phase_found = w->haploid_found = 0;
     for (uint32_t i = 0; i < 2 * w->n_samples; ++i) w->a[i] = i; /* iota, gt_block.hpp:179 */
+    for (uint32_t i = 0; i < 2 * w->n_samples; ++i) w->a_weird[i] = i; /* :180 */
     w->is_wah.n = w->has_missing.n = w->has_eov.n = w->has_phase.n = w->haploid.n = w->n_alts.n = 0;
     w->wah.n = w->sparse.n = w->miss_sparse.n = w->miss_wah.n = w->eov_sparse.n = w->eov_wah.n = 0;
     w->phase_wah.n = 0;
@@ -341,15 +343,19 @@ xo_writer* xo_writer_new(uint32_t n_samples, uint32_t block_len, uint32_t mac_th
     w->block_len = block_len;
     w->mac_thr = mac_thr;
     w->default_phased = default_phased;
-    w->strat = wah_encode_missing ? WS_WAH : WS_SPARSE; /* gt_block.hpp:174-176, 417 */
+    /* gt_block.hpp:174-176, 417: WS_SPARSE, or WS_WAH with --wah-encode-missing.  wah_encode_missing == 2 (tests only)
+     * selects WS_PBWT_WAH, the version-4 default that the current CLI cannot choose any more but GtBlock still
+     * implements (gt_block.hpp:340-395) and the reader still decodes (accessor_internals_new.hpp:300-340, 503-533) */
+    w->strat = wah_encode_missing == 2 ? WS_PBWT_WAH : (wah_encode_missing ? WS_WAH : WS_SPARSE);
     w->aet_block = (n_samples <= 65535u) ? 2 : 4;
     w->aet_header = ((uint64_t)n_samples * 2 <= 65535u) ? 2 : 4;
     size_t na = (size_t)2 * n_samples;
     w->a = (uint32_t*)malloc((na ? na : 1) * sizeof(uint32_t));
     w->b = (uint32_t*)malloc((na ? na : 1) * sizeof(uint32_t));
     w->a1 = (uint32_t*)malloc((na ? na : 1) * sizeof(uint32_t));
+    w->a_weird = (uint32_t*)malloc((na ? na : 1) * sizeof(uint32_t));
     w->names = (char**)calloc(n_samples ? n_samples : 1, sizeof(char*));
-    if (!w->a || !w->b || !w->a1 || !w->names) {
+    if (!w->a || !w->b || !w->a1 || !w->a_weird || !w->names) {
         xo_writer_free(w);
         return NULL;
     }
@@ -377,6 +383,7 @@ void xo_writer_free(xo_writer* w) {
         for (uint32_t i = 0; i < w->n_samples; ++i) free(w->names[i]);
     free(w->names);
     free(w->a);
+    free(w->a_weird);
     free(w->b);
     free(w->a1);
     free(w->indices);
@@ -485,7 +492,7 @@ static int block_flush(xo_writer* w) {
         int rc = wah_encode_bits_buf(f, v, w->binary_lines);
         free(v);
         if (rc) return -1;
-        if (w->strat == WS_WAH) {
+        if (w->strat != WS_SPARSE) {
             vals[KEY_MATRIX_MISSING] = (uint32_t)(f->n - gt_start);
             if (buf_put(f, w->miss_wah.p, w->miss_wah.n)) return -1;
         } else {
@@ -500,7 +507,7 @@ static int block_flush(xo_writer* w) {
         int rc = wah_encode_bits_buf(f, v, w->binary_lines);
         free(v);
         if (rc) return -1;
-        if (w->strat == WS_WAH) {
+        if (w->strat != WS_SPARSE) {
             vals[KEY_MATRIX_END_OF_VECTORS] = (uint32_t)(f->n - gt_start);
             if (buf_put(f, w->eov_wah.p, w->eov_wah.n)) return -1;
         } else {
@@ -618,6 +625,22 @@ int xo_writer_append(xo_writer* w, const int32_t* gt, int32_t ngt, int32_t n_all
         if (l_missing && wah_encode_pred(&w->miss_wah, gt, NULL, (size_t)ngt, PRED_MISSING, 0)) return -1;
         if (l_eov && wah_encode_pred(&w->eov_wah, gt, NULL, (size_t)ngt, PRED_EOV, 0)) return -1;
     }
+    if (w->strat == WS_PBWT_WAH && (l_missing || l_eov)) {
+        /* gt_block.hpp:340-395: the lines go through a_weirdness, which is then partitioned by "missing or end of
+         * vector" (WeirdnessPred).  A fully haploid line would be encoded through a1 and leave a_weirdness unsorted
+         * (:350, :380-384) while the reader indexes a_weird directly (accessor_internals_new.hpp:313): refused here */
+        if ((uint32_t)ngt != 2 * w->n_samples) return -1;
+        if (l_missing && wah_encode_pred(&w->miss_wah, gt, w->a_weird, (size_t)ngt, PRED_MISSING, 0)) return -1;
+        if (l_eov && wah_encode_pred(&w->eov_wah, gt, w->a_weird, (size_t)ngt, PRED_EOV, 0)) return -1;
+        size_t u = 0, v = 0;
+        for (size_t i = 0; i < (size_t)ngt; ++i) {
+            const int32_t g = gt[w->a_weird[i]];
+            const int weird = (g == XO_INT32_VECTOR_END) || ((g >> 1) == 0);
+            if (!weird) w->a_weird[u++] = w->a_weird[i];
+            else w->b[v++] = w->a_weird[i];
+        }
+        memcpy(w->a_weird + u, w->b, v * sizeof(uint32_t));
+    }
     if (l_phase && wah_encode_pred(&w->phase_wah, gt, NULL, (size_t)ngt, PRED_PHASE, w->default_phased)) return -1;
 
     w->bcf_lines++;
@@ -717,7 +740,9 @@ struct xo_reader {
     const uint8_t *wah_p, *sparse_p, *miss_wah_p, *miss_sparse_p, *eov_wah_p, *eov_sparse_p, *phase_p;
     size_t pos, weird_pos, phase_pos;
     uint32_t *a, *b, *a1;
+    uint32_t* a_weird; /* accessor_internals_new.hpp:62,146 */
     uint8_t *y, *y2, *x;
+    uint8_t* y3;
     size_t ones;
     int sparse_negated;
     uint32_t* sparse;
@@ -763,9 +788,11 @@ xo_reader* xo_reader_open(const uint8_t* file, size_t len) {
     r->a1 = (uint32_t*)malloc(n * sizeof(uint32_t));
     r->y = (uint8_t*)calloc(n, 1);
     r->y2 = (uint8_t*)calloc(n, 1);
+    r->y3 = (uint8_t*)calloc(n, 1);
+    r->a_weird = (uint32_t*)malloc(n * sizeof(uint32_t));
     r->x = (uint8_t*)calloc(n, 1);
     r->sparse = (uint32_t*)malloc(n * sizeof(uint32_t));
-    if (!r->a || !r->b || !r->a1 || !r->y || !r->y2 || !r->x || !r->sparse) {
+    if (!r->a || !r->b || !r->a1 || !r->y || !r->y2 || !r->y3 || !r->a_weird || !r->x || !r->sparse) {
         xo_reader_close(r);
         return NULL;
     }
@@ -779,6 +806,8 @@ void xo_reader_close(xo_reader* r) {
     free(r->a1);
     free(r->y);
     free(r->y2);
+    free(r->y3);
+    free(r->a_weird);
     free(r->x);
     free(r->sparse);
     free(r->is_wah);
@@ -824,6 +853,7 @@ static const uint8_t* dict_ptr(const xo_reader* r, const dict_ent* d, uint32_t k
 
 static void reader_reset(xo_reader* r) { /* reset(), accessor_internals_new.hpp:386-405 */
     for (size_t i = 0; i < r->N_HAPS; ++i) r->a[i] = (uint32_t)i;
+    for (size_t i = 0; i < r->N_HAPS; ++i) r->a_weird[i] = (uint32_t)i; /* :394 */
     r->pos = r->weird_pos = r->phase_pos = 0;
     r->wah_p = r->wah_origin;
     r->sparse_p = r->sparse_origin;
@@ -936,8 +966,8 @@ static void update_a(xo_reader* r) {
     }
 }
 
-/* weirdness_advance, accessor_internals_new.hpp:478-537 (WS_SPARSE and WS_WAH; WS_PBWT_WAH is a
- * v4-era strategy the current writer cannot produce, kept for its pointer walk only) */
+/* weirdness_advance, accessor_internals_new.hpp:478-537 (all three strategies; WS_PBWT_WAH, the version-4 default,
+ * has no fixture of the reference's to pin it: restated from the source alone) */
 static void weirdness_advance(xo_reader* r, size_t steps, size_t n) {
     for (size_t i = 0; i < steps; ++i) {
         int m = r->has_missing_vec && r->l_missing[r->weird_pos];
@@ -945,6 +975,21 @@ static void weirdness_advance(xo_reader* r, size_t steps, size_t n) {
         if (r->strat == WS_SPARSE) {
             if (m) r->miss_sparse_p = sparse_read(r, r->miss_sparse_p, 0, NULL, NULL, 0);
             if (e) r->eov_sparse_p = sparse_read(r, r->eov_sparse_p, 0, NULL, NULL, 0);
+        } else if (r->strat == WS_PBWT_WAH && (m || e)) {
+            /* :492-533: the lines are extracted and a_weird is partitioned by "missing or end of vector"; on a fully
+             * haploid line the sort is commented out in the reference (:508-510, :516-518, :525-527) */
+            memset(r->y2, 0, r->N_HAPS);
+            memset(r->y3, 0, r->N_HAPS);
+            if (m) r->miss_wah_p += 2 * xo_wah_extract((const uint16_t*)r->miss_wah_p, n, r->y2, NULL);
+            if (e) r->eov_wah_p += 2 * xo_wah_extract((const uint16_t*)r->eov_wah_p, n, r->y3, NULL);
+            if (!r->haploid[r->weird_pos]) {
+                size_t u = 0, v = 0;
+                for (size_t k = 0; k < r->N_HAPS; ++k) {
+                    if (!(r->y2[k] | r->y3[k])) r->a_weird[u++] = r->a_weird[k];
+                    else r->b[v++] = r->a_weird[k];
+                }
+                memcpy(r->a_weird + u, r->b, v * sizeof(uint32_t));
+            }
         } else {
             if (m) r->miss_wah_p += 2 * wah_skip((const uint16_t*)r->miss_wah_p, n);
             if (e) r->eov_wah_p += 2 * wah_skip((const uint16_t*)r->eov_wah_p, n);
@@ -1079,10 +1124,13 @@ int64_t xo_reader_fill_genotype_array(xo_reader* r, int32_t* gt, size_t gt_size,
                     size_t i = r->sparse[k];
                     gt[i] = XO_GT_MISSING | ((int32_t)(i & 1) & DP);
                 }
-            } else { /* WS_WAH / WS_PBWT_WAH: a_weird is identity for WS_WAH */
+            } else { /* WS_WAH / WS_PBWT_WAH through a_weird (the identity for WS_WAH), :308-318 */
                 (void)xo_wah_extract((const uint16_t*)r->miss_wah_p, N, r->y2, &n_missing);
                 for (size_t i = 0; i < N; ++i)
-                    if (r->y2[i]) gt[i] = XO_GT_MISSING | ((int32_t)(i & 1) & DP);
+                    if (r->y2[i]) {
+                        const size_t idx = r->a_weird[i];
+                        gt[idx] = XO_GT_MISSING | ((int32_t)(idx & 1) & DP);
+                    }
             }
         }
         if (r->has_eov_vec && r->l_eov[start]) {
@@ -1094,7 +1142,7 @@ int64_t xo_reader_fill_genotype_array(xo_reader* r, int32_t* gt, size_t gt_size,
             } else {
                 (void)xo_wah_extract((const uint16_t*)r->eov_wah_p, N, r->y2, &n_eovs);
                 for (size_t i = 0; i < N; ++i)
-                    if (r->y2[i]) gt[i] = XO_INT32_VECTOR_END;
+                    if (r->y2[i]) gt[r->a_weird[i]] = XO_INT32_VECTOR_END; /* :331-337 */
             }
         }
         weirdness_advance(r, n_alleles - 1, N);

@@ -916,3 +916,45 @@ def test_accessor_fills_a_caller_pinned_array(tmp_path):
     d = t.cuda(non_blocking=True)
     torch.cuda.synchronize()
     assert int(d.sum().item()) == 10 * n
+
+
+@pytest.mark.parametrize("n,n_lines,block_len,kw", [
+    (37, 150, 32, dict(missing=True, eov=True, phase=True, multi=True)),
+    (600, 90, 40, dict(missing=True, eov=True)),
+    (2504, 60, 16, dict(missing=True, multi=True)),
+    (70000, 6, 3, dict(missing=True, eov=True, multi=True)),   # u32 A_T, rows above 16 KiB
+])
+def test_decode_pbwt_weirdness_files(n, n_lines, block_len, kw, tmp_path):
+    """Files whose missing / end-of-vector lines are WAH lines permuted by a PBWT-sorted a_weirdness (WS_PBWT_WAH, the
+    version-4 default; gt_block.hpp:340-395, accessor_internals_new.hpp:300-340, 503-533), written by the oracle (the
+    reference's CLI cannot select the strategy any more; no fixture of the reference's exists for it, so this pins the
+    GPU decode to the CPU restatement and to the source rows only).  Whole-file decode and random accessor queries."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    rng = np.random.default_rng(31 * n + n_lines)
+    lines = _random_lines(rng, n, n_lines, **kw)
+    dp = oracle.default_phased_of(lines, n)
+    ref = oracle.encode_file(lines, n, block_len=block_len, mac_thr=max(1, n // 500), default_phased=dp, wah_encode_missing=2)
+    nal = [na for _, na in lines]
+    rows, counts = G.decode_gt(ref, nal)
+    oref = oracle.decode_file(ref, nal, block_len=block_len)
+    for i in range(len(lines)):
+        assert np.array_equal(rows[i], lines[i][0]), "line %d vs source" % i
+        assert np.array_equal(rows[i], oref[i][0]), "line %d vs oracle" % i
+        assert np.array_equal(counts[i][:nal[i]], oref[i][1][:nal[i]]), "line %d counts" % i
+    path = tmp_path / "pw.xsi"
+    path.write_bytes(ref)
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
+    buf = np.zeros(2 * n, dtype=np.int32)
+    bms, block, off = [], 0, 0
+    for i, (_, na) in enumerate(lines):
+        if i and i % block_len == 0:
+            block, off = block + 1, 0
+        bms.append((block << 15) | off)
+        off += na - 1
+    for i in [int(v) for v in rng.integers(0, len(lines), 12)]:
+        assert L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, nal[i], bms[i]) == 2 * n
+        assert np.array_equal(buf, lines[i][0]), "accessor line %d" % i
+    L.xsi_accessor_close(a)

@@ -489,6 +489,73 @@ __global__ void __launch_bounds__(64) k_dec_side_planes(const uint8_t* __restric
     }
 }
 
+// WS_PBWT_WAH (the version-4 default; gt_block.hpp:340-395 writes it, accessor_internals_new.hpp:300-340 and 503-533 read
+// it): the missing / end-of-vector lines of a block are stored permuted by a_weirdness, which starts as the identity
+// and is partitioned by "missing or end of vector" after every such line.  k_dec_side_planes has expanded the lines
+// as stored; this kernel replays the block's weird lines in order: plane[a_w[i]] = stored[i], then the stable
+// partition of a_w (bool_pbwt_sort / bool_pbwt_sort_two, gt_block.hpp:124-151).  One workgroup per block, thread t
+// owns positions [t K, t K + K) as k_arrangement_at does; weird lines are rare, nothing here is on the hot path.
+// Blocks with fully haploid lines are refused by the host (the reference encodes those lines through a1 but reads
+// them through a_weird: not decodable as written).
+__global__ void __launch_bounds__(1024) k_dec_side_unpermute(const DecBlock* __restrict__ blocks, DecLines L, DecSide S,
+                                                             uint32_t* __restrict__ a_scratch, uint32_t* __restrict__ tmp) {
+    __shared__ uint64_t scan_lds[17];
+    const DecBlock& D = blocks[blockIdx.x];
+    if (D.error || D.strategy != WS_PBWT_WAH) return;
+    if (D.off_line_missing == VAL_UNDEFINED && D.off_line_eov == VAL_UNDEFINED) return;
+    const uint32_t N = L.N, tid = threadIdx.x;
+    const uint32_t K = (N + 1023u) / 1024u;
+    const uint32_t lo = tid * K < N ? tid * K : N, hi = lo + K < N ? lo + K : N;
+    uint32_t* cur = a_scratch + (size_t)blockIdx.x * 2u * N;
+    uint32_t* nxt = cur + N;
+    uint32_t* tm = tmp + (size_t)blockIdx.x * 2u * S.stride_w;
+    uint32_t* te = tm + S.stride_w;
+    for (uint32_t i = lo; i < hi; ++i) cur[i] = i;
+    __syncthreads();
+    for (uint32_t k = 0; k < D.n_bin; ++k) {
+        const uint32_t l = D.first_bin + k;
+        const uint32_t f = S.side[l] & 3u;
+        if (!f) continue;
+        uint32_t* ym = S.miss_planes + (size_t)l * S.stride_w;
+        uint32_t* ye = S.eov_planes + (size_t)l * S.stride_w;
+        for (uint32_t i = tid; i < 2u * S.stride_w; i += 1024u) tm[i] = 0;
+        __threadfence_block();
+        __syncthreads();
+        uint32_t zc = 0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t h = cur[i];
+            const uint32_t bm = (f & 1u) ? (ym[i >> 5] >> (i & 31u)) & 1u : 0u;
+            const uint32_t be = (f & 2u) ? (ye[i >> 5] >> (i & 31u)) & 1u : 0u;
+            if (bm) atomicOr(&tm[h >> 5], 1u << (h & 31u));
+            if (be) atomicOr(&te[h >> 5], 1u << (h & 31u));
+            zc += 1u - (bm | be);
+        }
+        uint64_t Z;
+        const uint32_t zbase = (uint32_t)block_scan_excl64(zc, scan_lds, &Z);
+        uint32_t zpos = zbase, opos = (uint32_t)Z + (lo - zbase);
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t h = cur[i];
+            const uint32_t bm = (f & 1u) ? (ym[i >> 5] >> (i & 31u)) & 1u : 0u;
+            const uint32_t be = (f & 2u) ? (ye[i >> 5] >> (i & 31u)) & 1u : 0u;
+            if (bm | be) nxt[opos++] = h;
+            else nxt[zpos++] = h;
+        }
+        __threadfence_block();
+        __syncthreads();  // every stored bit has been read, every natural-order bit is in tm / te
+        // (the bits were set by atomics, which work in L2: read them past this CU's L1, where the lines may still sit
+        // as the copy loop of an earlier weird line read them)
+        if (f & 1u)
+            for (uint32_t i = tid; i < S.stride_w; i += 1024u) ym[i] = __hip_atomic_load(&tm[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f & 2u)
+            for (uint32_t i = tid; i < S.stride_w; i += 1024u) ye[i] = __hip_atomic_load(&te[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_block();
+        __syncthreads();
+        uint32_t* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+}
+
 // int32 rows as Accessor::fill_genotype_array writes them (fill_genotype_array_advance,
 // accessor_internals_new.hpp:198-384), bug-compatible: the per-haplotype sequence of overwrites
 // is replayed exactly (REF / first ALT, extra ALTs incl. the negated-sparse overwrite/restore of
@@ -819,11 +886,15 @@ int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, Decod
     WS(out->planes, "gt.planes", 4ull * stride_w * (size_t)(n_bin ? n_bin : 1));
     int rc = decode_planes(ctx, d_file, P, out->planes, stride_w, /*apply_negation=*/0);
     if (rc) return rc;
-    bool side = false;
+    bool side = false, pbwt_weird = false;
     for (auto& b : P.blocks_h) {
         if (b.off_line_missing != VAL_UNDEFINED || b.off_line_eov != VAL_UNDEFINED || b.off_line_phase != VAL_UNDEFINED) side = true;
-        if ((b.off_line_missing != VAL_UNDEFINED || b.off_line_eov != VAL_UNDEFINED) && b.strategy == WS_PBWT_WAH)
-            return set_error(XSI_ERR_UNSUPPORTED, "weirdness strategy WS_PBWT_WAH (format v4 files) is not supported");
+        if ((b.off_line_missing != VAL_UNDEFINED || b.off_line_eov != VAL_UNDEFINED) && b.strategy == WS_PBWT_WAH) {
+            if (b.off_line_haploid != VAL_UNDEFINED)
+                return set_error(XSI_ERR_UNSUPPORTED, "weirdness strategy WS_PBWT_WAH in a block with fully haploid lines (the reference "
+                                 "writes those lines through a1 and reads them through a_weird: not decodable as written)");
+            pbwt_weird = true;
+        }
     }
     out->has_side = side;
     WS(out->n_miss, "gt.n_miss", 4ull * n_bin + 64);
@@ -849,6 +920,13 @@ int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, Decod
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_dec_side_planes<<<dim3(n_bin), dim3(64), lds, s>>>((const uint8_t*)d_file, P.d_blocks, P.L, S, n_bin);
         HIP_TRY(hipGetLastError());
+        if (pbwt_weird) {  // version-4 files: the missing / end-of-vector lines back into natural order
+            uint32_t *d_aw, *d_tmp;
+            WS(d_aw, "gt.weird_a", 8ull * P.L.N * (size_t)P.n_blocks);
+            WS(d_tmp, "gt.weird_tmp", 8ull * stride_w * (size_t)P.n_blocks);
+            k_dec_side_unpermute<<<dim3(P.n_blocks), dim3(1024), 0, s>>>(P.d_blocks, P.L, S, d_aw, d_tmp);
+            HIP_TRY(hipGetLastError());
+        }
         out->side = S.side;
         out->miss_planes = S.miss_planes;
         out->eov_planes = S.eov_planes;
