@@ -148,6 +148,12 @@ def main():
             nal = [na for _, na in lines]
             rows, counts = G.decode_gt(got, nal)
             ok2 = all(np.array_equal(rows[i][:len(lines[i][0])], lines[i][0]) for i in range(n_lines))
+            # the same lines as a WS_PBWT_WAH file (version-4 missing-data strategy, written by the oracle): decode only;
+            # not with fully haploid lines (refused)
+            if ok2 and (kw["missing"] or kw["eov"]) and all(len(g) == 2 * n for g, _ in lines):
+                ref_pw = oracle.encode_file(lines, n, block_len=block_len, mac_thr=thr, default_phased=dp, wah_encode_missing=2)
+                rows_pw, _ = G.decode_gt(ref_pw, nal)
+                ok2 = all(np.array_equal(rows_pw[i][:len(lines[i][0])], lines[i][0]) for i in range(n_lines))
             print("%3d general samples=%6d lines=%4d block=%4d thr=%4d %s bytes=%8d  encode %s decode %s  (%.0f s)"
                   % (c, n, n_lines, block_len, thr, "".join(k[0] for k, v in kw.items() if v) or "-", len(got),
                      "ok" if ok else "MISMATCH", "ok" if ok2 else "MISMATCH", time.time() - t0), flush=True)
