@@ -18,6 +18,11 @@ encoded to the .xsi blocks region and decoded back to packed bits.  Workloads (B
 --gpus N without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself, as children of
 torch.distributed.run, before this process touches the GPU; under a launcher it is rank RANK of WORLD_SIZE.
 
+The default command (no flags: configs[2] on one GPU) counts the rows' ALT alleles on the device INSIDE the timed
+step (xsi_hip_encode_packed; --producer-counts is the opt-in for callers whose producer has the counts) and then
+runs configs[1], the configs[3] shard of one of 8 GPUs and configs[4] in the same process, attached to the same JSON
+line as `other_configs` (each with its own ms_per_step, roofline and parity flags; --no-other-configs skips them).
+
 No data-path collective: blocks are independent.  The path's one exchange step, the gather of the
 compressed block streams to the writer rank over RCCL, runs inside the timed region (overlapped with the
 decode) and is also timed on its own after it (`gather_ms`).  Prints ONE JSON line on rank 0.
@@ -99,7 +104,7 @@ def dry_launch_rank(args, real_stdout):
     return 0
 
 
-def run_config4(args, real_stdout):
+def run_config4(args, real_stdout, emit=True):
     """BASELINE.json configs[4]: decode-only random access through Accessor::get_genotypes (accessor.hpp:58-67; the
     replay it replaces: accessor_internals_new.hpp:154-196).  Mixed-ploidy + multi-allelic content at 200 000
     haplotypes (10 % tri-allelic sites, 5 % "male" samples whose second value is end-of-vector, seed 45), built and
@@ -117,7 +122,7 @@ def run_config4(args, real_stdout):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    distributed = world > 1 or args.force_dist
+    distributed = (world > 1 or args.force_dist) and emit
     tdist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -129,7 +134,7 @@ def run_config4(args, real_stdout):
         os.environ.setdefault("WORLD_SIZE", "1")
         tdist.init_process_group(backend="nccl", device_id=dev)
     L = binding.lib()
-    stream = torch.cuda.Stream(device=dev)
+    stream = torch.cuda.current_stream(dev) if not emit else torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = binding.Context(local_rank, stream.cuda_stream)
     N = args.haps if args.haps is not None else cfg["haps"]
@@ -289,11 +294,14 @@ def run_config4(args, real_stdout):
                                    "ms_per_query": 1e3 * t_cpu / max(len(ks), 1), "rows_match_source": cpu_ok}
         else:
             out["cpu_baseline"] = None
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        if emit:
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
     os.unlink(tmp.name)
     ctx.close()
     if distributed:
         tdist.destroy_process_group()
+    if not emit:
+        return out
     return 0 if (rank != 0 or out["rows_match_source"]) else 1
 
 
@@ -327,8 +335,14 @@ def main():
     ap.add_argument("--cpu-sample-cells", type=float, default=3.2e9, help="cells of the CPU-oracle baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the block-parallel CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--count-on-device", action="store_true",
-                    help="count the ALT alleles of every row inside the step instead of taking the counts from the producer")
+    ap.add_argument("--producer-counts", action="store_true",
+                    help="opt-in: the rows' ALT counts are handed over by their producer (xsi_hip_encode_packed_counted) "
+                         "instead of being counted on the device inside the timed step (the default)")
+    ap.add_argument("--count-on-device", action="store_true", help="(the default since round 4; kept for old command lines)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default command only: do not run configs[1], the configs[3] shard and configs[4] after configs[2]")
+    ap.add_argument("--other-configs-budget-s", type=float, default=240.0,
+                    help="wall-time budget after which the remaining other configs are skipped")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (process group + RCCL gather) even with one rank (testing)")
     ap.add_argument("--blocks", type=int, default=8, help="config 4: 8192-line blocks of the file each rank serves")
@@ -349,6 +363,63 @@ def main():
         raise SystemExit(dry_launch_rank(args, real_stdout))
     if args.config == 4:
         raise SystemExit(run_config4(args, real_stdout))
+    t_start = time.perf_counter()
+    out, ok = run_roundtrip(args, emit=True)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    custom = args.haps is not None or args.sites is not None
+    if rank == 0 and world == 1 and ok and args.config == 2 and not custom and not args.no_other_configs and not args.force_dist:
+        # The other single-GPU configurations of BASELINE.json in the same process, attached to the same line, so
+        # that they are timed by whoever runs this command and not only by the builder (VERDICT r3 #1b).
+        out["other_configs"] = run_other_configs(args, t_start)
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if rank == 0 and not ok:
+        raise SystemExit("round trip mismatch")
+
+
+def run_other_configs(args, t_start):
+    """configs[1], the configs[3] shard one of 8 GPUs gets, and configs[4] with 4 blocks, each with its own
+    ms_per_step, roofline and parity flags; bounded by --other-configs-budget-s of wall time."""
+    import copy
+    import gc
+    import torch
+    res = {}
+    plan = [
+        ("configs[1]", dict(config=1, steps=5, warmup=2, cpu_sample_cells=0.6e9)),
+        ("configs[3] shard (1 of 8 GPUs)", dict(config=3, sites_fraction=0.125, steps=2, warmup=1, cpu_sample_cells=4.2e9)),
+        ("configs[4]", dict(config=4, blocks=4, queries=20000, windows=100, steps=1, warmup=1, cpu_queries=4)),
+    ]
+    for name, over in plan:
+        gc.collect()
+        torch.cuda.empty_cache()
+        spent = time.perf_counter() - t_start
+        if spent > args.other_configs_budget_s:
+            res[name] = {"skipped": "wall-time budget of --other-configs-budget-s spent (%.0f s)" % spent}
+            continue
+        a = copy.copy(args)
+        a.haps = a.sites = a.seed = None
+        a.sites_fraction = 1.0
+        for k, v in over.items():
+            setattr(a, k, v)
+        t = time.perf_counter()
+        try:
+            if a.config == 4:
+                o = run_config4(a, None, emit=False)
+            else:
+                o, _ = run_roundtrip(a, emit=False)
+        except (Exception, SystemExit) as e:  # a sub-run must not take the main line with it
+            o = {"error": "%s: %s" % (type(e).__name__, e)}
+        o["wall_s"] = time.perf_counter() - t
+        res[name] = o
+    return res
+
+
+def run_roundtrip(args, emit=True):
+    """One encode+decode configuration; returns (the JSON object of rank 0 or None, round trip equal).  emit=False:
+    a sub-run of the default command (one GPU, no process group, a smaller CPU-oracle sample: encode only, for the
+    byte comparison of the first blocks)."""
     cfg = CONFIGS[args.config]
     custom = args.haps is not None or args.sites is not None
     N = args.haps if args.haps is not None else cfg["haps"]
@@ -364,7 +435,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    distributed = world > 1 or args.force_dist
+    distributed = (world > 1 or args.force_dist) and emit
     if distributed:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -381,7 +452,7 @@ def main():
     L = binding.lib()
     # ONE explicit stream shared by torch and the codec (torch's default stream has handle 0, which
     # the C ABI reads as "create your own stream": two unordered streams would race)
-    stream = torch.cuda.Stream(device=dev)
+    stream = torch.cuda.Stream(device=dev) if emit else torch.cuda.current_stream(dev)
     torch.cuda.set_stream(stream)
     ctx = binding.Context(local_rank, stream.cuda_stream)
 
@@ -409,9 +480,10 @@ def main():
 
     d_bits = torch.empty(S * stride, dtype=torch.uint8, device=dev)
     binding.check(L.xsi_hip_synth_packed(ctx.handle, seed, first_site, S, N, d_bits.data_ptr(), stride))
-    # The producer of the rows hands over their ALT counts with them (xsi_hip_encode_packed_counted), as the file
-    # writer does, whose packer counts while it packs: the 16.4 GB pass that only counts is then not part of the step.
-    # --count-on-device puts it back (xsi_hip_encode_packed); its time is reported either way (count_rows_ms).
+    # The step counts the ALT alleles of every row on the device (xsi_hip_encode_packed: the histogram half of
+    # GtBlock::scan_genotypes, gt_block.hpp:207-269): the synthetic producer makes no counts.  --producer-counts is the
+    # opt-in for a caller whose producer has them (the file writer's packer counts while it packs) and hands them to
+    # xsi_hip_encode_packed_counted; the counting pass alone is timed either way (count_rows_ms).
     d_cnt = torch.empty(S, dtype=torch.int32, device=dev)
     binding.check(L.xsi_hip_count_packed_rows(ctx.handle, d_bits.data_ptr(), S, stride, N, d_cnt.data_ptr()))
     torch.cuda.synchronize()
@@ -419,7 +491,8 @@ def main():
     binding.check(L.xsi_hip_count_packed_rows(ctx.handle, d_bits.data_ptr(), S, stride, N, d_cnt.data_ptr()))
     ctx.synchronize()
     count_rows_ms = (time.perf_counter() - _t) * 1e3
-    cnt_ptr = None if args.count_on_device else d_cnt.data_ptr()
+    count_in_step = not args.producer_counts
+    cnt_ptr = None if count_in_step else d_cnt.data_ptr()
     bound = int(L.xsi_hip_encode_bound(ctypes.byref(p), S, S))
     # the worst-case bound (every line incompressible) is ~N/7.5 bytes per line; this generator needs
     # < 0.03 B per cell, so large jobs get 8 GiB or 0.04 B per cell instead of the bound (the encoder
@@ -598,7 +671,7 @@ def main():
             "metric": "GT cells/sec (hap x site) encode+decode round-trip",
             "value": value, "unit": "GT cells/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u16" if n_samples * 2 <= 65535 else "u32", "data": "synthetic",
             "config": {"workload": "synthetic %d hap x %d biallelic sites %s, MAC threshold %d, %d-line blocks "
                                    "(%s), encode to .xsi + decode to packed bits, inputs in HBM"
                                    % (N, total_sites if strong else S, "in total, blocks sharded over the ranks" if strong
@@ -609,9 +682,9 @@ def main():
                        "seed": seed, "xsi_bytes_this_gpu": xsi_bytes, "bytes_per_cell": c,
                        "wah_lines_this_gpu": int(res.n_wah_lines), "row_stride_bytes": stride,
                        "launches_per_step": launches_per_step,
-                       "row_counts": ("counted on the device inside the step (xsi_hip_encode_packed)" if args.count_on_device else
-                                      "handed over with the rows by their producer (xsi_hip_encode_packed_counted), as the file "
-                                      "writer's packer does; the counting pass alone takes count_rows_ms"),
+                       "row_counts": ("counted on the device inside the timed step (xsi_hip_encode_packed)" if count_in_step else
+                                      "--producer-counts: handed over with the rows (xsi_hip_encode_packed_counted); the counting "
+                                      "pass alone takes count_rows_ms and is NOT in ms_per_step"),
                        "count_rows_ms": count_rows_ms,
                        "parallelism": "blocks sharded over %d GPU(s); RCCL gather of block streams" % world
                        if distributed else "1 GPU"},
@@ -631,7 +704,7 @@ def main():
                          "stage_ms": stages, "stage_ms_per_step": stages_step, "chain_launches_per_step": launches},
             "roundtrip_equal": roundtrip_ok,
         }
-        if not args.count_on_device:
+        if not count_in_step:
             # the same step with the counting pass made on the device as well (measured by itself, outside the timed
             # region, added here): what xsi_hip_encode_packed without producer counts costs
             out["with_device_row_count"] = {"ms_per_step": ms_per_step + count_rows_ms,
@@ -651,6 +724,7 @@ def main():
     # ---- CPU baseline: the oracle (parity-pinned restatement of the reference), 1 thread ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
+        full_leg = emit  # a sub-run only encodes its sample with the oracle, for the byte comparison
         cs = int(args.cpu_sample_cells / N)
         cs = cs // bl * bl if cs >= bl else max(1024, cs // 1024 * 1024)
         cs = min(S, cs, 12 * bl)
@@ -666,11 +740,11 @@ def main():
         t = time.perf_counter()
         ref = w.finalize(2)
         t_enc += time.perf_counter() - t
-        rd = oracle.Reader(ref)
+        rd = oracle.Reader(ref) if full_leg else None
         t_dec = 0.0
-        buf = np.empty((chunk, N), dtype=np.int32)
-        dec_ok = True
-        for r0 in range(0, cs, chunk):
+        buf = np.empty((chunk, N), dtype=np.int32) if full_leg else None
+        dec_ok = True if full_leg else None
+        for r0 in (range(0, cs, chunk) if full_leg else ()):
             n = min(chunk, cs - r0)
             t = time.perf_counter()
             rd.fill_rows(r0, n, bl, buf)
@@ -690,19 +764,23 @@ def main():
             io = struct.unpack_from("<Q", ref, 72)[0]
             ref_region = ref[256:io]
             bit_exact = bool(ref_region[:len(gpu_blocks)] == gpu_blocks and len(ref_region) - len(gpu_blocks) < 8)
-        out["cpu_baseline"] = {"value": cpu_cells / (t_enc + t_dec), "unit": "GT cells/s", "cores": 1, "kind": "port",
-                               "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
-                               "sample": "first %d sites x %d hap of the same matrix (int32 rows in host memory), "
-                                         "oracle encode %.2f s + decode %.2f s" % (cs, N, t_enc, t_dec),
-                               "encode_cells_per_s": cpu_cells / t_enc, "decode_cells_per_s": cpu_cells / t_dec,
-                               "decode_matches_input": dec_ok}
+        if full_leg:
+            out["cpu_baseline"] = {"value": cpu_cells / (t_enc + t_dec), "unit": "GT cells/s", "cores": 1, "kind": "port",
+                                   "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+                                   "sample": "first %d sites x %d hap of the same matrix (int32 rows in host memory), "
+                                             "oracle encode %.2f s + decode %.2f s" % (cs, N, t_enc, t_dec),
+                                   "encode_cells_per_s": cpu_cells / t_enc, "decode_cells_per_s": cpu_cells / t_dec,
+                                   "decode_matches_input": dec_ok}
+        else:
+            out["cpu_baseline"] = {"value": cpu_cells / t_enc, "unit": "GT cells/s (encode only)", "cores": 1, "kind": "port",
+                                   "sample": "first %d sites x %d hap of the same matrix, oracle encode %.2f s" % (cs, N, t_enc)}
         out["bit_exact_vs_oracle"] = bit_exact
         out["bit_exact_blocks_checked"] = nb
         # block-parallel leg: one thread per block, every thread with its own
         # writer/reader (blocks are independent); ctypes drops the GIL in the calls.  The int32 rows of
         # a block are made inside its thread and dropped again, so host memory stays at threads x block.
         n_thr = max(1, min(os.cpu_count() or 1, args.cpu_threads, int(24e9 / (4.0 * N * min(bl, cs)))))
-        par_blocks = min(n_blocks, n_thr) if cs >= bl else 0
+        par_blocks = (min(n_blocks, n_thr) if cs >= bl else 0) if full_leg else 0
         if par_blocks > 1:
             from concurrent.futures import ThreadPoolExecutor
             pk = d_bits[:par_blocks * bl * stride].cpu().numpy().reshape(par_blocks * bl, stride)
@@ -727,16 +805,12 @@ def main():
                                                           "(slowest thread's encode+decode time)" % par_blocks}
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if gat is not None:
         gat.close()
     ctx.close()
     if distributed:
         tdist.destroy_process_group()
-    if rank == 0 and not roundtrip_ok:
-        raise SystemExit("round trip mismatch")
+    return out, roundtrip_ok
 
 
 if __name__ == "__main__":

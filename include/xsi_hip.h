@@ -352,13 +352,23 @@ int xsi_accessor_open(xsi_accessor** a, xsi_hip_ctx* ctx, const char* path);
 /* Accessor::fill_genotype_array(gt_arr, gt_arr_size, n_alleles, position) (accessor.hpp:48-50):
  * position = BM value (block<<15 | binary-line offset).  Returns the number of values written
  * (N_HAPS or N_SAMPLES) or <0.
- * An array handed in twice in a row (lines of 64 KiB and more) is page-locked by the accessor until it is closed
- * or another array takes its place, and the device stores the line into it directly; free such an array only after
- * xsi_accessor_close or after other arrays have been used.  XSI_ACCESSOR_NO_REGISTER=1 in the environment turns
- * this off (every line then goes through the accessor's own pinned window and a memcpy); XSI_ACCESSOR_NO_ZEROCOPY=1
- * keeps the page-locking but fills the array with a device-to-host copy instead of stores from the kernel. */
+ * Any array works: the line is composed on the device, lands in the accessor's pinned window and is copied out
+ * behind the capacity check (XSI_ERR_CAPACITY when gt_size is smaller than the line).  Nothing is page-locked
+ * behind the caller's back; the fast path is the opt-in below. */
 int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_t gt_size, uint32_t n_alleles,
                                          uint64_t position);
+/* Opt-in fast path for a caller that reuses ONE destination array (what an htslib caller's gt_arr is): the accessor
+ * page-locks h_gt (hipHostRegister; an array the caller page-locked itself is taken as it is) and single-line
+ * fills into exactly this pointer are stored there by the compose kernel itself (posted PCIe writes: one launch,
+ * one completion, no window copy; 33 instead of 73 us per line at 200 000 haplotypes).
+ * n_values must be at least 2 * num_samples - the width of a composed row whatever a line's ploidy; a smaller array
+ * is refused (XSI_ERR_CAPACITY) and keeps working through the ordinary path.
+ * LIFETIME: the array must stay allocated, at this address, until xsi_accessor_unregister_array, the next
+ * xsi_accessor_register_array or xsi_accessor_close returns; freeing it earlier leaves the device with a mapping of
+ * freed pages.  One array per accessor.  XSI_ACCESSOR_NO_REGISTER=1 makes this call a no-op (measurement);
+ * XSI_ACCESSOR_NO_ZEROCOPY=1 keeps the page-locking but fills the array with the copy engine. */
+int xsi_accessor_register_array(xsi_accessor* a, int32_t* h_gt, uint64_t n_values);
+int xsi_accessor_unregister_array(xsi_accessor* a);
 /* Accessor::get_genotypes without the htslib record: mallocs *h_gt when NULL (hap_samples ints),
  * sets *ngt_arr = hap_samples (accessor.hpp:58-67). */
 int64_t xsi_accessor_get_genotypes(xsi_accessor* a, uint32_t n_alleles, uint64_t position, void** h_gt,

@@ -173,6 +173,44 @@ def test_block_batched_calls_equal_single_call():
         binding.check(L.xsi_hip_ctx_set_workspace_budget(h, 0))
 
 
+def test_batched_decode_keeps_the_workspace_within_the_budget():
+    """the batch-cutting pre-pass of xsi_hip_decode_packed must not size the expanded-row buffer by the
+    WHOLE block range.  A fresh context (its row buffer has never grown) decodes 11 blocks under a budget of about
+    three: the rows come back right and the context holds no more than the budget plus its small per-line arrays."""
+    import ctypes
+    import gpu_util as G
+    import torch
+    L = binding.lib()
+    n_haps, block_len, n_blocks = 40000, 256, 11
+    n_lines = n_blocks * block_len
+    bits, packed, stride = _device_synth(n_haps, n_lines, 19)
+    p = G.params(n_haps // 2, block_len, 40)
+    region, offs, res = G.encode_packed(packed, n_haps, p)
+    image = G.assemble_file(region, offs, p, n_lines, n_lines, ["S%d" % i for i in range(n_haps // 2)])
+    per_line = 16 * ((n_haps + 63) // 64) + 64
+    whole = int(res.n_wah_lines) * per_line
+    budget = 3 * block_len * per_line
+    assert whole > 2 * budget  # the unbatched row buffer would be more than twice the budget
+    G.ctx()
+    stream = torch.cuda.current_stream()
+    c2 = binding.Context(0, stream.cuda_stream)
+    try:
+        binding.check(L.xsi_hip_ctx_set_workspace_budget(c2.handle, budget))
+        d_file = G.dev_u8(np.frombuffer(image, dtype=np.uint8))
+        d_out = G.dev_empty(n_lines * stride)
+        rows = ctypes.c_uint64(0)
+        binding.check(L.xsi_hip_decode_packed(c2.handle, d_file.data_ptr(), len(image), 0, n_blocks, d_out.data_ptr(),
+                                              stride, n_lines, ctypes.byref(rows), None))
+        c2.synchronize()
+        assert rows.value == n_lines
+        assert np.array_equal(d_out.cpu().numpy().reshape(n_lines, stride), packed)
+        held = c2.workspace_bytes()
+        # budget + the buffer's own growth margin (1/8) + per-line arrays, tiles and the ranks parked between launches
+        assert held < budget * 1.125 + (4 << 20), (held, budget, whole)
+    finally:
+        c2.close()
+
+
 def test_accessor_u32_random_access_evicting_cache(tmp_path):
     """BASELINE configs[4] in small: > 131 072 haplotypes (u32 A_T in header and blocks), multi-allelic
     lines, end-of-vector ("male") samples, missing values and fully haploid lines, random BM positions
@@ -337,8 +375,12 @@ def test_config4_shape_against_oracle(tmp_path):
         assert np.array_equal(buf, rows[i]), "line %d vs source" % i
         binding.check(L.xsi_accessor_allele_counts(a, cnt.ctypes.data, int(nal[i])))
         assert np.array_equal(cnt[:int(nal[i])], ecnt)
-    # the same caller array again and again is page-locked and filled by the copy engine directly: the same line
-    # twice, a sequential run (which goes back through the window), another array in between, then the first again
+    # a REGISTERED caller array (xsi_accessor_register_array) is page-locked and the compose kernel stores single lines
+    # into it: the same line twice, a sequential run (which goes back through the window), another (unregistered)
+    # array in between, then the first again; a too-small array is refused and nothing is locked
+    small = np.zeros(n_haps - 2, dtype=np.int32)
+    assert L.xsi_accessor_register_array(a, small.ctypes.data, small.size) == binding.XSI_ERR_CAPACITY
+    binding.check(L.xsi_accessor_register_array(a, buf.ctypes.data, buf.size))
     buf2 = np.zeros(n_haps, dtype=np.int32)
     seq = [77, 77, 78, 79, 80, 81, 77, 3000, 3000]
     for k, i in enumerate(seq):
@@ -346,6 +388,10 @@ def test_config4_shape_against_oracle(tmp_path):
         dst[:] = -5
         assert L.xsi_accessor_fill_genotype_array(a, dst.ctypes.data, dst.size, int(nal[i]), int(bm[i])) == n_haps
         assert np.array_equal(dst, rows[i]), "step %d line %d" % (k, i)
+    binding.check(L.xsi_accessor_unregister_array(a))
+    buf[:] = -5   # unregistered: the ordinary path again
+    assert L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, int(nal[77]), int(bm[77])) == n_haps
+    assert np.array_equal(buf, rows[77])
     L.xsi_accessor_close(a)
     buf[:] = 1  # the array is unlocked again and ordinary memory
     assert int(buf.sum()) == n_haps

@@ -884,14 +884,15 @@ def test_accessor_internal_access_with_haploid_lines(tmp_path):
 
 
 def test_accessor_fills_a_caller_pinned_array(tmp_path):
-    """fill_genotype_array into an array the CALLER has page-locked (torch pinned memory): hipHostRegister refuses it
-    as already registered, the accessor uses it as it is (the kernel stores into it) and leaves it locked at close."""
+    """xsi_accessor_register_array with an array the CALLER has page-locked (torch pinned memory): hipHostRegister
+    refuses it as already registered, the accessor uses it as it is (the kernel stores into it) and leaves it locked at
+    close."""
     import gpu_util as G
     from oracle import oracle
     torch = G.torch_mod()
     L = binding.lib()
     rng = np.random.default_rng(99)
-    n = 12000   # 96 KB lines: above the 64 KiB threshold of the direct path
+    n = 12000
     lines = _random_lines(rng, n, 12, multi=True, missing=True)
     dp = oracle.default_phased_of(lines, n)
     ref = oracle.encode_file(lines, n, block_len=8, mac_thr=12, default_phased=dp)
@@ -901,6 +902,7 @@ def test_accessor_fills_a_caller_pinned_array(tmp_path):
     binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
     t = torch.empty(2 * n, dtype=torch.int32, pin_memory=True)
     buf = t.numpy()
+    binding.check(L.xsi_accessor_register_array(a, buf.ctypes.data, buf.size))
     bms, block, off = [], 0, 0
     for i, (_, na) in enumerate(lines):
         if i and i % 8 == 0:
@@ -916,6 +918,57 @@ def test_accessor_fills_a_caller_pinned_array(tmp_path):
     d = t.cuda(non_blocking=True)
     torch.cuda.synchronize()
     assert int(d.sum().item()) == 10 * n
+
+
+@pytest.mark.parametrize("no_zerocopy", [False, True])
+def test_haploid_file_never_overruns_the_callers_array(tmp_path, monkeypatch, no_zerocopy):
+    """a max_ploidy = 1 file has hap_samples = num_samples, but composed rows are 2 * num_samples wide.  The
+    array get_genotypes mallocs (hap_samples values) must never be written past its end - not by the kernel, not by
+    the copy engine - and registering it for the direct path is refused.  20 000 samples: 80 KB lines, with guard
+    values behind the array; once through the kernel-store path, once with XSI_ACCESSOR_NO_ZEROCOPY=1."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    if no_zerocopy:
+        monkeypatch.setenv("XSI_ACCESSOR_NO_ZEROCOPY", "1")
+    rng = np.random.default_rng(5150)
+    n = 20000
+    lines = []
+    for i in range(6):
+        k = int(rng.integers(30, n // 2))
+        g = np.zeros(n, dtype=np.int32)
+        g[rng.choice(n, k, replace=False)] = 1
+        lines.append((((g + 1) << 1).astype(np.int32), 2))   # haploid line: n values, unphased
+    ref = oracle.encode_file(lines, n, block_len=4, mac_thr=20, default_phased=0, max_ploidy=1)
+    assert struct.unpack_from("<Q", ref, 32)[0] == n and struct.unpack_from("<Q", ref, 112)[0] == n
+    path = tmp_path / "hap.xsi"
+    path.write_bytes(ref)
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
+    assert L.xsi_accessor_hap_samples(a) == n
+    guard = 4096
+    store = np.full(n + guard, -99, dtype=np.int32)
+    buf = store[:n]
+    # an array of hap_samples values cannot take a composed row: the direct path refuses it
+    assert L.xsi_accessor_register_array(a, buf.ctypes.data, n) == binding.XSI_ERR_CAPACITY
+    pbuf = ctypes.c_void_p(buf.ctypes.data)
+    nout = ctypes.c_int(0)
+    for i in (1, 1, 1, 4, 5, 0, 0):
+        store[:] = -99
+        bm = ((i // 4) << 15) | (i % 4)
+        r = L.xsi_accessor_get_genotypes(a, 2, bm, ctypes.byref(pbuf), ctypes.byref(nout))
+        assert r == n and nout.value == n, L.xsi_hip_last_error()
+        assert np.array_equal(buf, lines[i][0]), "line %d" % i
+        assert np.all(store[n:] == -99), "values written behind the caller's array (line %d)" % i
+    # a registered array that is wide enough takes the direct path and gets the same values
+    wide = np.full(2 * n + guard, -99, dtype=np.int32)
+    binding.check(L.xsi_accessor_register_array(a, wide.ctypes.data, 2 * n))
+    for i in (2, 2, 3):
+        wide[:] = -99
+        assert L.xsi_accessor_fill_genotype_array(a, wide.ctypes.data, 2 * n, 2, ((i // 4) << 15) | (i % 4)) == n
+        assert np.array_equal(wide[:n], lines[i][0])
+        assert np.all(wide[2 * n:] == -99)
+    L.xsi_accessor_close(a)
 
 
 @pytest.mark.parametrize("n,n_lines,block_len,kw", [

@@ -56,6 +56,7 @@ SYMBOLS = [
     "xsi_hip_shard_blocks", "xsi_hip_shard_of_block", "xsi_hip_comm_unique_id", "xsi_hip_comm_create", "xsi_hip_comm_destroy",
     "xsi_hip_comm_world", "xsi_hip_comm_rank", "xsi_hip_gather_block_streams", "xsi_hip_comm_wait", "xsi_htslib_shim_available", "xsi_debug_pack_bit_row",
     "xsi_hip_encode_packed_counted", "xsi_hip_count_packed_rows",
+    "xsi_accessor_register_array", "xsi_accessor_unregister_array",
 ]
 
 
@@ -193,6 +194,10 @@ def lib():
     L.xsi_accessor_open.argtypes = [c.POINTER(vp), vp, c.c_char_p]
     L.xsi_accessor_fill_genotype_array.restype = c.c_int64
     L.xsi_accessor_fill_genotype_array.argtypes = [vp, vp, u64, u32, u64]
+    L.xsi_accessor_register_array.restype = c.c_int
+    L.xsi_accessor_register_array.argtypes = [vp, vp, u64]
+    L.xsi_accessor_unregister_array.restype = c.c_int
+    L.xsi_accessor_unregister_array.argtypes = [vp]
     L.xsi_accessor_get_genotypes.restype = c.c_int64
     L.xsi_accessor_get_genotypes.argtypes = [vp, u32, u64, c.POINTER(vp), c.POINTER(c.c_int)]
     L.xsi_accessor_genotypes_view.restype = c.c_int64

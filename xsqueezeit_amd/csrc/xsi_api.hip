@@ -684,7 +684,7 @@ int xsi_hip_decode_packed(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_le
             std::vector<uint32_t> n_wah(n_blocks64);
             {
                 DecodePlan plan;
-                int rc = decode_prepare(ctx, d_file, file_len, first_block, n_blocks64, &plan);
+                int rc = decode_prepare(ctx, d_file, file_len, first_block, n_blocks64, &plan, /*counts_only=*/true);
                 if (rc) return rc;
                 for (uint64_t b = 0; b < n_blocks64; ++b) n_wah[b] = plan.blocks_h[b].n_wah;
             }
@@ -810,7 +810,7 @@ namespace xsi {
 // Parse header + block dictionaries, size and fill the per-line arrays.  Synchronises twice
 // (header read-back, totals read-back): decode needs the line counts to size its workspace.
 int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block, uint64_t n_blocks64,
-                   DecodePlan* P) {
+                   DecodePlan* P, bool counts_only) {
     hipStream_t s = ctx->stream;
     uint8_t h[256];
     HIP_TRY(hipMemcpyAsync(h, d_file, 256, hipMemcpyDeviceToHost, s));
@@ -895,6 +895,7 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
             P->has_side = true;
     L.y_stride64 = (L.N + 63u) / 64u;
     L.yp_stride = L.y_stride64 * 2u;
+    if (counts_only) return XSI_OK;  // the caller only wants blocks_h: nothing sized by the WAH lines is allocated
     WS(L.yp, "ws.rows", 8ull * L.yp_stride * (size_t)(P->n_wah ? P->n_wah : 1));  // shared with the encode's permuted rows
     WS(L.wah_z, "dec.wah_z", 4ull * (P->n_wah ? P->n_wah : 1) + 64);
     {

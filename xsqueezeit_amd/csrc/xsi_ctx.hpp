@@ -102,8 +102,10 @@ int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D,
 int select_samples(xsi_hip_ctx* ctx, const int32_t* d_rows, uint64_t row_stride, const uint32_t* d_line_ngt,
                    uint32_t n_lines, uint32_t n_samples, const uint32_t* d_sel, uint32_t n_sel, int32_t* d_out,
                    uint64_t out_stride, uint32_t* d_ac, uint32_t n_alt);
+// counts_only: parse the dictionaries and flag vectors (blocks_h[b].n_wah, n_bin, ...) without allocating the expanded
+// rows, the boundary tiles or anything else sized by the range's WAH lines (the batch-cutting pre-pass of a decode)
 int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint64_t first_block, uint64_t n_blocks,
-                   DecodePlan* P);
+                   DecodePlan* P, bool counts_only = false);
 int decode_counts_only(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P);
 int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t* out, uint32_t stride_w,
                   int apply_negation);

@@ -539,12 +539,11 @@ struct xsi_accessor {
     // Accessor::get_genotypes mallocs it once, accessor.hpp:59-62) gets it page-locked on its second appearance: a
     // single-line request is then copied from HBM straight into it, without the stop in the pinned window (at 200 000
     // haplotypes that memcpy is a third of a warm random query).  Unregistered when another array shows up and at close.
-    void* seen_dst = nullptr;       // the array of the call before
-    void* reg_dst = nullptr;        // the array that is registered now
+    void* reg_dst = nullptr;        // the caller's array registered with xsi_accessor_register_array
     size_t reg_bytes = 0;
     int32_t* reg_dev = nullptr;     // the device's address of that array (the compose kernel may store into it)
-    bool reg_owned = false;         // this accessor page-locked it (false: the caller had: it stays locked at close)
-    void* reg_failed = nullptr;     // an array that could not be page-locked: not tried again call after call
+    bool reg_owned = false;         // this accessor page-locked it (false: the caller had: it stays locked at unregister)
+    uint64_t n_full = 0;            // values of a composed row: 2 * num_samples (hap_samples of a v4 file without the field)
     int32_t* direct_dst = nullptr;  // set for the duration of one call: where a single composed line should land
     bool direct_done = false;       // this call's line went there (not into h_rows)
     bool win_in_rows = true;        // the window's lines are in h_rows (false after a direct single-line copy)
@@ -746,8 +745,8 @@ static int accessor_compose(xsi_accessor* a, uint32_t first, uint32_t n, uint32_
     // kernel reads / writes directly (a few hundred bytes over PCIe): the only copy per call is the rows
     // A single line for a page-locked caller array: the compose kernel stores it there itself (the array's device
     // address; posted writes over PCIe) - one submission and one completion less than kernel + copy.
-    static const bool zero_copy = getenv("XSI_ACCESSOR_NO_ZEROCOPY") == nullptr;
-    const bool direct = n == 1u && a->direct_dst;
+    const bool zero_copy = getenv("XSI_ACCESSOR_NO_ZEROCOPY") == nullptr;  // read per call: tests switch it
+    const bool direct = n == 1u && a->direct_dst;  // only ever set for a registered array of at least N values
     const bool stores_direct = direct && zero_copy && a->reg_dev && a->direct_dst == a->reg_dst;
     int rc = compose_lines(a->ctx, a->P, a->D, a->h_meta, a->h_meta + a->win_rows, n, stores_direct ? a->reg_dev : a->d_rows, N,
                            a->h_meta + 2ull * a->win_rows, a->h_counts, max_al);
@@ -915,6 +914,7 @@ int xsi_accessor_open(xsi_accessor** out, xsi_hip_ctx* ctx, const char* path) {
         if (e == hipSuccess) e = hipMemcpy(a->d_file, h, (size_t)sz, hipMemcpyHostToDevice);
     }
     const uint64_t N = a->num_samples ? a->num_samples * 2 : a->hap_samples;
+    a->n_full = N;
     // window of composed rows: <= 64 MiB of int32
     uint64_t win = N ? (64ull << 20) / (N * 4) : 1;
     if (win < 1) win = 1;
@@ -967,40 +967,59 @@ static int64_t accessor_line_view(xsi_accessor* a, uint32_t n_alleles, uint64_t 
 int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_t gt_size, uint32_t n_alleles,
                                          uint64_t position) {
     if (!a || !h_gt) return set_error(XSI_ERR_ARG, "fill_genotype_array: null argument");
-    const size_t line_bytes = (size_t)a->hap_samples * sizeof(int32_t);
     a->direct_dst = nullptr;
     a->direct_done = false;
-    if (gt_size >= a->hap_samples && line_bytes >= (64u << 10) && !getenv("XSI_ACCESSOR_NO_REGISTER")) {
-        if (h_gt == a->reg_dst) {
-            a->direct_dst = h_gt;
-        } else if (h_gt == a->seen_dst && h_gt != a->reg_failed) {  // second call in a row with this array: page-lock it
-            if (a->reg_dst && a->reg_owned && hipHostUnregister(a->reg_dst) != hipSuccess) (void)hipGetLastError();
-            a->reg_dst = nullptr;
-            a->reg_dev = nullptr;
-            const hipError_t re = hipHostRegister(h_gt, line_bytes, hipHostRegisterDefault);
-            // an array the caller has page-locked already (hipHostMalloc, its own hipHostRegister) serves as it is
-            if (re == hipSuccess || re == hipErrorHostMemoryAlreadyRegistered) {
-                if (re != hipSuccess) (void)hipGetLastError();
-                a->reg_owned = re == hipSuccess;
-                a->reg_dst = h_gt;
-                a->reg_bytes = line_bytes;
-                void* dev = nullptr;
-                if (hipHostGetDevicePointer(&dev, h_gt, 0) == hipSuccess) a->reg_dev = static_cast<int32_t*>(dev);
-                else (void)hipGetLastError();
-                a->direct_dst = h_gt;
-            } else {
-                (void)hipGetLastError();
-                a->reg_failed = h_gt;
-            }
-        }
-    }
-    a->seen_dst = h_gt;
+    // The composed row is n_full = 2 * num_samples values wide whatever the line's ploidy, so the device may only
+    // write into the caller's array when it holds that many (a haploid file's hap_samples is half of it) and the
+    // caller has registered it (xsi_accessor_register_array); every other array is filled by the memcpy below,
+    // behind the capacity check.
+    if (a->reg_dst && h_gt == a->reg_dst && gt_size >= a->n_full && a->reg_bytes >= a->n_full * sizeof(int32_t)) a->direct_dst = h_gt;
     const int32_t* view = nullptr;
     const int64_t ngt = accessor_line_view(a, n_alleles, position, &view);
     if (ngt < 0) return ngt;
     if (gt_size < (uint64_t)ngt) return set_error(XSI_ERR_CAPACITY, "gt array holds %llu values, line has %lld", (unsigned long long)gt_size, (long long)ngt);
     if (view != h_gt) memcpy(h_gt, view, (size_t)ngt * sizeof(int32_t));
     return ngt;
+}
+
+static void accessor_drop_registration(xsi_accessor* a) {
+    if (a->reg_dst && a->reg_owned && hipHostUnregister(a->reg_dst) != hipSuccess) (void)hipGetLastError();
+    a->reg_dst = nullptr;
+    a->reg_dev = nullptr;
+    a->reg_bytes = 0;
+    a->reg_owned = false;
+}
+
+int xsi_accessor_register_array(xsi_accessor* a, int32_t* h_gt, uint64_t n_values) {
+    if (!a || !h_gt) return set_error(XSI_ERR_ARG, "register_array: null argument");
+    if (n_values < a->n_full)
+        return set_error(XSI_ERR_CAPACITY, "register_array: the array holds %llu values, a composed row has %llu",
+                         (unsigned long long)n_values, (unsigned long long)a->n_full);
+    if (a->ctx) HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    accessor_drop_registration(a);
+    if (getenv("XSI_ACCESSOR_NO_REGISTER")) return XSI_OK;  // measurement: every line through the pinned window + memcpy
+    const size_t bytes = (size_t)a->n_full * sizeof(int32_t);
+    const hipError_t re = hipHostRegister(h_gt, bytes, hipHostRegisterDefault);
+    // an array the caller has page-locked already (hipHostMalloc, its own hipHostRegister) serves as it is
+    if (re != hipSuccess && re != hipErrorHostMemoryAlreadyRegistered) {
+        (void)hipGetLastError();
+        return set_error(XSI_ERR_HIP, "register_array: hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(re));
+    }
+    if (re != hipSuccess) (void)hipGetLastError();
+    a->reg_owned = re == hipSuccess;
+    a->reg_dst = h_gt;
+    a->reg_bytes = bytes;
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, h_gt, 0) == hipSuccess) a->reg_dev = static_cast<int32_t*>(dev);
+    else (void)hipGetLastError();  // the copy engine still fills the page-locked array directly
+    return XSI_OK;
+}
+
+int xsi_accessor_unregister_array(xsi_accessor* a) {
+    if (!a) return set_error(XSI_ERR_ARG, "unregister_array: null accessor");
+    if (a->ctx) HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    accessor_drop_registration(a);
+    return XSI_OK;
 }
 
 int64_t xsi_accessor_genotypes_view(xsi_accessor* a, uint32_t n_alleles, uint64_t position, const int32_t** h_gt) {
@@ -1326,7 +1345,7 @@ const char* xsi_accessor_sample_name(const xsi_accessor* a, uint64_t i) {
 void xsi_accessor_close(xsi_accessor* a) {
     if (!a) return;
     if (a->ctx) (void)hipStreamSynchronize(a->ctx->stream);
-    if (a->reg_dst && a->reg_owned && hipHostUnregister(a->reg_dst) != hipSuccess) (void)hipGetLastError();  // (the caller may have freed it already)
+    accessor_drop_registration(a);  // xsi_hip.h: a registered array must outlive its registration
     for (auto& e : a->cache) (void)hipFree(e.mem);
     if (a->d_file) (void)hipFree(a->d_file);
     if (a->d_mini) (void)hipFree(a->d_mini);
