@@ -194,6 +194,8 @@ def run_config4(args, real_stdout, emit=True):
     buf = np.zeros(N, dtype=np.int32)
     pbuf = ctypes.c_void_p(buf.ctypes.data)
     nout = ctypes.c_int(0)
+    # the caller reuses one destination array (an htslib caller's gt_arr): opt in to the direct path
+    binding.check(L.xsi_accessor_register_array(a, buf.ctypes.data, buf.size))
     get = L.xsi_accessor_get_genotypes
     u64 = ctypes.c_uint64
 

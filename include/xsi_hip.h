@@ -315,6 +315,18 @@ int xsi_hip_gather_block_streams(xsi_hip_comm* comm, const void* d_region, uint6
                                  uint64_t n_blocks, int dst, void* d_region_all, uint64_t region_capacity,
                                  uint64_t* d_offsets_all, uint64_t offsets_capacity, uint64_t* h_bytes_per_rank,
                                  uint64_t* h_blocks_per_rank);
+/* The same for a job whose ranks encode their shards in several ROUNDS (a shard that does not fit HBM at once: round k
+ * of every rank is gathered while round k + 1 is encoded).  The writer rank appends: this round's regions land at
+ * d_region_all + region_base, its offsets at d_offsets_all + blocks_base, rebased by region_base as well, so that
+ * after the last round d_offsets_all holds the offsets of all blocks relative to the start of d_region_all.  With
+ * rounds the file order is round-major; a job that wants rank-major order gives every rank its own base.
+ * region_capacity / offsets_capacity stay the sizes of the whole buffers.  A call that fails (a refused post, a
+ * capacity error) leaves no RCCL group open and the communicator usable, and xsi_hip_comm_wait behind it returns
+ * without waiting for anything.  xsi_hip_gather_block_streams is round 0 with both bases 0. */
+int xsi_hip_gather_block_streams_round(xsi_hip_comm* comm, const void* d_region, uint64_t nbytes, const uint64_t* d_offsets,
+                                       uint64_t n_blocks, int dst, void* d_region_all, uint64_t region_capacity,
+                                       uint64_t* d_offsets_all, uint64_t offsets_capacity, uint64_t region_base,
+                                       uint64_t blocks_base, uint64_t* h_bytes_per_rank, uint64_t* h_blocks_per_rank);
 
 /* Wait for the exchange started last: host != 0 blocks the calling thread, host == 0 makes the context's stream
  * wait (work enqueued on it afterwards sees the gathered bytes). */
@@ -430,11 +442,34 @@ uint64_t xsi_accessor_num_samples(const xsi_accessor* a);
 const char* xsi_accessor_sample_name(const xsi_accessor* a, uint64_t i);
 void xsi_accessor_close(xsi_accessor* a);
 
-/* 1 when the library was built where htslib is installed and therefore also exports the reference's own C API
- * over this one - c_xcf_new / c_xcf_add_readers / c_xcf_update_readers / c_xcf_sample_name / c_xcf_nsamples /
- * __c__xcf__get__genotypes__void / c_xcf_delete (include/c_api.h:38-93) - and xsi_compress_bcf, the -c fill loop
- * (bcf_traversal.cpp:3-16, xcf.cpp:641-714); 0 otherwise (csrc/xsi_htslib_shim.cpp). */
+/* ---- htslib-facing layer (csrc/xsi_htslib_shim.cpp) ----
+ * 1 when the library was built with htslib (make HTSLIB=1) and therefore also exports the reference's own C API over
+ * this one - c_xcf_new / c_xcf_add_readers / c_xcf_update_readers / c_xcf_sample_name / c_xcf_nsamples /
+ * __c__xcf__get__genotypes__void / c_xcf_delete (include/c_api.h:38-93; declared by that header, they take htslib
+ * types) - and gives the two fill loops below a body; 0 otherwise: the loops then return XSI_ERR_UNSUPPORTED. */
 int xsi_htslib_shim_available(void);
+/* xsqueezeit -c -f in_bcf -o out_xsi [--maf] [--variant-block-length] [--zstd --zl]: writes out_xsi and
+ * out_xsi + "_var.bcf" (the variant-only BCF whose one pseudo sample carries FORMAT/BM = block << 15 | binary-line
+ * offset; replace_samples_by_pos_in_binary_matrix, xcf.cpp:641-714), the genotypes through xsi_writer_append
+ * (bcf_traversal.cpp:3-16, gt_compressor_new.hpp:84-142).  zstd_level 0 = no zstd layer. */
+int xsi_compress_bcf(const char* in_bcf, const char* out_xsi, double maf, uint32_t block_len, uint32_t zstd_level);
+/* xsqueezeit -x -f in_xsi -o out_path with the CLI's selection and output flags (xsqueezeit.hpp:36-93): */
+typedef struct xsi_decompress_options {
+    const char* regions;  /* -r "chr:from-to[,...]" or, with regions_is_file, -R file; NULL = none (needs the index) */
+    int regions_is_file;
+    const char* targets;  /* -t; used when no region is given; NULL = none */
+    const char* samples;  /* -s "A,B" (that order) or "^A,B" (all but); NULL = all.  AC / AN are recomputed */
+    char output_type;     /* -O: 'b' BCF (0 = default), 'u' uncompressed BCF, 'z' vcf.gz, 'v' VCF, 'x' a new .xsi */
+    int fast_pipe;        /* -p: out_path "-" is written as uncompressed BCF */
+    int no_header;        /* -H, VCF outputs only */
+    double maf;           /* 'x' only: --maf of the new file */
+    uint32_t zstd_level;  /* 'x' only: 0 keeps the input file's setting */
+} xsi_decompress_options;
+/* NewDecompressor::decompress (gt_decompressor_new.hpp:57-90, 113-206, 241-320, 432-543): walks in_xsi + "_var.bcf",
+ * fetches every record's genotypes by its BM value (xsi_accessor_fill_genotype_array / _fill_selected_genotypes),
+ * puts them back into the record and writes it; 'x' re-encodes into out_path (+ "_var.bcf" with the new BM values).
+ * opt may be NULL (everything, as BCF). */
+int xsi_decompress_bcf(const char* in_xsi, const char* out_path, const xsi_decompress_options* opt);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,83 @@ def test_c_abi_gather_world_one_on_gpu_encoded_blocks():
     assert (lo.value, hi.value) == (458, 611)
 
 
+def test_point_to_point_branch_with_self_send_and_rounds(monkeypatch):
+    """The grouped ncclSend / ncclRecv branch of the gather has no second GPU to run on here, so the writer rank sends its
+    own part to ITSELF (XSI_DIST_SELF_SEND=1: ncclSend + ncclRecv posted inside the group instead of the device copy).
+    Two "ranks' worth" of regions: the GPU-encoded blocks region is cut at a block boundary and gathered in two rounds
+    (xsi_hip_gather_block_streams_round) into one buffer - second round behind the first, its offsets (relative to its
+    own part, as a rank's are) rebased by the bytes in front of it.  The assembled file must equal the oracle's.
+    Then a receive that RCCL refuses (XSI_DIST_TEST_BAD_RECV=1: a peer that does not exist): the call reports the error,
+    the group is closed, xsi_hip_comm_wait does not hang, and the next gather on the same communicator works."""
+    import gpu_util as G
+    torch = G.torch_mod()
+    L = binding.lib()
+    n_haps, n_lines, bl = 5008, 4000, 512
+    bits = synth.synth_bits(12, 0, n_lines, n_haps)
+    stride = synth.row_stride_bytes(n_haps)
+    packed = synth.pack_rows(bits, stride)
+    p = G.params(n_haps // 2, bl, 5)
+    region, offsets, res = G.encode_packed(packed, n_haps, p)
+    n_blocks = len(offsets)
+    k = 3  # "rank 0": blocks [0, 3), "rank 1": blocks [3, n)
+    cut = int(offsets[k]) - 256
+    rel = offsets.astype(np.int64) - 256
+    parts = [(region[:cut], rel[:k]), (region[cut:], rel[k:] - cut)]
+    idb = (ctypes.c_uint8 * 128)()
+    binding.check(L.xsi_hip_comm_unique_id(idb))
+    comm = ctypes.c_void_p()
+    binding.check(L.xsi_hip_comm_create(ctypes.byref(comm), G.ctx().handle, 1, 0, idb))
+    monkeypatch.setenv("XSI_DIST_SELF_SEND", "1")
+    try:
+        d_all = G.dev_empty(len(region) + 64)
+        d_all.fill_(0xEE)
+        d_oall = torch.full((n_blocks,), -1, dtype=torch.int64, device="cuda")
+        per_b = (ctypes.c_uint64 * 1)()
+        per_n = (ctypes.c_uint64 * 1)()
+        base_b = base_n = 0
+        keep = []
+        for reg, offs in parts:
+            d_reg = G.dev_u8(np.frombuffer(reg, dtype=np.uint8))
+            d_off = torch.from_numpy(np.ascontiguousarray(offs)).cuda()
+            keep.append((d_reg, d_off))
+            binding.check(L.xsi_hip_gather_block_streams_round(comm, d_reg.data_ptr(), len(reg), d_off.data_ptr(), len(offs), 0,
+                                                              d_all.data_ptr(), len(region), d_oall.data_ptr(), n_blocks,
+                                                              base_b, base_n, per_b, per_n))
+            binding.check(L.xsi_hip_comm_wait(comm, 1))
+            assert per_b[0] == len(reg) and per_n[0] == len(offs)
+            base_b += len(reg)
+            base_n += len(offs)
+        assert d_all[:len(region)].cpu().numpy().tobytes() == region
+        assert int(d_all[len(region)].item()) == 0xEE  # nothing behind the gathered bytes
+        assert np.array_equal(d_oall.cpu().numpy().astype(np.uint64) + 256, offsets)
+        names = ["S%d" % i for i in range(n_haps // 2)]
+        got = G.assemble_file(d_all[:len(region)].cpu().numpy().tobytes(), d_oall.cpu().numpy().astype(np.uint64) + 256, p,
+                              n_lines, n_lines, names)
+        assert got == G.oracle_file_from_bits(bits, p, names)
+        # a round that does not fit behind its base is refused before anything moves
+        d_reg, d_off = keep[1]
+        rc = L.xsi_hip_gather_block_streams_round(comm, d_reg.data_ptr(), len(parts[1][0]), d_off.data_ptr(), len(parts[1][1]), 0,
+                                                  d_all.data_ptr(), len(region), d_oall.data_ptr(), n_blocks, cut + 1, k, per_b, per_n)
+        assert rc == binding.XSI_ERR_CAPACITY
+        binding.check(L.xsi_hip_comm_wait(comm, 1))
+        # a refused receive: error out, group closed, communicator still good
+        monkeypatch.setenv("XSI_DIST_TEST_BAD_RECV", "1")
+        d_reg, d_off = keep[0]
+        rc = L.xsi_hip_gather_block_streams(comm, d_reg.data_ptr(), len(parts[0][0]), d_off.data_ptr(), k, 0,
+                                            d_all.data_ptr(), len(region), d_oall.data_ptr(), n_blocks, per_b, per_n)
+        assert rc == binding.XSI_ERR_HIP, rc
+        assert b"ncclRecv" in L.xsi_hip_last_error()
+        binding.check(L.xsi_hip_comm_wait(comm, 1))
+        monkeypatch.delenv("XSI_DIST_TEST_BAD_RECV")
+        d_all.fill_(0)
+        binding.check(L.xsi_hip_gather_block_streams(comm, d_reg.data_ptr(), len(parts[0][0]), d_off.data_ptr(), k, 0,
+                                                     d_all.data_ptr(), len(region), d_oall.data_ptr(), n_blocks, per_b, per_n))
+        binding.check(L.xsi_hip_comm_wait(comm, 1))
+        assert d_all[:cut].cpu().numpy().tobytes() == region[:cut]
+    finally:
+        L.xsi_hip_comm_destroy(comm)
+
+
 @pytest.mark.parametrize("torch_gather", [False, True])
 def test_bench_multi_rank_path_with_one_rank(torch_gather):
     """bench.py --force-dist: process group (nccl), the C-ABI gather inside the timed region and alone, the

@@ -41,6 +41,85 @@ def test_micro_fixture_through_gpu(name, golden_dir):
         assert np.array_equal(counts[i][:lines[i][1]], ref[i][1])
 
 
+@pytest.mark.parametrize("maf,block_len", [(0.002, 8192), (0.0, 8192), (0.002, 4), (0.0, 4)])
+def test_region_target_fixture_through_gpu(maf, block_len, golden_dir, tmp_path):
+    """The reference's binary fixture test_region_target.bcf (test/cukinia_v4.conf:19; 6 records x 3202 samples of
+    1000 Genomes data = 6404 haplotypes, re-expressed GT-only by tests/golden/make_region_target_fixture.py) through
+    every GPU entry point.  --maf 0.002 is what verify_v4.sh passes (MAC threshold 12: two WAH lines, four sparse);
+    --maf 0 makes all six WAH lines; block length 4 gives two blocks.
+      * xsi_hip_encode_gt and xsi_hip_encode_packed (the lines are bi-allelic, fully called, default-phased): file ==
+        the oracle's file, byte for byte;
+      * xsi_writer (append / finalize) with the fixture's sample names: file == the oracle's;
+      * xsi_hip_decode_gt == the VCF's genotypes (the reference's own pass criterion) and the oracle's allele counts;
+      * xsi_hip_decode_packed == the ALT bit rows;
+      * the -t chr17:117980-117999 subset (records by POS) through xsi_accessor_get_genotypes == the oracle's reader."""
+    import gpu_util as G
+    from oracle import oracle
+    from xsqueezeit_amd import synth
+    L = binding.lib()
+    samples, recs = vcf_lite.read_vcf(os.path.join(golden_dir, "region_target.vcf"))
+    lines = [(r["gt"], r["n_allele"]) for r in recs]
+    n = len(samples)
+    assert n == 3202 and len(lines) == 6
+    thr = int(float(2 * n) * maf)
+    dp = oracle.default_phased_of(lines, n)
+    ref = oracle.encode_file(lines, n, maf=maf, block_len=block_len, sample_names=samples)
+    p = G.params(n, block_len, thr, dp)
+    nal = [na for _, na in lines]
+    # general entry point
+    region, offsets, res = G.encode_gt(lines, n, p)
+    got = G.assemble_file(region, offsets, p, len(lines), G.num_variants(lines), samples, 2)
+    assert got == ref
+    assert res.n_wah_lines == (2 if maf else 6)
+    # packed entry point on the ALT bit rows
+    bits = np.stack([(((g >> 1) - 1) == 1).astype(np.uint8) for g, _ in lines])
+    stride = synth.row_stride_bytes(2 * n)
+    packed = synth.pack_rows(bits, stride)
+    region2, offsets2, _ = G.encode_packed(packed, 2 * n, p)
+    assert region2 == region and np.array_equal(offsets2, offsets)
+    # file writer
+    path = str(tmp_path / "rt.xsi").encode()
+    w = ctypes.c_void_p()
+    arr = (ctypes.c_char_p * n)(*[x.encode() for x in samples])
+    binding.check(L.xsi_writer_open(ctypes.byref(w), G.ctx().handle, path, ctypes.byref(p), arr))
+    for gt, na in lines:
+        gt = np.ascontiguousarray(gt, dtype=np.int32)
+        binding.check(L.xsi_writer_append(w, gt.ctypes.data, gt.size, na))
+    binding.check(L.xsi_writer_finalize(w, 0))
+    L.xsi_writer_close(w)
+    assert open(path, "rb").read() == ref
+    # decode
+    rows, counts = G.decode_gt(ref, nal)
+    oref = oracle.decode_file(ref, nal, block_len=block_len)
+    for i in range(len(lines)):
+        assert np.array_equal(rows[i], lines[i][0]), "record %d" % i
+        assert np.array_equal(counts[i][:2], oref[i][1][:2])
+    out, cnt = G.decode_packed(ref, 2 * n, stride)
+    assert np.array_equal(out, packed)
+    assert np.array_equal(cnt, bits.sum(1).astype(np.int32))
+    # -t chr17:117980-117999 through the accessor, out of order
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, path))
+    assert L.xsi_accessor_num_samples(a) == n and L.xsi_accessor_sample_name(a, 0) == samples[0].encode()
+    rd = oracle.Reader(ref)
+    picked = [i for i, r in enumerate(recs) if r["chrom"] == "chr17" and 117980 <= r["pos"] <= 117999]
+    assert picked == [1, 2, 3, 4, 5]
+    pp = ctypes.c_void_p()
+    ngt_arr = ctypes.c_int(0)
+    cbuf = np.zeros(2, dtype=np.uint64)
+    for i in picked + [5, 2, 4]:
+        bm = ((i // block_len) << 15) | (i % block_len)
+        r = L.xsi_accessor_get_genotypes(a, 2, bm, ctypes.byref(pp), ctypes.byref(ngt_arr))
+        assert r == 2 * n and ngt_arr.value == 2 * n, L.xsi_hip_last_error()
+        gotrow = np.ctypeslib.as_array(ctypes.cast(pp, ctypes.POINTER(ctypes.c_int32)), shape=(r,))
+        egt, ecnt = rd.fill_genotype_array(2, bm)
+        assert np.array_equal(gotrow, egt) and np.array_equal(gotrow, recs[i]["gt"]), "target record %d" % i
+        binding.check(L.xsi_accessor_allele_counts(a, cbuf.ctypes.data, 2))
+        assert np.array_equal(cbuf, ecnt[:2])
+    ctypes.CDLL(None).free(pp)
+    L.xsi_accessor_close(a)
+
+
 @pytest.mark.parametrize("n_samples,n_lines,block_len,maf,kw", [
     (50, 300, 64, 0.01, {}),
     (50, 200, 64, 0.01, dict(multi=True)),
@@ -939,7 +1018,7 @@ def test_haploid_file_never_overruns_the_callers_array(tmp_path, monkeypatch, no
         g = np.zeros(n, dtype=np.int32)
         g[rng.choice(n, k, replace=False)] = 1
         lines.append((((g + 1) << 1).astype(np.int32), 2))   # haploid line: n values, unphased
-    ref = oracle.encode_file(lines, n, block_len=4, mac_thr=20, default_phased=0, max_ploidy=1)
+    ref = oracle.encode_file(lines, n, block_len=4, mac_thr=20, default_phased=0)
     assert struct.unpack_from("<Q", ref, 32)[0] == n and struct.unpack_from("<Q", ref, 112)[0] == n
     path = tmp_path / "hap.xsi"
     path.write_bytes(ref)

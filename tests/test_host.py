@@ -289,6 +289,36 @@ def test_header_is_plain_c():
     assert r.returncode == 0, r.stderr
 
 
+def test_htslib_shim_compiles_against_declaration_only_prototypes():
+    """csrc/xsi_htslib_shim.cpp (c_xcf_* of the reference's c_api.h, the -c and -x fill loops) needs htslib, which this
+    image lacks, so the default library carries its stub.  Its real body is at least COMPILED here: -fsyntax-only with
+    -DXSI_HAVE_HTSLIB against tests/cxx/htslib_decls/htslib/*.h, hand-written prototypes of the ~35 htslib names it
+    uses (test infrastructure: no bodies, never linked).  It has never run; configs[0] stays untested."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    src = os.path.join(ROOT, "xsqueezeit_amd", "csrc", "xsi_htslib_shim.cpp")
+    r = subprocess.run([gxx, "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-DXSI_HAVE_HTSLIB",
+                        "-I", os.path.join(ROOT, "tests", "cxx", "htslib_decls"), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # both fill loops and every c_xcf_* entry point of c_api.h:38-93 are defined in the htslib build ...
+    text = open(src).read()
+    for name in ("c_xcf_new", "c_xcf_add_readers", "c_xcf_update_readers", "c_xcf_sample_name", "c_xcf_nsamples",
+                 "__c__xcf__get__genotypes__void", "c_xcf_delete", "xsi_compress_bcf", "xsi_decompress_bcf"):
+        assert name + "(" in text, name
+    # ... and the default library says it has no htslib and refuses the loops instead of pretending
+    L = binding.lib()
+    assert L.xsi_htslib_shim_available() == 0
+    L.xsi_compress_bcf.restype = ctypes.c_int
+    L.xsi_compress_bcf.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_double, ctypes.c_uint32, ctypes.c_uint32]
+    L.xsi_decompress_bcf.restype = ctypes.c_int
+    L.xsi_decompress_bcf.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
+    assert L.xsi_compress_bcf(b"in.bcf", b"out.xsi", 0.001, 8192, 0) == binding.XSI_ERR_UNSUPPORTED
+    assert L.xsi_decompress_bcf(b"in.xsi", b"out.bcf", None) == binding.XSI_ERR_UNSUPPORTED
+
+
 def test_file_num_samples_without_a_device(tmp_path):
     """c_xcf_nsamples-style query: header-only, works on a box without a GPU."""
     from oracle import oracle

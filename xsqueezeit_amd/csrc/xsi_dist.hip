@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -162,6 +163,14 @@ int xsi_hip_gather_block_streams(xsi_hip_comm* c, const void* d_region, uint64_t
                                  uint64_t n_blocks, int dst, void* d_region_all, uint64_t region_capacity,
                                  uint64_t* d_offsets_all, uint64_t offsets_capacity, uint64_t* h_bytes_per_rank,
                                  uint64_t* h_blocks_per_rank) {
+    return xsi_hip_gather_block_streams_round(c, d_region, nbytes, d_offsets, n_blocks, dst, d_region_all, region_capacity,
+                                              d_offsets_all, offsets_capacity, 0, 0, h_bytes_per_rank, h_blocks_per_rank);
+}
+
+int xsi_hip_gather_block_streams_round(xsi_hip_comm* c, const void* d_region, uint64_t nbytes, const uint64_t* d_offsets,
+                                       uint64_t n_blocks, int dst, void* d_region_all, uint64_t region_capacity,
+                                       uint64_t* d_offsets_all, uint64_t offsets_capacity, uint64_t region_base,
+                                       uint64_t blocks_base, uint64_t* h_bytes_per_rank, uint64_t* h_blocks_per_rank) {
     if (!c || dst < 0 || dst >= c->world) return set_error(XSI_ERR_ARG, "gather_block_streams: bad communicator / dst");
     if ((nbytes && !d_region) || (n_blocks && !d_offsets)) return set_error(XSI_ERR_ARG, "gather_block_streams: null input");
     const RcclApi& R = rccl();
@@ -170,11 +179,18 @@ int xsi_hip_gather_block_streams(xsi_hip_comm* c, const void* d_region, uint64_t
     HIP_TRY(hipSetDevice(c->ctx->device));
     HIP_TRY(hipEventRecord(c->ev_in, c->ctx->stream));  // everything the caller has enqueued so far (the encode) comes first
     HIP_TRY(hipStreamWaitEvent(s, c->ev_in, 0));
-    // 1. sizes: every rank's bytes and blocks, and (from the writer rank) the capacities of its output buffers, so
-    //    that all ranks reach the same verdict before anybody sends
+    // Whatever happens below, ev_done is recorded on the exchange stream before this call returns, so that a later
+    // xsi_hip_comm_wait never waits on the event of an EARLIER exchange.
+    struct DoneGuard {
+        xsi_hip_comm* c;
+        ~DoneGuard() { (void)hipEventRecord(c->ev_done, c->cs); }
+    } done_guard{c};
+    // 1. sizes: every rank's bytes and blocks, and (from the writer rank) the room left in its output buffers behind the
+    //    bases of this round, so that all ranks reach the same verdict before anybody sends
     if (!d_region_all) region_capacity = 0;  // a writer rank without buffers fails the capacity check on every rank
     if (!d_offsets_all) offsets_capacity = 0;
-    const uint64_t mine[4] = {nbytes, n_blocks, region_capacity, offsets_capacity};
+    const uint64_t mine[4] = {nbytes, n_blocks, region_capacity > region_base ? region_capacity - region_base : 0,
+                              offsets_capacity > blocks_base ? offsets_capacity - blocks_base : 0};
     HIP_TRY(hipMemcpyAsync(c->d_meta + 4u * (size_t)W, mine, 32, hipMemcpyHostToDevice, s));
     NCCL_TRY(R.AllGather(c->d_meta + 4u * (size_t)W, c->d_meta, 4, ncclUint64, c->comm, s));
     std::vector<uint64_t> meta4(4u * (size_t)W);
@@ -191,45 +207,67 @@ int xsi_hip_gather_block_streams(xsi_hip_comm* c, const void* d_region, uint64_t
         tot_n += meta[2u * r + 1u];
     }
     if (tot_b > meta4[4u * dst + 2u] || tot_n > meta4[4u * dst + 3u])
-        return set_error(XSI_ERR_CAPACITY, "gather_block_streams: %llu bytes / %llu blocks, the writer rank's capacity is %llu / %llu",
+        return set_error(XSI_ERR_CAPACITY, "gather_block_streams: %llu bytes / %llu blocks, the writer rank has room for %llu / %llu",
                          (unsigned long long)tot_b, (unsigned long long)tot_n, (unsigned long long)meta4[4u * dst + 2u],
                          (unsigned long long)meta4[4u * dst + 3u]);
-    // 2. exactly each rank's bytes and offsets to the writer rank (no padding to the longest region)
+    // 2. exactly each rank's bytes and offsets to the writer rank (no padding to the longest region).  A call that
+    //    fails inside the group must not return with the group open: every post goes through `post`, which keeps the
+    //    first error and skips the rest, and ncclGroupEnd is issued whatever happened.
+    // Test hooks (tests/test_gpu_dist.py): XSI_DIST_SELF_SEND=1 sends the writer rank's own part to itself with
+    // ncclSend + ncclRecv inside the group instead of copying it, so that the point-to-point branch runs on a one-GPU
+    // box; XSI_DIST_TEST_BAD_RECV=1 posts a receive from a peer that does not exist.
+    const bool self_send = getenv("XSI_DIST_SELF_SEND") != nullptr;
+    const bool bad_recv = getenv("XSI_DIST_TEST_BAD_RECV") != nullptr;
+    uint8_t* const reg_all = static_cast<uint8_t*>(d_region_all) + region_base;
+    uint64_t* const off_all = d_offsets_all ? d_offsets_all + blocks_base : nullptr;
+    ncclResult_t first = ncclSuccess;
+    const char* what = "";
+    auto post = [&](const char* name, auto&& call) {
+        if (first != ncclSuccess) return;
+        const ncclResult_t r = call();
+        if (r != ncclSuccess) {
+            first = r;
+            what = name;
+        }
+    };
     NCCL_TRY(R.GroupStart());
     if (me == dst) {
         uint64_t bb = 0, bn = 0;
         for (int r = 0; r < W; ++r) {
             const uint64_t b = meta[2u * r], n = meta[2u * r + 1u];
-            if (r != me) {
-                if (b) NCCL_TRY(R.Recv(static_cast<uint8_t*>(d_region_all) + bb, b, ncclUint8, r, c->comm, s));
-                if (n) NCCL_TRY(R.Recv(d_offsets_all + bn, n, ncclUint64, r, c->comm, s));
+            if (r != me || self_send) {
+                const int peer = bad_recv ? W + 7 : r;
+                if (b) post("ncclRecv(region)", [&] { return R.Recv(reg_all + bb, b, ncclUint8, peer, c->comm, s); });
+                if (n) post("ncclRecv(offsets)", [&] { return R.Recv(off_all + bn, n, ncclUint64, peer, c->comm, s); });
             }
             bb += b;
             bn += n;
         }
-    } else {
-        if (nbytes) NCCL_TRY(R.Send(d_region, nbytes, ncclUint8, dst, c->comm, s));
-        if (n_blocks) NCCL_TRY(R.Send(d_offsets, n_blocks, ncclUint64, dst, c->comm, s));
     }
-    NCCL_TRY(R.GroupEnd());
+    if (me != dst || self_send) {
+        if (nbytes) post("ncclSend(region)", [&] { return R.Send(d_region, nbytes, ncclUint8, dst, c->comm, s); });
+        if (n_blocks) post("ncclSend(offsets)", [&] { return R.Send(d_offsets, n_blocks, ncclUint64, dst, c->comm, s); });
+    }
+    const ncclResult_t ge = R.GroupEnd();  // always: a group left open poisons the communicator's next call
+    if (first != ncclSuccess) return set_error(XSI_ERR_HIP, "gather_block_streams: %s: %s", what, R.GetErrorString(first));
+    if (ge != ncclSuccess) return set_error(XSI_ERR_HIP, "gather_block_streams: ncclGroupEnd: %s", R.GetErrorString(ge));
     if (me == dst) {
         uint64_t bb = 0, bn = 0;
         for (int r = 0; r < W; ++r) {
             const uint64_t b = meta[2u * r], n = meta[2u * r + 1u];
-            if (r == me) {
-                if (b) HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(d_region_all) + bb, d_region, b, hipMemcpyDeviceToDevice, s));
-                if (n) HIP_TRY(hipMemcpyAsync(d_offsets_all + bn, d_offsets, 8ull * n, hipMemcpyDeviceToDevice, s));
+            if (r == me && !self_send) {
+                if (b) HIP_TRY(hipMemcpyAsync(reg_all + bb, d_region, b, hipMemcpyDeviceToDevice, s));
+                if (n) HIP_TRY(hipMemcpyAsync(off_all + bn, d_offsets, 8ull * n, hipMemcpyDeviceToDevice, s));
             }
-            if (n && bb) {
-                k_rebase_offsets<<<dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, s>>>(d_offsets_all + bn, n, bb);
+            if (n && (bb + region_base)) {
+                k_rebase_offsets<<<dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, s>>>(off_all + bn, n, bb + region_base);
                 HIP_TRY(hipGetLastError());
             }
             bb += b;
             bn += n;
         }
     }
-    HIP_TRY(hipEventRecord(c->ev_done, s));
-    return XSI_OK;
+    return XSI_OK;  // done_guard records ev_done behind everything enqueued above
 }
 
 int xsi_hip_comm_wait(xsi_hip_comm* c, int host) {

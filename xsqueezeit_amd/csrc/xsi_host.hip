@@ -999,14 +999,22 @@ int xsi_accessor_register_array(xsi_accessor* a, int32_t* h_gt, uint64_t n_value
     accessor_drop_registration(a);
     if (getenv("XSI_ACCESSOR_NO_REGISTER")) return XSI_OK;  // measurement: every line through the pinned window + memcpy
     const size_t bytes = (size_t)a->n_full * sizeof(int32_t);
-    const hipError_t re = hipHostRegister(h_gt, bytes, hipHostRegisterDefault);
-    // an array the caller has page-locked already (hipHostMalloc, its own hipHostRegister) serves as it is
-    if (re != hipSuccess && re != hipErrorHostMemoryAlreadyRegistered) {
+    // an array the caller has page-locked already (hipHostMalloc, its own hipHostRegister) serves as it is:
+    // hipHostRegister refuses such memory (hipHostMalloc'ed pages with "invalid argument" on this runtime)
+    hipPointerAttribute_t attr;
+    bool callers = hipPointerGetAttributes(&attr, h_gt) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!callers) {
         (void)hipGetLastError();
-        return set_error(XSI_ERR_HIP, "register_array: hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(re));
+        const hipError_t re = hipHostRegister(h_gt, bytes, hipHostRegisterDefault);
+        if (re == hipErrorHostMemoryAlreadyRegistered) {
+            (void)hipGetLastError();
+            callers = true;
+        } else if (re != hipSuccess) {
+            (void)hipGetLastError();
+            return set_error(XSI_ERR_HIP, "register_array: hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(re));
+        }
     }
-    if (re != hipSuccess) (void)hipGetLastError();
-    a->reg_owned = re == hipSuccess;
+    a->reg_owned = !callers;
     a->reg_dst = h_gt;
     a->reg_bytes = bytes;
     void* dev = nullptr;
