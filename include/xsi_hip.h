@@ -63,6 +63,7 @@ uint64_t xsi_hip_ctx_workspace_bytes(const xsi_hip_ctx* ctx);
  * aborted: its workgroups must all be resident at once, which another process, stream or CU mask can prevent.
  * The bytes written are the same either way (pbwt_sort, include/internal_gt_record.hpp:32-59). */
 uint64_t xsi_hip_ctx_chain_fallbacks(const xsi_hip_ctx* ctx);
+uint32_t xsi_hip_ctx_reencode_ranges(const xsi_hip_ctx* ctx);
 
 /* Bytes of per-line device workspace one block-level call may hold.  A job that needs more (e.g. 153 blocks
  * of 500 000 haplotypes) is run as several batches of whole blocks inside the call; the bytes written are
@@ -152,9 +153,10 @@ int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_
  * device: the "-Ox" path of NewDecompressor (include/gt_decompressor_new.hpp:241-273, fill_selected_genotypes
  * :209-238 + XsiFactoryInterface::append).  h_n_allele[l] for every BCF line as for xsi_hip_decode_gt;
  * h_sample_idx (n_sel indices into the file's samples, NULL = all); p_new->n_samples must be the number of
- * samples written.  Output as xsi_hip_encode_gt.  The int32 rows of the whole file are held in HBM at once
- * (4 bytes per value, + 8 per selected sample and line); a file too large for that returns XSI_ERR_CAPACITY with
- * the sizes in the message: re-encode such a file by block ranges (xsi_hip_decode_gt + xsi_hip_encode_gt).
+ * samples written.  Output as xsi_hip_encode_gt.  The file is walked in ranges of whole source blocks sized by the
+ * context's workspace budget (xsi_hip_ctx_set_workspace_budget; about 6 bytes per value staged), so its int32 rows
+ * never have to fit HBM at once; source blocks and new blocks need not line up (the leftover of a range is carried
+ * into the next).  xsi_hip_ctx_reencode_ranges says how many ranges the last call took.
  */
 int xsi_hip_reencode(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, const uint32_t* h_n_allele, uint64_t n_lines,
                      const xsi_encode_params* p_new, const uint32_t* h_sample_idx, uint32_t n_sel, void* d_out,

@@ -74,7 +74,7 @@ def test_point_to_point_branch_with_self_send_and_rounds(monkeypatch):
     Two "ranks' worth" of regions: the GPU-encoded blocks region is cut at a block boundary and gathered in two rounds
     (xsi_hip_gather_block_streams_round) into one buffer - second round behind the first, its offsets (relative to its
     own part, as a rank's are) rebased by the bytes in front of it.  The assembled file must equal the oracle's.
-    Then a receive that RCCL refuses (XSI_DIST_TEST_BAD_RECV=1: a peer that does not exist): the call reports the error,
+    Then a receive that is refused (XSI_DIST_TEST_BAD_RECV=1: the first post of the group fails): the call reports the error,
     the group is closed, xsi_hip_comm_wait does not hang, and the next gather on the same communicator works."""
     import gpu_util as G
     torch = G.torch_mod()

@@ -3,6 +3,7 @@ end-of-vector, non-default phase, haploid lines) and of the file-level writer / 
 import ctypes
 import hashlib
 import os
+import struct
 
 import numpy as np
 import pytest
@@ -808,6 +809,33 @@ def test_reencode_on_device(tmp_path):
             new_lines = [(gt.reshape(n, len(gt) // n)[sel].reshape(-1), na) for gt, na in lines]
         ref = oracle.encode_file(new_lines, n_new, block_len=80, mac_thr=3, default_phased=dp, sample_names=names)
         assert got == ref
+        assert L.xsi_hip_ctx_reencode_ranges(G.ctx().handle) == 1
+        # the same job under a workspace budget that cannot hold the file's rows - it is walked in
+        # ranges of whole source blocks (50 lines) that do not line up with the new blocks (80 or 30 lines): the leftover
+        # of a range is carried into the next.  1000 bytes: the smallest staging buffer that makes progress (one new
+        # block - 1 + one source block of lines): 2 ranges for 80-line blocks, 4 for 30-line blocks.
+        per_line = 6 * 2 * n + (8 * n_new if sel is not None else 0)
+        for budget, new_bl, min_ranges in ((1000, 80, 2), (1000, 30, 4), (170 * per_line, 80, 2)):
+            p2 = G.params(n_new, new_bl, 3, dp)
+            nb2 = (len(lines) + new_bl - 1) // new_bl
+            d_off2 = torch.zeros(nb2, dtype=torch.int64, device="cuda")
+            cap2 = int(L.xsi_hip_encode_gt_bound(ctypes.byref(p2), len(lines), n_bin))
+            d_out2 = G.dev_empty(cap2)
+            try:
+                binding.check(L.xsi_hip_ctx_set_workspace_budget(G.ctx().handle, budget))
+                res2 = binding.EncodeResult()
+                binding.check(L.xsi_hip_reencode(G.ctx().handle, d_file.data_ptr(), len(src), nal.ctypes.data, len(lines),
+                                                 ctypes.byref(p2), sel.ctypes.data if sel is not None else None, n_new,
+                                                 d_out2.data_ptr(), cap2, d_off2.data_ptr(), ctypes.byref(res2)))
+            finally:
+                binding.check(L.xsi_hip_ctx_set_workspace_budget(G.ctx().handle, 0))
+            assert L.xsi_hip_ctx_reencode_ranges(G.ctx().handle) >= min_ranges
+            assert res2.n_blocks == nb2 and res2.n_binary_lines == res.n_binary_lines and res2.max_ploidy == res.max_ploidy
+            region2 = d_out2[:res2.blocks_bytes].cpu().numpy().tobytes()
+            got2 = G.assemble_file(region2, d_off2.cpu().numpy().astype(np.uint64), p2, len(lines), G.num_variants(lines), names, 2)
+            ref2 = ref if new_bl == 80 else oracle.encode_file(new_lines, n_new, block_len=new_bl, mac_thr=3, default_phased=dp,
+                                                               sample_names=names)
+            assert got2 == ref2, "budget %d, %d-line blocks" % (budget, new_bl)
     bad = G.params(n + 1, 80, 3, dp)
     assert L.xsi_hip_reencode(G.ctx().handle, d_file.data_ptr(), len(src), nal.ctypes.data, len(lines), ctypes.byref(bad),
                               None, 0, d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)) == binding.XSI_ERR_ARG

@@ -57,7 +57,7 @@ SYMBOLS = [
     "xsi_hip_comm_world", "xsi_hip_comm_rank", "xsi_hip_gather_block_streams", "xsi_hip_comm_wait", "xsi_htslib_shim_available", "xsi_debug_pack_bit_row",
     "xsi_hip_encode_packed_counted", "xsi_hip_count_packed_rows",
     "xsi_accessor_register_array", "xsi_accessor_unregister_array", "xsi_hip_gather_block_streams_round",
-    "xsi_compress_bcf", "xsi_decompress_bcf",
+    "xsi_compress_bcf", "xsi_decompress_bcf", "xsi_hip_ctx_reencode_ranges",
 ]
 
 
@@ -124,6 +124,8 @@ def lib():
     L.xsi_hip_gather_block_streams.argtypes = [vp, vp, u64, vp, u64, c.c_int, vp, u64, vp, u64, vp, vp]
     L.xsi_hip_gather_block_streams_round.restype = c.c_int
     L.xsi_hip_gather_block_streams_round.argtypes = [vp, vp, u64, vp, u64, c.c_int, vp, u64, vp, u64, u64, u64, vp, vp]
+    L.xsi_hip_ctx_reencode_ranges.restype = u32
+    L.xsi_hip_ctx_reencode_ranges.argtypes = [vp]
     L.xsi_hip_ctx_chain_fallbacks.restype = u64
     L.xsi_hip_ctx_chain_fallbacks.argtypes = [vp]
     L.xsi_hip_ctx_set_timing.restype = c.c_int

@@ -57,6 +57,7 @@ struct xsi_hip_ctx {
     double stage_ms[XSI_STAGE_COUNT] = {0};
     uint64_t stage_n[XSI_STAGE_COUNT] = {0};
     uint64_t chain_fallbacks = 0;     // encode batches run again with the streaming chain after an aborted launch
+    uint32_t reencode_ranges = 0;     // block ranges the last xsi_hip_reencode walked the file in
 };
 
 struct xsi_encode_params;

@@ -1048,9 +1048,21 @@ int expand_bit_rows(xsi_hip_ctx* ctx, const uint8_t* d_bits, uint32_t bit_stride
 
 extern "C" {
 
+// region_offset: bytes of the blocks region that earlier ranges of the same job already wrote in front of d_out (block
+// offsets continue from there; xsi_hip_reencode walks a file in ranges of whole blocks)
+static int encode_gt_impl(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_t* d_gt, uint64_t gt_stride,
+                          uint64_t n_lines, const uint32_t* h_ngt, const uint32_t* h_n_allele, void* d_out,
+                          uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result, uint64_t region_offset);
+
 int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_t* d_gt, uint64_t gt_stride,
                       uint64_t n_lines, const uint32_t* h_ngt, const uint32_t* h_n_allele, void* d_out,
                       uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result) {
+    return encode_gt_impl(ctx, p, d_gt, gt_stride, n_lines, h_ngt, h_n_allele, d_out, out_capacity, d_block_offsets, h_result, 0);
+}
+
+static int encode_gt_impl(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_t* d_gt, uint64_t gt_stride,
+                          uint64_t n_lines, const uint32_t* h_ngt, const uint32_t* h_n_allele, void* d_out,
+                          uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result, uint64_t region_offset) {
     if (!ctx || !p || !d_gt || !h_ngt || !h_n_allele || !d_out) return set_error(XSI_ERR_ARG, "encode_gt: null argument");
     if (!p->n_samples || !p->block_len) return set_error(XSI_ERR_ARG, "encode_gt: n_samples and block_len must be > 0");
     if (at_mismatch_window(p->n_samples))
@@ -1188,7 +1200,7 @@ int xsi_hip_encode_gt(xsi_hip_ctx* ctx, const xsi_encode_params* p, const int32_
     k_side_flagbits<<<dim3(n_blocks), dim3(256), 0, s>>>(d_blocks, S, flagbits);
     HIP_TRY(hipGetLastError());
 
-    int rc = encode_run(ctx, p, L, S, blocks, d_out, out_capacity, d_block_offsets, h_result);
+    int rc = encode_run(ctx, p, L, S, blocks, d_out, out_capacity, d_block_offsets, h_result, region_offset);
     if (rc) return rc;
     uint32_t err = 0;
     HIP_TRY(hipMemcpyAsync(&err, U.d_error, 4, hipMemcpyDeviceToHost, s));  // on the context's stream: a copy on the
@@ -1386,48 +1398,106 @@ int xsi_hip_reencode(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, co
     if (h_sample_idx)
         for (uint32_t i = 0; i < n_sel; ++i)
             if (h_sample_idx[i] >= n_src) return set_error(XSI_ERR_ARG, "reencode: sample %u of %u", h_sample_idx[i], n_src);
-    // decode every line to int32 rows in HBM, (optionally) gather the selected samples there, encode again.
-    // The rows of the WHOLE file are held at once (4 N bytes per line, + 8 n_sel with a selection): a file whose
-    // rows do not fit the free HBM next to the codec's own workspace is refused, with the numbers, instead of
-    // failing somewhere inside hipMalloc (split such a job by block ranges: decode_gt + encode_gt per range).
-    {
-        const uint64_t need = 4ull * N * n_lines + (h_sample_idx ? 8ull * n_sel * n_lines : 0ull);
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        uint64_t have = free_b;
-        auto it = ctx->bufs.find("reenc.rows");
-        if (it != ctx->bufs.end()) have += it->second.cap;
-        it = ctx->bufs.find("reenc.sub");
-        if (it != ctx->bufs.end()) have += it->second.cap;
-        if (need > have - have / 4)
-            return set_error(XSI_ERR_CAPACITY, "reencode: the int32 rows of %llu lines x %llu values need %.1f GB, %.1f GB of HBM are free "
-                             "(three quarters are usable next to the codec's workspace): re-encode by block ranges",
-                             (unsigned long long)n_lines, (unsigned long long)N, need / 1e9, have / 1e9);
-    }
-    int32_t* d_rows;
-    WS(d_rows, "reenc.rows", 4ull * N * (size_t)n_lines);
-    std::vector<uint32_t> ngt(n_lines);
-    int rc = xsi_hip_decode_gt(ctx, d_file, file_len, 0, n_blocks, h_n_allele, n_lines, d_rows, N, ngt.data(), nullptr, 0);
+    // Decode to int32 rows in HBM, (optionally) gather the selected samples there, encode again - in RANGES of whole
+    // source blocks sized by the workspace budget, so a file of any size goes through (a 64 976 x 2 M file has 520 GB of
+    // rows).  The source's blocks and the new blocks need not line up: the rows of a range are staged behind what the
+    // previous range left over, whole new blocks are encoded from the front of the staging buffer (their bytes and
+    // offsets continue the region: blocks are independent, gt_block.hpp:179-180), the remainder (< one new block)
+    // moves to the front.  gt_decompressor_new.hpp:241-273 does the same one line at a time.
+    DecodePlan plan;
+    int rc = decode_prepare(ctx, d_file, file_len, 0, n_blocks, &plan, /*counts_only=*/true);
     if (rc) return rc;
-    const int32_t* d_enc = d_rows;
-    uint64_t stride = N;
-    if (h_sample_idx) {
-        uint32_t *d_sel, *d_ngt;
-        int32_t* d_sub;
-        WS(d_sel, "reenc.sel", 4ull * n_sel);
-        WS(d_ngt, "reenc.ngt", 4ull * n_lines);
-        WS(d_sub, "reenc.sub", 8ull * n_sel * (size_t)n_lines);
-        HIP_TRY(hipMemcpyAsync(d_sel, h_sample_idx, 4ull * n_sel, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_ngt, ngt.data(), 4ull * n_lines, hipMemcpyHostToDevice, s));
-        rc = select_samples(ctx, d_rows, N, d_ngt, (uint32_t)n_lines, n_src, d_sel, n_sel, d_sub, 2ull * n_sel, nullptr, 0);
-        if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(s));  // the host vectors above must outlive the copies
-        for (auto& v : ngt) v = v / n_src * n_sel;
-        d_enc = d_sub;
-        stride = 2ull * n_sel;
+    if (plan.n_bcf != n_lines)
+        return set_error(XSI_ERR_ARG, "reencode: the file holds %u BCF lines, caller passed %llu", plan.n_bcf, (unsigned long long)n_lines);
+    std::vector<uint32_t> src_lines(n_blocks);
+    uint32_t max_src = 1;
+    for (uint64_t b = 0; b < n_blocks; ++b) {
+        src_lines[b] = plan.blocks_h[b].n_bcf;
+        if (src_lines[b] > max_src) max_src = src_lines[b];
     }
-    return xsi_hip_encode_gt(ctx, p_new, d_enc, stride, n_lines, ngt.data(), h_n_allele, d_out, out_capacity, d_block_offsets,
-                             h_result);
+    const uint64_t bl_new = p_new->block_len;
+    if (!bl_new) return set_error(XSI_ERR_ARG, "reencode: block_len must be > 0");
+    // per staged line: its int32 row, the selected copy, and about half a row of bit planes on either side of the codec
+    const uint64_t per_line = 4ull * N + (h_sample_idx ? 8ull * n_sel : 0ull) + 2ull * N;
+    uint64_t cap_lines = ws_budget_now(ctx) / per_line;
+    const uint64_t min_lines = (bl_new - 1u) + max_src;  // a leftover plus one source block: always makes progress
+    if (cap_lines < min_lines) cap_lines = min_lines;
+    if (cap_lines > n_lines) cap_lines = n_lines;
+    int32_t* d_rows;
+    WS(d_rows, "reenc.rows", 4ull * N * (size_t)cap_lines);
+    uint32_t *d_sel = nullptr, *d_ngt = nullptr;
+    int32_t* d_sub = nullptr;
+    if (h_sample_idx) {
+        WS(d_sel, "reenc.sel", 4ull * n_sel);
+        WS(d_ngt, "reenc.ngt", 4ull * cap_lines);
+        WS(d_sub, "reenc.sub", 8ull * n_sel * (size_t)cap_lines);
+        HIP_TRY(hipMemcpyAsync(d_sel, h_sample_idx, 4ull * n_sel, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    std::vector<uint32_t> ngt(cap_lines), ngt_enc(cap_lines);
+    xsi_encode_result total{};
+    uint64_t staged = 0;      // lines in d_rows
+    uint64_t line_in = 0;     // source lines decoded so far
+    uint64_t line_out = 0;    // lines encoded so far
+    uint64_t region_off = 0, blocks_out = 0, src_b = 0;
+    uint32_t ranges = 0;
+    while (line_out < n_lines) {
+        // fill: as many whole source blocks as fit behind the leftover
+        uint64_t take_b = 0, take_l = 0;
+        while (src_b + take_b < n_blocks && staged + take_l + src_lines[src_b + take_b] <= cap_lines) take_l += src_lines[src_b + take_b++];
+        if (take_b) {
+            rc = xsi_hip_decode_gt(ctx, d_file, file_len, src_b, take_b, h_n_allele + line_in, take_l, d_rows + staged * N, N,
+                                   ngt.data() + staged, nullptr, 0);
+            if (rc) return rc;
+            staged += take_l;
+            line_in += take_l;
+            src_b += take_b;
+        }
+        // encode: whole new blocks from the front (everything once the source is exhausted)
+        const uint64_t m = src_b == n_blocks ? staged : staged / bl_new * bl_new;
+        if (!m) return set_error(XSI_ERR_CAPACITY, "reencode: the staging buffer of %llu lines cannot hold one new block of %llu",
+                                 (unsigned long long)cap_lines, (unsigned long long)bl_new);
+        const int32_t* d_enc = d_rows;
+        uint64_t stride = N;
+        for (uint64_t l = 0; l < m; ++l) ngt_enc[l] = ngt[l];
+        if (h_sample_idx) {
+            HIP_TRY(hipMemcpyAsync(d_ngt, ngt.data(), 4ull * m, hipMemcpyHostToDevice, s));
+            rc = select_samples(ctx, d_rows, N, d_ngt, (uint32_t)m, n_src, d_sel, n_sel, d_sub, 2ull * n_sel, nullptr, 0);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(s));
+            for (uint64_t l = 0; l < m; ++l) ngt_enc[l] = ngt[l] / n_src * n_sel;
+            d_enc = d_sub;
+            stride = 2ull * n_sel;
+        }
+        if (region_off > out_capacity) return set_error(XSI_ERR_CAPACITY, "reencode: output capacity exhausted");
+        xsi_encode_result r{};
+        rc = encode_gt_impl(ctx, p_new, d_enc, stride, m, ngt_enc.data(), h_n_allele + line_out, static_cast<uint8_t*>(d_out) + region_off,
+                            out_capacity - region_off, d_block_offsets ? d_block_offsets + blocks_out : nullptr, &r, region_off);
+        if (rc) return rc;
+        region_off += r.blocks_bytes;
+        blocks_out += r.n_blocks;
+        total.n_blocks += r.n_blocks;
+        total.n_binary_lines += r.n_binary_lines;
+        total.n_wah_lines += r.n_wah_lines;
+        if (r.max_ploidy > total.max_ploidy) total.max_ploidy = r.max_ploidy;
+        total.last_block_bytes = r.last_block_bytes;
+        line_out += m;
+        // the leftover (< one new block, so it cannot overlap its destination) moves to the front
+        const uint64_t rem = staged - m;
+        if (rem) {
+            HIP_TRY(hipMemcpyAsync(d_rows, d_rows + m * N, 4ull * N * rem, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            for (uint64_t l = 0; l < rem; ++l) ngt[l] = ngt[m + l];
+        }
+        staged = rem;
+        ++ranges;
+    }
+    total.blocks_bytes = region_off;
+    ctx->reencode_ranges = ranges;
+    if (h_result) *h_result = total;
+    return XSI_OK;
 }
+
+uint32_t xsi_hip_ctx_reencode_ranges(const xsi_hip_ctx* ctx) { return ctx ? ctx->reencode_ranges : 0u; }
 
 }  // extern "C"
