@@ -215,7 +215,9 @@ int xsi_hip_gather_block_streams_round(xsi_hip_comm* c, const void* d_region, ui
     //    first error and skips the rest, and ncclGroupEnd is issued whatever happened.
     // Test hooks (tests/test_gpu_dist.py): XSI_DIST_SELF_SEND=1 sends the writer rank's own part to itself with
     // ncclSend + ncclRecv inside the group instead of copying it, so that the point-to-point branch runs on a one-GPU
-    // box; XSI_DIST_TEST_BAD_RECV=1 posts a receive from a peer that does not exist.
+    // box; XSI_DIST_TEST_BAD_RECV=1 makes the FIRST receive of the group fail with ncclInvalidArgument as a refused post
+    // would (reported here: nothing invalid is handed to RCCL and nothing has been queued yet, so no peer is left
+    // waiting for a message that never comes).
     const bool self_send = getenv("XSI_DIST_SELF_SEND") != nullptr;
     const bool bad_recv = getenv("XSI_DIST_TEST_BAD_RECV") != nullptr;
     uint8_t* const reg_all = static_cast<uint8_t*>(d_region_all) + region_base;
@@ -236,9 +238,8 @@ int xsi_hip_gather_block_streams_round(xsi_hip_comm* c, const void* d_region, ui
         for (int r = 0; r < W; ++r) {
             const uint64_t b = meta[2u * r], n = meta[2u * r + 1u];
             if (r != me || self_send) {
-                const int peer = bad_recv ? W + 7 : r;
-                if (b) post("ncclRecv(region)", [&] { return R.Recv(reg_all + bb, b, ncclUint8, peer, c->comm, s); });
-                if (n) post("ncclRecv(offsets)", [&] { return R.Recv(off_all + bn, n, ncclUint64, peer, c->comm, s); });
+                if (b) post("ncclRecv(region)", [&] { return bad_recv ? ncclInvalidArgument : R.Recv(reg_all + bb, b, ncclUint8, r, c->comm, s); });
+                if (n) post("ncclRecv(offsets)", [&] { return R.Recv(off_all + bn, n, ncclUint64, r, c->comm, s); });
             }
             bb += b;
             bn += n;
