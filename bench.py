@@ -237,6 +237,40 @@ def run_config4(args, real_stdout, emit=True):
     fence()
     dt = time.perf_counter() - t0
     _, ok_chk = one_pass(499)  # the same queries again, checked against the source rows (not timed)
+    # ---- the random queries again through ONE call per batch (xsi_accessor_get_genotypes_batch): the kernels store the
+    # rows of a batch into a page-locked array of args.batch rows; one launch per block touched, one completion ----
+    binding.check(L.xsi_accessor_unregister_array(a))
+    nb_rows = max(1, min(args.batch, len(q_lines)))
+    bat = torch.empty((nb_rows, N), dtype=torch.int32, pin_memory=True)
+    bat_np = bat.numpy()
+    binding.check(L.xsi_accessor_register_array(a, bat_np.ctypes.data, bat_np.size))
+    q_bm = np.ascontiguousarray(all_bm[:len(q_lines)], dtype=np.uint64)
+    q_na = np.ascontiguousarray(all_na[:len(q_lines)], dtype=np.uint32)
+
+    def batched_pass(check):
+        ok = True
+        t_chk = 0.0
+        t = time.perf_counter()
+        for b0 in range(0, len(q_lines), nb_rows):
+            m = min(nb_rows, len(q_lines) - b0)
+            r = L.xsi_accessor_get_genotypes_batch(a, m, q_na[b0:].ctypes.data, q_bm[b0:].ctypes.data, bat_np.ctypes.data, N, None)
+            if r != m * N:
+                raise SystemExit("get_genotypes_batch failed: %s" % L.xsi_hip_last_error())
+            if check:
+                tc = time.perf_counter()
+                for k in range(0, m, 37):
+                    ok = ok and bool(np.array_equal(bat_np[k], rows[int(q_lines[b0 + k])].cpu().numpy()))
+                t_chk += time.perf_counter() - tc
+        return time.perf_counter() - t - t_chk, ok
+
+    batched_pass(False)
+    fence()
+    t_b0 = time.perf_counter()
+    for _ in range(steps):
+        batched_pass(False)
+    fence()
+    dt_batched = (time.perf_counter() - t_b0) / steps
+    _, ok_batched = batched_pass(True)
     binding.check(L.xsi_accessor_cache_stats(a, ctypes.byref(cb), ctypes.byref(cby), ctypes.byref(hits), ctypes.byref(misses)))
     timed_misses = int(misses.value) - cold_misses
     if distributed:
@@ -276,7 +310,13 @@ def run_config4(args, real_stdout, emit=True):
                           # touches cost (decode of all the block's lines to planes in HBM, cache allocation)
                           "ms_per_block_decode": 1e3 * max(t_cold - dt / steps, 0.0) / max(cold_misses, 1)},
             "build": {"synth_s": t_synth, "encode_gt_s": t_encode, "encode_cells_per_s": float(N) * S / t_encode},
-            "rows_match_source": bool(ok_cold and ok_warm and ok_chk),
+            "batched": {"what": "the %d random queries of the step through xsi_accessor_get_genotypes_batch, %d per call, rows stored by "
+                                "the compose kernels into a page-locked array" % (len(q_lines), nb_rows),
+                        "us_per_query": dt_batched / max(len(q_lines), 1) * 1e6,
+                        "value": float(N) * len(q_lines) / dt_batched, "unit": "GT cells/s",
+                        "host_GBps": 4.0 * float(N) * len(q_lines) / dt_batched / 1e9,
+                        "rows_match_source": bool(ok_batched)},
+            "rows_match_source": bool(ok_cold and ok_warm and ok_chk and ok_batched),
         }
         if not args.no_cpu_baseline:
             from oracle import oracle
@@ -352,6 +392,7 @@ def main():
     ap.add_argument("--windows", type=int, default=1000, help="config 4: contiguous windows per step")
     ap.add_argument("--window-len", type=int, default=1000)
     ap.add_argument("--cpu-queries", type=int, default=12, help="config 4: random queries of the CPU-oracle leg")
+    ap.add_argument("--batch", type=int, default=64, help="config 4: lines per xsi_accessor_get_genotypes_batch call")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check without a GPU: the ranks only form a gloo group and report in (CPU test)")
     args = ap.parse_args()

@@ -376,7 +376,8 @@ int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_
  * fills into exactly this pointer are stored there by the compose kernel itself (posted PCIe writes: one launch,
  * one completion, no window copy; 33 instead of 73 us per line at 200 000 haplotypes).
  * n_values must be at least 2 * num_samples - the width of a composed row whatever a line's ploidy; a smaller array
- * is refused (XSI_ERR_CAPACITY) and keeps working through the ordinary path.
+ * is refused (XSI_ERR_CAPACITY) and keeps working through the ordinary path.  All n_values are page-locked, so an
+ * array of many rows serves xsi_accessor_get_genotypes_batch as well.
  * LIFETIME: the array must stay allocated, at this address, until xsi_accessor_unregister_array, the next
  * xsi_accessor_register_array or xsi_accessor_close returns; freeing it earlier leaves the device with a mapping of
  * freed pages.  One array per accessor.  XSI_ACCESSOR_NO_REGISTER=1 makes this call a no-op (measurement);
@@ -387,6 +388,16 @@ int xsi_accessor_unregister_array(xsi_accessor* a);
  * sets *ngt_arr = hap_samples (accessor.hpp:58-67). */
 int64_t xsi_accessor_get_genotypes(xsi_accessor* a, uint32_t n_alleles, uint64_t position, void** h_gt,
                                    int* ngt_arr);
+/* n lines in one call (no reference counterpart: Accessor::get_genotypes is one line per call, and every call here is
+ * one kernel launch and one completion, 33 us at 200 000 haplotypes): query i = (n_alleles[i], positions[i]), any
+ * order, any blocks; its values land in h_rows + i * row_stride (row_stride >= 2 * num_samples values), their number in
+ * h_ngt[i] (optional).  The queries are grouped by block, each block touched costs one compose launch, a chunk of up
+ * to 4096 lines one completion.  Rows inside the array registered with xsi_accessor_register_array are stored there by
+ * the kernels themselves; other memory is filled through the accessor's device window, one copy per chunk.  Returns the
+ * total number of values or <0.  Allele counts are not collected (xsi_accessor_allele_counts keeps the last single
+ * fill's). */
+int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint32_t* n_alleles, const uint64_t* positions,
+                                         int32_t* h_rows, uint64_t row_stride, uint32_t* h_ngt);
 /* The line's values without the copy into a caller array: *h_gt points into the accessor's pinned host window
  * (valid until the next call on this accessor); returns the number of values.  Counts as after a fill. */
 int64_t xsi_accessor_genotypes_view(xsi_accessor* a, uint32_t n_alleles, uint64_t position, const int32_t** h_gt);

@@ -389,6 +389,17 @@ def test_config4_shape_against_oracle(tmp_path):
         assert L.xsi_accessor_fill_genotype_array(a, dst.ctypes.data, dst.size, int(nal[i]), int(bm[i])) == n_haps
         assert np.array_equal(dst, rows[i]), "step %d line %d" % (k, i)
     binding.check(L.xsi_accessor_unregister_array(a))
+    # batched queries at this shape: 48 random lines of all blocks in one call, into a registered 2-D array
+    bq = np.asarray([int(x) for x in rng.integers(0, n_lines, 48)], dtype=np.int64)
+    b_na = np.ascontiguousarray(nal[bq], dtype=np.uint32)
+    b_bm = np.ascontiguousarray(bm[bq], dtype=np.uint64)
+    brow = np.full((len(bq), n_haps), -3, dtype=np.int32)
+    binding.check(L.xsi_accessor_register_array(a, brow.ctypes.data, brow.size))
+    tot = L.xsi_accessor_get_genotypes_batch(a, len(bq), b_na.ctypes.data, b_bm.ctypes.data, brow.ctypes.data, n_haps, None)
+    assert tot == len(bq) * n_haps, L.xsi_hip_last_error()
+    for k, i in enumerate(bq):
+        assert np.array_equal(brow[k], rows[int(i)]), "batched query %d (line %d)" % (k, int(i))
+    binding.check(L.xsi_accessor_unregister_array(a))
     buf[:] = -5   # unregistered: the ordinary path again
     assert L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, int(nal[77]), int(bm[77])) == n_haps
     assert np.array_equal(buf, rows[77])

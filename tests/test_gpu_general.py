@@ -263,6 +263,31 @@ def test_writer_and_accessor_files(tmp_path, kw):
         assert np.array_equal(buf[:r], exp), "line %d" % i
         binding.check(L.xsi_accessor_allele_counts(a, cnt.ctypes.data, na))
         assert np.array_equal(cnt[:na], ecnt)
+    # the same lines through ONE batched call: random order, several blocks, rows with a stride wider than a line;
+    # first into ordinary memory (device window + one copy per chunk), then into a registered array (the kernels store
+    # into it), then with a cache that holds one block (every switch of block decodes again)
+    q = np.asarray(order[::-1] + [5, 5, 699], dtype=np.int64)
+    q_na = np.asarray([lines[i][1] for i in q], dtype=np.uint32)
+    q_bm = np.asarray([bms[i] for i in q], dtype=np.uint64)
+    stride = 2 * n + 3
+    for mode in ("plain", "registered", "one-block cache"):
+        rows2 = np.full((len(q), stride), -9, dtype=np.int32)
+        ngt2 = np.zeros(len(q), dtype=np.uint32)
+        if mode == "registered":
+            binding.check(L.xsi_accessor_register_array(a, rows2.ctypes.data, rows2.size))
+        if mode == "one-block cache":
+            binding.check(L.xsi_accessor_set_cache_bytes(a, 1))
+        tot = L.xsi_accessor_get_genotypes_batch(a, len(q), q_na.ctypes.data, q_bm.ctypes.data, rows2.ctypes.data, stride,
+                                                 ngt2.ctypes.data)
+        assert tot == int(sum(len(lines[i][0]) for i in q)), L.xsi_hip_last_error()
+        for k, i in enumerate(q):
+            assert ngt2[k] == len(lines[i][0])
+            assert np.array_equal(rows2[k, :ngt2[k]], lines[i][0]), "%s: query %d (line %d)" % (mode, k, i)
+        assert np.all(rows2[:, 2 * n:] == -9)
+        if mode == "registered":
+            binding.check(L.xsi_accessor_unregister_array(a))
+    assert L.xsi_accessor_get_genotypes_batch(a, 1, q_na.ctypes.data, q_bm.ctypes.data, rows2.ctypes.data, 2 * n - 1,
+                                              None) == binding.XSI_ERR_CAPACITY
     # get_genotypes allocates like Accessor::get_genotypes (accessor.hpp:58-67)
     pp = ctypes.c_void_p()
     ngt_arr = ctypes.c_int(0)

@@ -58,6 +58,7 @@ SYMBOLS = [
     "xsi_hip_encode_packed_counted", "xsi_hip_count_packed_rows",
     "xsi_accessor_register_array", "xsi_accessor_unregister_array", "xsi_hip_gather_block_streams_round",
     "xsi_compress_bcf", "xsi_decompress_bcf", "xsi_hip_ctx_reencode_ranges",
+    "xsi_accessor_get_genotypes_batch",
 ]
 
 
@@ -205,6 +206,8 @@ def lib():
     L.xsi_accessor_unregister_array.argtypes = [vp]
     L.xsi_accessor_get_genotypes.restype = c.c_int64
     L.xsi_accessor_get_genotypes.argtypes = [vp, u32, u64, c.POINTER(vp), c.POINTER(c.c_int)]
+    L.xsi_accessor_get_genotypes_batch.restype = c.c_int64
+    L.xsi_accessor_get_genotypes_batch.argtypes = [vp, u64, vp, vp, vp, u64, vp]
     L.xsi_accessor_genotypes_view.restype = c.c_int64
     L.xsi_accessor_genotypes_view.argtypes = [vp, u32, u64, vp]
     L.xsi_accessor_get_internal_access.restype = c.c_int

@@ -99,7 +99,8 @@ int dot_planes(xsi_hip_ctx* ctx, const DecodePlan& P, const uint32_t* planes, ui
                uint32_t n_pheno, double* d_out);
 int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D, const uint32_t* d_first_bin,
                   const uint32_t* d_n_allele, uint32_t n_out, int32_t* d_gt_out, uint64_t gt_stride,
-                  uint32_t* d_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles);
+                  uint32_t* d_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles,
+                  const uint32_t* d_out_index = nullptr);
 int select_samples(xsi_hip_ctx* ctx, const int32_t* d_rows, uint64_t row_stride, const uint32_t* d_line_ngt,
                    uint32_t n_lines, uint32_t n_samples, const uint32_t* d_sel, uint32_t n_sel, int32_t* d_out,
                    uint64_t out_stride, uint32_t* d_ac, uint32_t n_alt);

@@ -578,6 +578,7 @@ struct ComposeArgs {
     uint32_t* line_ngt;       // per BCF line
     uint64_t* allele_counts;  // [n_bcf][max_alleles] or nullptr
     uint32_t max_alleles;
+    const uint32_t* out_index;  // nullptr: line li of the launch is output row li; else row out_index[li] (batched queries)
 };
 
 __global__ void __launch_bounds__(256) k_compose_gt(ComposeArgs C) {
@@ -591,7 +592,8 @@ __global__ void __launch_bounds__(256) k_compose_gt(ComposeArgs C) {
     const uint32_t* mp = C.S.miss_planes ? C.S.miss_planes + (size_t)start * C.S.stride_w : nullptr;
     const uint32_t* ep = C.S.eov_planes ? C.S.eov_planes + (size_t)start * C.S.stride_w : nullptr;
     const uint32_t* pp = C.S.phase_planes ? C.S.phase_planes + (size_t)start * C.S.stride_w : nullptr;
-    int32_t* orow = C.out + (size_t)li * C.out_stride;
+    const uint32_t oi = C.out_index ? C.out_index[li] : li;  // where this line's row, value count and allele counts go
+    int32_t* orow = C.out + (size_t)oi * C.out_stride;
     // value of haplotype i of this line
     // w0 = word i / 32 of the line's first plane (the callers fetch it ahead of time)
     auto value_of = [&](uint32_t i, uint32_t w0) -> int32_t {
@@ -669,16 +671,16 @@ __global__ void __launch_bounds__(256) k_compose_gt(ComposeArgs C) {
         for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < Nl; i += blockDim.x * gridDim.y) orow[i] = value_of(i, p0[i >> 5]);
     }
     if (threadIdx.x == 0 && blockIdx.y == 0) {
-        C.line_ngt[li] = Nl;
+        C.line_ngt[oi] = Nl;
         if (C.allele_counts) {
             uint64_t total = 0;
             for (uint32_t alt = 1; alt < n_allele && alt < C.max_alleles; ++alt) {
                 const uint64_t o = C.ones[start + alt - 1u];
-                C.allele_counts[(size_t)li * C.max_alleles + alt] = o;
+                C.allele_counts[(size_t)oi * C.max_alleles + alt] = o;
                 total += o;
             }
             const uint64_t nm = (f & 1u) ? C.S.n_miss[start] : 0u, ne = (f & 2u) ? C.S.n_eov[start] : 0u;
-            C.allele_counts[(size_t)li * C.max_alleles] = (uint64_t)Nl - (total + nm + ne);
+            C.allele_counts[(size_t)oi * C.max_alleles] = (uint64_t)Nl - (total + nm + ne);
         }
     }
 }
@@ -943,7 +945,7 @@ int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, Decod
 // int32 rows for n_out BCF lines given (first binary line, n_allele) per line (device arrays).
 int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D, const uint32_t* d_first_bin,
                   const uint32_t* d_n_allele, uint32_t n_out, int32_t* d_gt_out, uint64_t gt_stride,
-                  uint32_t* d_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles) {
+                  uint32_t* d_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles, const uint32_t* d_out_index) {
     if (!n_out) return XSI_OK;
     ComposeArgs C{};
     C.planes = D.planes;
@@ -968,6 +970,7 @@ int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D,
     C.line_ngt = d_line_ngt;
     C.allele_counts = d_allele_counts;
     C.max_alleles = max_alleles;
+    C.out_index = d_out_index;
     stage_mark(ctx, XSI_ST_GT_COMPOSE);
     uint32_t splits = (P.L.N + 2047u) / 2048u;  // >= 8 values per thread
     if (splits > 2048u / n_out) splits = 2048u / n_out;

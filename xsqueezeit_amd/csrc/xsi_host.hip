@@ -12,6 +12,7 @@
 //             learns from each call's n_alleles, accessor.hpp:48-50) and served from pinned memory.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -549,6 +550,8 @@ struct xsi_accessor {
     bool win_in_rows = true;        // the window's lines are in h_rows (false after a direct single-line copy)
     uint64_t* h_counts = nullptr;  // pinned [win][2] or [1][max]
     uint32_t* h_meta = nullptr;    // pinned
+    uint32_t* h_bmeta = nullptr;   // pinned, batched queries: [4][bmeta_cap] first binary line, alleles, output row, values
+    uint32_t bmeta_cap = 0;
     uint32_t win_rows = 0, win_first = 0, win_n = 0, win_target = 1;
     int64_t win_block = -1;
     uint32_t counts_cap = 0;
@@ -998,7 +1001,7 @@ int xsi_accessor_register_array(xsi_accessor* a, int32_t* h_gt, uint64_t n_value
     if (a->ctx) HIP_TRY(hipStreamSynchronize(a->ctx->stream));
     accessor_drop_registration(a);
     if (getenv("XSI_ACCESSOR_NO_REGISTER")) return XSI_OK;  // measurement: every line through the pinned window + memcpy
-    const size_t bytes = (size_t)a->n_full * sizeof(int32_t);
+    const size_t bytes = (size_t)n_values * sizeof(int32_t);  // the whole array: a batch fills many rows of it
     // an array the caller has page-locked already (hipHostMalloc, its own hipHostRegister) serves as it is:
     // hipHostRegister refuses such memory (hipHostMalloc'ed pages with "invalid argument" on this runtime)
     hipPointerAttribute_t attr;
@@ -1088,6 +1091,95 @@ int64_t xsi_accessor_get_genotypes(xsi_accessor* a, uint32_t n_alleles, uint64_t
     }
     *ngt_arr = (int)ngt;
     return xsi_accessor_fill_genotype_array(a, (int32_t*)*h_gt, ngt, n_alleles, position);
+}
+
+int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint32_t* n_alleles, const uint64_t* positions,
+                                         int32_t* h_rows, uint64_t row_stride, uint32_t* h_ngt) {
+    if (!a || !n_alleles || !positions || !h_rows) return set_error(XSI_ERR_ARG, "get_genotypes_batch: null argument");
+    if (row_stride < a->n_full)
+        return set_error(XSI_ERR_CAPACITY, "get_genotypes_batch: row_stride %llu < %llu values of a composed row",
+                         (unsigned long long)row_stride, (unsigned long long)a->n_full);
+    if (!n) return 0;
+    hipStream_t s = a->ctx->stream;
+    const uint64_t N = a->n_full;
+    a->direct_dst = nullptr;
+    a->direct_done = false;
+    a->win_n = 0;  // the single-line window does not survive a batch
+    // Destination: rows inside the registered array are stored there by the compose kernels themselves (posted PCIe
+    // writes, one completion per chunk); any other memory goes through the device window and one copy per chunk.
+    const bool zero_copy = getenv("XSI_ACCESSOR_NO_ZEROCOPY") == nullptr;
+    const uint8_t* rb = reinterpret_cast<const uint8_t*>(a->reg_dst);
+    const uint8_t* hb = reinterpret_cast<const uint8_t*>(h_rows);
+    const bool direct = zero_copy && a->reg_dst && a->reg_dev && hb >= rb &&
+                        hb + ((n - 1u) * row_stride + N) * sizeof(int32_t) <= rb + a->reg_bytes;
+    const uint32_t chunk_cap = direct ? 4096u : a->win_rows;
+    if (a->bmeta_cap < chunk_cap) {
+        if (a->h_bmeta) (void)hipHostFree(a->h_bmeta);
+        a->h_bmeta = nullptr;
+        a->bmeta_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&a->h_bmeta, 16ull * chunk_cap, hipHostMallocDefault));
+        a->bmeta_cap = chunk_cap;
+    }
+    uint32_t* fb = a->h_bmeta;
+    uint32_t* na = fb + a->bmeta_cap;
+    uint32_t* oi = na + a->bmeta_cap;
+    uint32_t* ng = oi + a->bmeta_cap;
+    std::vector<uint32_t> order;
+    int64_t total = 0;
+    for (uint64_t c0 = 0; c0 < n; c0 += chunk_cap) {
+        const uint32_t m = (uint32_t)(n - c0 < chunk_cap ? n - c0 : chunk_cap);
+        // queries of a chunk grouped by block (stable): one compose launch per block touched
+        order.resize(m);
+        for (uint32_t i = 0; i < m; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            return ((positions[c0 + x] & 0xFFFFFFFFull) >> BM_BLOCK_BITS) < ((positions[c0 + y] & 0xFFFFFFFFull) >> BM_BLOCK_BITS);
+        });
+        int32_t* const d_dst = direct ? a->reg_dev + ((h_rows - static_cast<int32_t*>(a->reg_dst)) + (ptrdiff_t)(c0 * row_stride)) : a->d_rows;
+        const uint64_t d_stride = direct ? row_stride : N;
+        for (uint32_t g0 = 0; g0 < m;) {
+            const uint64_t block = (positions[c0 + order[g0]] & 0xFFFFFFFFull) >> BM_BLOCK_BITS;
+            uint32_t g1 = g0;
+            while (g1 < m && ((positions[c0 + order[g1]] & 0xFFFFFFFFull) >> BM_BLOCK_BITS) == block) ++g1;
+            if (a->cur_block < 0 || (uint64_t)a->cur_block != block) {
+                // a block that lives in the context workspace (cache too small) is overwritten by the next decode:
+                // the composes that read it must have finished
+                if (a->cur_in_workspace) HIP_TRY(hipStreamSynchronize(s));
+                int rc = accessor_load_block(a, block);
+                if (rc) return rc;
+            }
+            for (uint32_t g = g0; g < g1; ++g) {
+                const uint64_t q = c0 + order[g];
+                const uint32_t offset = (uint32_t)(positions[q] & ((1u << BM_BLOCK_BITS) - 1u));
+                if (n_alleles[q] < 2u) return set_error(XSI_ERR_ARG, "get_genotypes_batch: query %llu: n_alleles < 2", (unsigned long long)q);
+                if (offset + (n_alleles[q] - 1u) > a->P.n_bin)
+                    return set_error(XSI_ERR_ARG, "get_genotypes_batch: query %llu: offset %u (+%u alleles) beyond the %u binary lines of block %llu",
+                                     (unsigned long long)q, offset, n_alleles[q] - 1u, a->P.n_bin, (unsigned long long)block);
+                fb[g] = offset;
+                na[g] = n_alleles[q];
+                oi[g] = order[g];
+            }
+            int rc = compose_lines(a->ctx, a->P, a->D, fb + g0, na + g0, g1 - g0, d_dst, d_stride, ng, nullptr, 0, oi + g0);
+            if (rc) return rc;
+            g0 = g1;
+        }
+        if (!direct) {
+            if (row_stride == N)
+                HIP_TRY(hipMemcpyAsync(h_rows + c0 * row_stride, a->d_rows, (size_t)m * N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            else
+                HIP_TRY(hipMemcpy2DAsync(h_rows + c0 * row_stride, row_stride * sizeof(int32_t), a->d_rows, N * sizeof(int32_t),
+                                         N * sizeof(int32_t), m, hipMemcpyDeviceToHost, s));
+        }
+        // one completion per chunk: the pinned metadata is reused by the next chunk, and the rows must have landed
+        hipError_t qe;
+        while ((qe = hipStreamQuery(s)) == hipErrorNotReady) {
+        }
+        HIP_TRY(qe);
+        for (uint32_t i = 0; i < m; ++i) {
+            if (h_ngt) h_ngt[c0 + i] = ng[i];
+            total += ng[i];
+        }
+    }
+    return total;
 }
 
 int xsi_accessor_set_sample_subset(xsi_accessor* a, const uint32_t* sample_idx, uint32_t n) {
@@ -1361,6 +1453,7 @@ void xsi_accessor_close(xsi_accessor* a) {
     if (a->h_rows) (void)hipHostFree(a->h_rows);
     if (a->h_counts) (void)hipHostFree(a->h_counts);
     if (a->h_meta) (void)hipHostFree(a->h_meta);
+    if (a->h_bmeta) (void)hipHostFree(a->h_bmeta);
     if (a->d_sel) (void)hipFree(a->d_sel);
     if (a->d_sel_row) (void)hipFree(a->d_sel_row);
     if (a->h_sel_row) (void)hipHostFree(a->h_sel_row);
