@@ -263,6 +263,34 @@ def run_config4(args, real_stdout, emit=True):
                 t_chk += time.perf_counter() - tc
         return time.perf_counter() - t - t_chk, ok
 
+    # ---- cold isolated queries: the block is not in HBM, ONE line at binary-line offset o is asked for.  The first
+    # touch runs the chain over the WAH lines in front of o only (what the reference's seek replays on the host,
+    # accessor_internals_new.hpp:154-196), so its cost scales with o; full_block_ms is the same query with
+    # XSI_ACCESSOR_FULL_DECODE=1 (the whole block decoded on first touch, as before round 4) ----
+    cold_iso = []
+    binding.check(L.xsi_accessor_unregister_array(a))
+    binding.check(L.xsi_accessor_register_array(a, buf.ctypes.data, buf.size))
+    budget_before = int(cby.value) * 4 + (8 << 30)
+    line_of_block0 = np.arange(min(bl, S))
+    for frac in (0.3, 1.0 / 128, 1.0 / 16, 0.25, 0.5, 0.97):  # the first one warms the path up and is dropped
+        li = int(line_of_block0[int(frac * (len(line_of_block0) - 1))])
+        rec = {"line": li, "bm_offset": int(bm[li] & 0x7FFF)}
+        for mode in ("prefix", "full"):
+            if mode == "full":
+                os.environ["XSI_ACCESSOR_FULL_DECODE"] = "1"
+            binding.check(L.xsi_accessor_set_cache_bytes(a, 0))       # evict everything
+            binding.check(L.xsi_accessor_set_cache_bytes(a, budget_before))
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            r = get(a, int(nal[li]), int(bm[li]), ctypes.byref(pbuf), ctypes.byref(nout))
+            rec[mode + "_ms"] = (time.perf_counter() - tq) * 1e3
+            os.environ.pop("XSI_ACCESSOR_FULL_DECODE", None)
+            if r != N or not np.array_equal(buf, rows[li].cpu().numpy()):
+                raise SystemExit("cold query at line %d (%s) failed: %s" % (li, mode, L.xsi_hip_last_error()))
+        cold_iso.append(rec)
+    cold_iso = cold_iso[1:]
+    binding.check(L.xsi_accessor_unregister_array(a))
+    binding.check(L.xsi_accessor_register_array(a, bat_np.ctypes.data, bat_np.size))
     batched_pass(False)
     fence()
     t_b0 = time.perf_counter()
@@ -316,6 +344,9 @@ def run_config4(args, real_stdout, emit=True):
                         "value": float(N) * len(q_lines) / dt_batched, "unit": "GT cells/s",
                         "host_GBps": 4.0 * float(N) * len(q_lines) / dt_batched / 1e9,
                         "rows_match_source": bool(ok_batched)},
+            "cold_isolated_queries": {"what": "one line asked of a block that is not in HBM, at rising offsets into the block: "
+                                              "prefix_ms = first touch decodes the lines in front of it only, full_ms = the whole block",
+                                      "block_lines": int(min(bl, S)), "queries": cold_iso},
             "rows_match_source": bool(ok_cold and ok_warm and ok_chk and ok_batched),
         }
         if not args.no_cpu_baseline:

@@ -408,6 +408,13 @@ int xsi_accessor_set_cache_bytes(xsi_accessor* a, uint64_t bytes);
 /* Any of the outputs may be NULL. */
 int xsi_accessor_cache_stats(const xsi_accessor* a, uint64_t* blocks, uint64_t* bytes, uint64_t* hits,
                              uint64_t* misses);
+/* The first touch of a block decodes only what the query needs: its sparse lines and side channels, and the PBWT chain
+ * over the WAH lines IN FRONT of the requested line - what the reference's seek replays on the host
+ * (accessor_internals_new.hpp:154-196) - leaving the chain's ranks parked in HBM; a later query further into the block
+ * continues from there (in steps that grow by half of what is decoded, so a scan through a cold block is a dozen
+ * continuations).  prefix_decodes: first touches that stopped before the block's end; extensions: continuations since
+ * open.  XSI_ACCESSOR_FULL_DECODE=1 decodes whole blocks on first touch (measurement, as before round 4). */
+int xsi_accessor_prefix_stats(const xsi_accessor* a, uint64_t* prefix_decodes, uint64_t* extensions);
 /* Sample selection on decode (NewDecompressor::fill_selected_genotypes, include/gt_decompressor_new.hpp:209-238):
  * after set_sample_subset(idx, n) (indices into the file's sample list, any order, repeats allowed; n = 0
  * clears), fill_selected_genotypes composes the line on the device, gathers the listed samples there and

@@ -375,6 +375,10 @@ def test_config4_shape_against_oracle(tmp_path):
         assert np.array_equal(buf, rows[i]), "line %d vs source" % i
         binding.check(L.xsi_accessor_allele_counts(a, cnt.ctypes.data, int(nal[i])))
         assert np.array_equal(cnt[:int(nal[i])], ecnt)
+    # first touches stopped at the requested line (prefix decode) and later queries further in continued from there
+    pd, ext = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    binding.check(L.xsi_accessor_prefix_stats(a, ctypes.byref(pd), ctypes.byref(ext)))
+    assert pd.value >= 1 and ext.value >= 1, (pd.value, ext.value)
     # a REGISTERED caller array (xsi_accessor_register_array) is page-locked and the compose kernel stores single lines
     # into it: the same line twice, a sequential run (which goes back through the window), another (unregistered)
     # array in between, then the first again; a too-small array is refused and nothing is locked

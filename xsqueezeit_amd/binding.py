@@ -58,7 +58,7 @@ SYMBOLS = [
     "xsi_hip_encode_packed_counted", "xsi_hip_count_packed_rows",
     "xsi_accessor_register_array", "xsi_accessor_unregister_array", "xsi_hip_gather_block_streams_round",
     "xsi_compress_bcf", "xsi_decompress_bcf", "xsi_hip_ctx_reencode_ranges",
-    "xsi_accessor_get_genotypes_batch",
+    "xsi_accessor_get_genotypes_batch", "xsi_accessor_prefix_stats",
 ]
 
 
@@ -222,6 +222,8 @@ def lib():
     L.xsi_accessor_sample_name.argtypes = [vp, u64]
     L.xsi_accessor_set_cache_bytes.restype = c.c_int
     L.xsi_accessor_set_cache_bytes.argtypes = [vp, u64]
+    L.xsi_accessor_prefix_stats.restype = c.c_int
+    L.xsi_accessor_prefix_stats.argtypes = [vp, c.POINTER(u64), c.POINTER(u64)]
     L.xsi_accessor_cache_stats.restype = c.c_int
     L.xsi_accessor_cache_stats.argtypes = [vp, c.POINTER(u64), c.POINTER(u64), c.POINTER(u64), c.POINTER(u64)]
     L.xsi_hip_decode_dot.restype = c.c_int

@@ -924,6 +924,116 @@ int decode_counts_only(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P) {
     return XSI_OK;
 }
 
+// The WAH lines [lo[b], hi[b]) of every block b (block-relative ranks; nullptr: all of them) in K ranges: the expansion
+// of range p + 1 (side stream) runs underneath the chain of range p, which parks its ranks in `d_state` between the
+// launches - and behind the last one, when hi[b] is not the block's last WAH line, so that a later call continues
+// from there (the accessor's prefix decode).  The boundaries must have been computed on the context's stream.
+static int run_wah_phases(xsi_hip_ctx* ctx, const uint8_t* f, DecodePlan& P, uint32_t* out, uint32_t stride_w,
+                          const uint32_t* lo, const uint32_t* hi, uint32_t K, uint32_t* d_state) {
+    hipStream_t s = ctx->stream;
+    DecLines& L = P.L;
+    const uint32_t nb = P.n_blocks, lpg = wah_expand_lines_per_group(L);
+    // per phase and block: first WAH line (batch-wide rank), lines, and the running number of 4-line groups
+    P.phase_tab.assign((size_t)K * (3u * nb + 1u), 0u);
+    for (uint32_t p = 0; p < K; ++p) {
+        uint32_t* start = P.phase_tab.data() + (size_t)p * (3u * nb + 1u);
+        uint32_t *cnt = start + nb, *gpre = cnt + nb;
+        uint32_t g = 0;
+        for (uint32_t b = 0; b < nb; ++b) {
+            const DecBlock& D = P.blocks_h[b];
+            const uint32_t nw = D.error ? 0u : D.n_wah;
+            const uint32_t b_lo = lo ? (lo[b] < nw ? lo[b] : nw) : 0u, b_hi = hi ? (hi[b] < nw ? hi[b] : nw) : nw;
+            const uint32_t n = b_hi > b_lo ? b_hi - b_lo : 0u;
+            const uint32_t plo = (uint32_t)((uint64_t)n * p / K), phi = (uint32_t)((uint64_t)n * (p + 1u) / K);
+            start[b] = D.wah_first + b_lo + plo;
+            cnt[b] = phi - plo;
+            gpre[b] = g;
+            g += (phi - plo + lpg - 1u) / lpg;
+        }
+        gpre[nb] = g;
+    }
+    uint32_t* d_tab;
+    WS(d_tab, "dec.phase_tab", 4ull * P.phase_tab.size());
+    HIP_TRY(hipMemcpyAsync(d_tab, P.phase_tab.data(), 4ull * P.phase_tab.size(), hipMemcpyHostToDevice, s));
+    if (!ctx->side2) HIP_TRY(hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
+    while (ctx->ev_phase.size() < (size_t)K + 1u) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->ev_phase.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(ctx->ev_phase[K], s));  // boundaries done, table uploaded
+    HIP_TRY(hipStreamWaitEvent(ctx->side2, ctx->ev_phase[K], 0));
+    for (uint32_t p = 0; p < K; ++p) {
+        const uint32_t* tab = d_tab + (size_t)p * (3u * nb + 1u);
+        const uint32_t groups = P.phase_tab[(size_t)p * (3u * nb + 1u) + 3u * nb];
+        HIP_TRY(launch_wah_expand_phase(ctx->side2, f, P.d_blocks, L, P.d_totals, tab, tab + nb, tab + 2u * nb, nb, groups));
+        HIP_TRY(hipEventRecord(ctx->ev_phase[p], ctx->side2));
+    }
+    stage_mark(ctx, XSI_ST_DEC_EXPAND);  // what shows of the expansion: the wait for its first range
+    // (measurement: XSI_DEC_PHASES_SERIAL=1 lets every range expand before the first chain launch, which leaves
+    // the chain's launches by themselves: their time minus the unphased chain's is the cost of cutting it up)
+    HIP_TRY(hipStreamWaitEvent(s, ctx->ev_phase[getenv("XSI_DEC_PHASES_SERIAL") ? K - 1u : 0u], 0));
+    stage_mark(ctx, XSI_ST_CHAIN_DEC);
+    for (uint32_t p = 0; p < K; ++p) {
+        const uint32_t* tab = d_tab + (size_t)p * (3u * nb + 1u);
+        if (p) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_phase[p], 0));
+        HIP_TRY(launch_rank_decode_phase(s, P.d_blocks, nb, L, out, stride_w, tab, tab + nb, d_state));
+    }
+    return XSI_OK;
+}
+
+bool decode_partial_supported(const DecodePlan& P) {
+    if (P.n_blocks != 1u) return false;
+    for (auto& b : P.blocks_h) {
+        if (b.error || b.off_line_haploid != VAL_UNDEFINED) return false;
+        // version-4 weirdness lines are permuted by a chain of their own that is replayed whole (k_dec_side_unpermute)
+        if ((b.off_line_missing != VAL_UNDEFINED || b.off_line_eov != VAL_UNDEFINED) && b.strategy == WS_PBWT_WAH) return false;
+    }
+    return rank_decode_phased_ok(P.L.N, P.L.yp_stride, 1u);
+}
+
+// One block, part of its WAH lines: [wah_lo, wah_hi) in block-relative rank order, continuing the chain from the ranks
+// parked in d_state (4 * rank_decode_state_words(N, 1) bytes, owned by the caller) when wah_lo > 0; and its sparse lines
+// of rank [sp_lo, sp_hi) (they do not depend on the chain, but their lists are a pointer chase whose cursor is carried
+// in d_sp_state[0]).  The accessor's prefix decode: a cold query at line o of
+// a block replays the o lines in front of it like the reference's seek (accessor_internals_new.hpp:154-196), not all
+// 8192, and a later query further into the block continues where this one stopped.
+int decode_planes_partial(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t* out, uint32_t stride_w,
+                          uint32_t wah_lo, uint32_t wah_hi, uint32_t* d_state, uint32_t sp_lo, uint32_t sp_hi, uint64_t* d_sp_state) {
+    hipStream_t s = ctx->stream;
+    const uint8_t* f = (const uint8_t*)d_file;
+    DecLines& L = P.L;
+    if (!decode_partial_supported(P)) return set_error(XSI_ERR_UNSUPPORTED, "decode_planes_partial: not a block the ranged chain takes");
+    const bool sparse = sp_hi > sp_lo;
+    if (sparse) {  // the sparse lines in front of the range's end: their lists are a pointer chase of their own
+        L.sp_lo = sp_lo;
+        L.sp_hi = sp_hi < P.n_sparse ? sp_hi : P.n_sparse;
+        L.sp_state = d_sp_state;
+        HIP_TRY(hipEventRecord(ctx->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        HIP_TRY(launch_sparse_walk(ctx->side, f, P.d_blocks, P.n_blocks, L));
+        if (L.sp_hi > L.sp_lo)
+            HIP_TRY(launch_sparse_fill(ctx->side, f, P.d_blocks, L, L.sp_hi - L.sp_lo, P.d_totals, out, stride_w, /*apply_negation=*/0));
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
+    }
+    L.yp_rows = P.n_wah ? P.n_wah : 1u;
+    L.yp_compact = rank_decode_takes_compact(L.N, L.yp_stride, P.n_blocks) ? 1u : 0u;
+    stage_mark(ctx, XSI_ST_DEC_BOUND);
+    HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
+    if (wah_hi > wah_lo) {
+        const uint32_t n = wah_hi - wah_lo;
+        const uint32_t K = n >= 2048u ? 8u : (n >= 512u ? 4u : (n >= 128u ? 2u : 1u));
+        int rc = run_wah_phases(ctx, f, P, out, stride_w, &wah_lo, &wah_hi, K, d_state);
+        if (rc) return rc;
+    }
+    if (sparse) {
+        stage_mark(ctx, XSI_ST_DEC_SPARSE);
+        HIP_TRY(hipStreamWaitEvent(s, ctx->ev_join, 0));
+    }
+    stage_mark(ctx, -1);
+    return XSI_OK;
+}
+
 // WAH boundaries -> expand -> chain; sparse walk -> fill.  Output: one natural-order bit row
 // per binary line at out + l*stride_w.
 int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t* out, uint32_t stride_w, int apply_negation) {
@@ -961,52 +1071,10 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
         return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
     }();
     if (n_phases > 1u && !any_haploid && P.n_wah >= 256u * P.n_blocks && rank_decode_phased_ok(L.N, L.yp_stride, P.n_blocks)) {
-        const uint32_t K = n_phases, nb = P.n_blocks, lpg = wah_expand_lines_per_group(L);
-        // per phase and block: first WAH line (batch-wide rank), lines, and the running number of 4-line groups
-        P.phase_tab.assign((size_t)K * (3u * nb + 1u), 0u);
-        for (uint32_t p = 0; p < K; ++p) {
-            uint32_t* start = P.phase_tab.data() + (size_t)p * (3u * nb + 1u);
-            uint32_t *cnt = start + nb, *gpre = cnt + nb;
-            uint32_t g = 0;
-            for (uint32_t b = 0; b < nb; ++b) {
-                const DecBlock& D = P.blocks_h[b];
-                const uint32_t n = D.error ? 0u : D.n_wah;
-                const uint32_t lo = (uint32_t)((uint64_t)n * p / K), hi = (uint32_t)((uint64_t)n * (p + 1u) / K);
-                start[b] = D.wah_first + lo;
-                cnt[b] = hi - lo;
-                gpre[b] = g;
-                g += (hi - lo + lpg - 1u) / lpg;
-            }
-            gpre[nb] = g;
-        }
-        uint32_t *d_tab, *d_state;
-        WS(d_tab, "dec.phase_tab", 4ull * P.phase_tab.size());
-        WS(d_state, "dec.rank_state", 4ull * rank_decode_state_words(L.N, nb));
-        HIP_TRY(hipMemcpyAsync(d_tab, P.phase_tab.data(), 4ull * P.phase_tab.size(), hipMemcpyHostToDevice, s));
-        if (!ctx->side2) HIP_TRY(hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
-        while (ctx->ev_phase.size() < (size_t)K + 1u) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->ev_phase.push_back(e);
-        }
-        HIP_TRY(hipEventRecord(ctx->ev_phase[K], s));  // boundaries done, table uploaded
-        HIP_TRY(hipStreamWaitEvent(ctx->side2, ctx->ev_phase[K], 0));
-        for (uint32_t p = 0; p < K; ++p) {
-            const uint32_t* tab = d_tab + (size_t)p * (3u * nb + 1u);
-            const uint32_t groups = P.phase_tab[(size_t)p * (3u * nb + 1u) + 3u * nb];
-            HIP_TRY(launch_wah_expand_phase(ctx->side2, f, P.d_blocks, L, P.d_totals, tab, tab + nb, tab + 2u * nb, nb, groups));
-            HIP_TRY(hipEventRecord(ctx->ev_phase[p], ctx->side2));
-        }
-        stage_mark(ctx, XSI_ST_DEC_EXPAND);  // what shows of the expansion: the wait for its first range
-        // (measurement: XSI_DEC_PHASES_SERIAL=1 lets every range expand before the first chain launch, which leaves
-        // the chain's launches by themselves: their time minus the unphased chain's is the cost of cutting it up)
-        HIP_TRY(hipStreamWaitEvent(s, ctx->ev_phase[getenv("XSI_DEC_PHASES_SERIAL") ? K - 1u : 0u], 0));
-        stage_mark(ctx, XSI_ST_CHAIN_DEC);
-        for (uint32_t p = 0; p < K; ++p) {
-            const uint32_t* tab = d_tab + (size_t)p * (3u * nb + 1u);
-            if (p) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_phase[p], 0));
-            HIP_TRY(launch_rank_decode_phase(s, P.d_blocks, nb, L, out, stride_w, tab, tab + nb, d_state));
-        }
+        uint32_t* d_state;
+        WS(d_state, "dec.rank_state", 4ull * rank_decode_state_words(L.N, P.n_blocks));
+        int prc = run_wah_phases(ctx, f, P, out, stride_w, nullptr, nullptr, n_phases, d_state);
+        if (prc) return prc;
     } else {
         stage_mark(ctx, XSI_ST_DEC_EXPAND);
         HIP_TRY(launch_wah_expand(s, f, P.d_blocks, L, P.n_wah, P.d_totals));

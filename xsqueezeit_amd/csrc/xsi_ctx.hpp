@@ -94,7 +94,20 @@ struct DecodedPlanes {
     uint32_t *n_miss = nullptr, *n_eov = nullptr;
 };
 
-int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, DecodedPlanes* out);
+// part != nullptr: one block, only the WAH lines [wah_lo, wah_hi) of it (block-relative rank order), the chain's ranks
+// parked in / resumed from d_state (4 * rank_decode_state_words(N, 1) bytes); first: everything that does not depend on
+// the chain (sparse lines, side channels) is decoded as well, into the workspace; !first: more WAH lines into out->planes
+struct PartialDecode {
+    uint32_t wah_lo, wah_hi;
+    uint32_t* d_state;
+    bool first;
+    // the binary lines this call makes valid: [bin_lo, bin_hi) (everything in front of the WAH line of rank wah_hi); the
+    // side matrices (missing / end of vector / phase) of exactly these lines are walked and expanded, the walk's cursors
+    // carried in d_walk[0..3)
+    uint32_t bin_lo, bin_hi;
+    uint64_t* d_walk;  // [0..3) side-matrix cursors, [3] the sparse matrix cursor
+};
+int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, DecodedPlanes* out, const PartialDecode* part = nullptr);
 int dot_planes(xsi_hip_ctx* ctx, const DecodePlan& P, const uint32_t* planes, uint32_t stride_w, const double* d_y,
                uint32_t n_pheno, double* d_out);
 int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D, const uint32_t* d_first_bin,
@@ -111,6 +124,9 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
 int decode_counts_only(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P);
 int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t* out, uint32_t stride_w,
                   int apply_negation);
+bool decode_partial_supported(const DecodePlan& P);
+int decode_planes_partial(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t* out, uint32_t stride_w,
+                          uint32_t wah_lo, uint32_t wah_hi, uint32_t* d_state, uint32_t sp_lo, uint32_t sp_hi, uint64_t* d_sp_state);
 // region_offset: bytes of the blocks region that earlier batches of the same job already wrote before d_out
 int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide S, std::vector<EncBlock>& blocks_h,
                void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result,

@@ -346,6 +346,10 @@ struct DecSide {
     uint32_t* n_miss;       // per binary line
     uint32_t* n_eov;
     uint32_t stride_w;
+    // ranged walk (the accessor's prefix decode, one block): binary lines [bin_lo, bin_hi) of the block; the cursors behind
+    // line bin_hi - 1 are left in walk_state[0..3) and picked up from there when bin_lo > 0.  walk_state == nullptr: all lines.
+    uint32_t bin_lo, bin_hi;
+    uint64_t* walk_state;
 };
 
 __global__ void __launch_bounds__(64) k_dec_side_flags(const uint8_t* __restrict__ file,
@@ -407,7 +411,17 @@ __global__ void __launch_bounds__(64) k_dec_side_walk(const uint8_t* __restrict_
     uint64_t pm = (D.strategy == WS_SPARSE) ? D.off_miss_sparse : D.off_miss_wah;
     uint64_t pe = (D.strategy == WS_SPARSE) ? D.off_eov_sparse : D.off_eov_wah;
     uint64_t pp = D.off_phase;
-    for (uint32_t i = 0; i < D.n_bin; ++i) {
+    uint32_t i_lo = 0, i_hi = D.n_bin;
+    if (S.walk_state) {
+        i_lo = S.bin_lo < D.n_bin ? S.bin_lo : D.n_bin;
+        i_hi = S.bin_hi < D.n_bin ? S.bin_hi : D.n_bin;
+        if (i_lo) {
+            pm = S.walk_state[0];
+            pe = S.walk_state[1];
+            pp = S.walk_state[2];
+        }
+    }
+    for (uint32_t i = i_lo; i < i_hi; ++i) {
         const uint32_t l = D.first_bin + i;
         const uint32_t f = S.side[l];
         const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
@@ -430,6 +444,11 @@ __global__ void __launch_bounds__(64) k_dec_side_walk(const uint8_t* __restrict_
             pp = wah_skip(pp, nbits);
         }
     }
+    if (S.walk_state) {
+        S.walk_state[0] = pm;
+        S.walk_state[1] = pe;
+        S.walk_state[2] = pp;
+    }
 }
 
 // planes of one flagged line's side channels.  One wave per binary line, row built in LDS.
@@ -438,7 +457,7 @@ __global__ void __launch_bounds__(64) k_dec_side_planes(const uint8_t* __restric
                                                         uint32_t n_bin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* row = reinterpret_cast<uint32_t*>(smem);
-    const uint32_t l = blockIdx.x;
+    const uint32_t l = blockIdx.x + (S.walk_state ? S.bin_lo : 0u);  // ranged: the grid covers [bin_lo, bin_hi) of one block
     if (l >= n_bin) return;
     const uint32_t f = S.side[l];
     const uint32_t lane = lane_id();
@@ -880,13 +899,23 @@ int dot_planes(xsi_hip_ctx* ctx, const DecodePlan& P, const uint32_t* planes, ui
 }
 
 // Planes of every binary line of the parsed blocks, plus the side-channel planes when present.
-int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, DecodedPlanes* out) {
+int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, DecodedPlanes* out, const PartialDecode* part) {
     hipStream_t s = ctx->stream;
     const uint32_t n_bin = P.n_bin;
     const uint32_t stride_w = P.L.y_stride64 * 2u;
-    out->stride_w = stride_w;
-    WS(out->planes, "gt.planes", 4ull * stride_w * (size_t)(n_bin ? n_bin : 1));
-    int rc = decode_planes(ctx, d_file, P, out->planes, stride_w, /*apply_negation=*/0);
+    const bool cont = part && !part->first;  // continuation of a prefix decode: more lines into what the caller keeps
+    if (cont) {
+        if (out->stride_w != stride_w || !out->planes) return set_error(XSI_ERR_ARG, "decode_all_planes: continuation without planes");
+    } else {
+        out->stride_w = stride_w;
+        WS(out->planes, "gt.planes", 4ull * stride_w * (size_t)(n_bin ? n_bin : 1));
+    }
+    // binary lines [bin_lo, bin_hi) are WAH lines [wah_lo, wah_hi) and sparse lines [bin_lo - wah_lo, bin_hi - wah_hi)
+    int rc = part ? decode_planes_partial(ctx, d_file, P, out->planes, stride_w, part->wah_lo, part->wah_hi, part->d_state,
+                                          part->bin_lo - part->wah_lo, part->bin_hi - part->wah_hi, part->d_walk + 3)
+                  : decode_planes(ctx, d_file, P, out->planes, stride_w, /*apply_negation=*/0);
+    P.L.sp_state = nullptr;  // the plan outlives this call (cache entries keep a copy): no dangling range in it
+    P.L.sp_lo = P.L.sp_hi = 0u;
     if (rc) return rc;
     bool side = false, pbwt_weird = false;
     for (auto& b : P.blocks_h) {
@@ -898,30 +927,51 @@ int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, Decod
             pbwt_weird = true;
         }
     }
-    out->has_side = side;
-    WS(out->n_miss, "gt.n_miss", 4ull * n_bin + 64);
-    WS(out->n_eov, "gt.n_eov", 4ull * n_bin + 64);
+    if (part && pbwt_weird) return set_error(XSI_ERR_UNSUPPORTED, "decode_all_planes: ranged decode of a WS_PBWT_WAH block");
+    if (!cont) {
+        out->has_side = side;
+        WS(out->n_miss, "gt.n_miss", 4ull * n_bin + 64);
+        WS(out->n_eov, "gt.n_eov", 4ull * n_bin + 64);
+    }
     if (side) {
         DecSide S{};
         S.stride_w = stride_w;
-        WS(S.side, "gt.side", (size_t)n_bin + 64);
         WS(S.miss_start, "gt.miss_start", 4ull * n_bin + 64);
         WS(S.eov_start, "gt.eov_start", 4ull * n_bin + 64);
         WS(S.phase_start, "gt.phase_start", 4ull * n_bin + 64);
-        WS(S.miss_planes, "gt.dmiss_planes", 4ull * stride_w * (size_t)n_bin);
-        WS(S.eov_planes, "gt.deov_planes", 4ull * stride_w * (size_t)n_bin);
-        WS(S.phase_planes, "gt.dphase_planes", 4ull * stride_w * (size_t)n_bin);
+        if (cont) {
+            S.side = out->side;
+            S.miss_planes = out->miss_planes;
+            S.eov_planes = out->eov_planes;
+            S.phase_planes = out->phase_planes;
+        } else {
+            WS(S.side, "gt.side", (size_t)n_bin + 64);
+            WS(S.miss_planes, "gt.dmiss_planes", 4ull * stride_w * (size_t)n_bin);
+            WS(S.eov_planes, "gt.deov_planes", 4ull * stride_w * (size_t)n_bin);
+            WS(S.phase_planes, "gt.dphase_planes", 4ull * stride_w * (size_t)n_bin);
+        }
         S.n_miss = out->n_miss;
         S.n_eov = out->n_eov;
-        k_dec_side_flags<<<dim3(P.n_blocks), dim3(64), 0, s>>>((const uint8_t*)d_file, P.d_blocks, P.L, S);
-        HIP_TRY(hipGetLastError());
-        k_dec_side_walk<<<dim3(P.n_blocks), dim3(64), 0, s>>>((const uint8_t*)d_file, P.d_blocks, P.L, S);
-        HIP_TRY(hipGetLastError());
-        const uint32_t lds = stride_w * 4u;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_side_planes),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_dec_side_planes<<<dim3(n_bin), dim3(64), lds, s>>>((const uint8_t*)d_file, P.d_blocks, P.L, S, n_bin);
-        HIP_TRY(hipGetLastError());
+        uint32_t lines = n_bin;
+        if (part) {  // the side matrices of the lines this range makes valid, cursors carried in the state
+            S.bin_lo = part->bin_lo;
+            S.bin_hi = part->bin_hi < n_bin ? part->bin_hi : n_bin;
+            S.walk_state = part->d_walk;
+            lines = S.bin_hi > S.bin_lo ? S.bin_hi - S.bin_lo : 0u;
+        }
+        if (!cont) {
+            k_dec_side_flags<<<dim3(P.n_blocks), dim3(64), 0, s>>>((const uint8_t*)d_file, P.d_blocks, P.L, S);
+            HIP_TRY(hipGetLastError());
+        }
+        if (lines) {
+            k_dec_side_walk<<<dim3(P.n_blocks), dim3(64), 0, s>>>((const uint8_t*)d_file, P.d_blocks, P.L, S);
+            HIP_TRY(hipGetLastError());
+            const uint32_t lds = stride_w * 4u;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_side_planes),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_dec_side_planes<<<dim3(lines), dim3(64), lds, s>>>((const uint8_t*)d_file, P.d_blocks, P.L, S, n_bin);
+            HIP_TRY(hipGetLastError());
+        }
         if (pbwt_weird) {  // version-4 files: the missing / end-of-vector lines back into natural order
             uint32_t *d_aw, *d_tmp;
             WS(d_aw, "gt.weird_a", 8ull * P.L.N * (size_t)P.n_blocks);
@@ -929,11 +979,13 @@ int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, Decod
             k_dec_side_unpermute<<<dim3(P.n_blocks), dim3(1024), 0, s>>>(P.d_blocks, P.L, S, d_aw, d_tmp);
             HIP_TRY(hipGetLastError());
         }
-        out->side = S.side;
-        out->miss_planes = S.miss_planes;
-        out->eov_planes = S.eov_planes;
-        out->phase_planes = S.phase_planes;
-    } else {
+        if (!cont) {
+            out->side = S.side;
+            out->miss_planes = S.miss_planes;
+            out->eov_planes = S.eov_planes;
+            out->phase_planes = S.phase_planes;
+        }
+    } else if (!cont) {
         HIP_TRY(hipMemsetAsync(out->n_miss, 0, 4ull * n_bin + 64, s));
         HIP_TRY(hipMemsetAsync(out->n_eov, 0, 4ull * n_bin + 64, s));
         out->side = nullptr;

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -520,8 +521,17 @@ struct xsi_accessor {
         DecodePlan P;
         DecodedPlanes D;
         bool biallelic = false;
+        // Prefix decode: only the first wah_done WAH lines of the block have been through the chain (sparse lines and
+        // side channels are complete); the chain's ranks behind line wah_done are parked in d_state, and a query
+        // further into the block continues from there (accessor_ensure_lines).
+        bool partial = false;
+        uint32_t wah_done = 0;
+        uint32_t* d_state = nullptr;           // inside mem: the chain's parked ranks, then 64 bytes of side-matrix cursors
+        uint64_t* d_walk = nullptr;
+        std::vector<uint32_t> wah_before;      // [n_bin + 1]: WAH lines among the binary lines in front of line i
     };
     std::vector<CachedBlock> cache;
+    uint64_t prefix_decodes = 0, prefix_extensions = 0;
     size_t cache_bytes = 0, cache_budget = 0;
     uint64_t tick = 0, cache_hits = 0, cache_misses = 0;
     // zstd files: every block is inflated on the host into a one-block image (header + block + index)
@@ -631,13 +641,20 @@ static void accessor_evict(xsi_accessor* a, size_t idx) {
 
 // Copy the decoded state of the block that sits in the context workspace into a private
 // allocation and repoint (P, D) at it.  Returns false when the budget / HBM cannot take it.
-static bool accessor_cache_store(xsi_accessor* a, uint64_t block) {
+struct PartialInfo {
+    uint32_t wah_done = 0;
+    const uint32_t* ws_state = nullptr;  // the chain's parked ranks in the context workspace
+    size_t state_bytes = 0;
+    std::vector<uint32_t>* wah_before = nullptr;
+};
+
+static bool accessor_cache_store(xsi_accessor* a, uint64_t block, const PartialInfo* part = nullptr) {
     const size_t n_bin = a->P.n_bin ? a->P.n_bin : 1;
     const size_t plane_b = 4ull * a->D.stride_w * n_bin;
     auto al = [](size_t v) { return (v + 255u) & ~(size_t)255u; };
     const bool side = a->D.has_side;
     const size_t need = al(plane_b) * (side ? 4u : 1u) + al(n_bin) * (side ? 2u : 1u) + al(4 * n_bin + 64) * 4u +
-                        al(sizeof(DecBlock));
+                        al(sizeof(DecBlock)) + (part ? al(part->state_bytes) : 0u);
     if (need > a->cache_budget) return false;
     while (a->cache_bytes + need > a->cache_budget && !a->cache.empty()) {
         size_t lru = 0;
@@ -679,6 +696,13 @@ static bool accessor_cache_store(xsi_accessor* a, uint64_t block) {
         e.D.eov_planes = (uint32_t*)take(a->D.eov_planes, plane_b);
         e.D.phase_planes = (uint32_t*)take(a->D.phase_planes, plane_b);
     }
+    if (part) {
+        e.partial = true;
+        e.wah_done = part->wah_done;
+        e.d_state = (uint32_t*)take(part->ws_state, part->state_bytes);
+        e.d_walk = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(e.d_state) + part->state_bytes - 64u);
+        e.wah_before = *part->wah_before;
+    }
     if (!ok || hipStreamSynchronize(s) != hipSuccess || off > need) {
         (void)hipGetLastError();
         (void)hipFree(mem);
@@ -696,7 +720,61 @@ static bool accessor_cache_store(xsi_accessor* a, uint64_t block) {
     return true;
 }
 
-static int accessor_load_block(xsi_accessor* a, uint64_t block) {
+// WAH lines to have decoded so that every binary line below `need_bin` is valid (0 or beyond the block: all), growing
+// geometrically from what is there so that a scan through a cold block is a handful of extensions, not one per line
+static uint32_t prefix_target(const std::vector<uint32_t>& wah_before, uint32_t n_wah, uint32_t wah_done, uint32_t need_bin) {
+    const uint32_t n_bin = (uint32_t)wah_before.size() - 1u;
+    const uint32_t k_need = (need_bin == 0u || need_bin >= n_bin) ? n_wah : wah_before[need_bin];
+    if (k_need <= wah_done) return wah_done;
+    uint32_t k = wah_done + (wah_done / 2u > 32u ? wah_done / 2u : 32u);
+    if (k < k_need) k = k_need;
+    if (k > n_wah || (uint64_t)k * 10u >= (uint64_t)n_wah * 9u) k = n_wah;  // the last tenth is not worth another launch sequence
+    return k;
+}
+
+// every binary line in front of the WAH line of rank k is valid once k WAH lines have been through the chain
+static uint32_t bin_valid_of(const std::vector<uint32_t>& wah_before, uint32_t n_wah, uint32_t k) {
+    const uint32_t n_bin = (uint32_t)wah_before.size() - 1u;
+    if (k >= n_wah) return n_bin;
+    // smallest i with wah_before[i + 1] > k: the id of the WAH line of rank k
+    return (uint32_t)(std::upper_bound(wah_before.begin() + 1, wah_before.end(), k) - (wah_before.begin() + 1));
+}
+
+// The current block is a prefix-decoded cache entry and the caller is about to read binary lines below need_bin (0: all):
+// run the chain on from where it stopped (the reference's seek does the same replay, one line at a time, on the host:
+// accessor_internals_new.hpp:154-196).
+static int accessor_ensure_lines(xsi_accessor* a, uint32_t need_bin) {
+    if (a->cur_block < 0 || a->cur_in_workspace) return XSI_OK;
+    xsi_accessor::CachedBlock* e = nullptr;
+    for (auto& c : a->cache)
+        if (c.block == (uint64_t)a->cur_block) e = &c;
+    if (!e || !e->partial) return XSI_OK;
+    const uint32_t n_wah = e->P.n_wah;
+    const uint32_t target = prefix_target(e->wah_before, n_wah, e->wah_done, need_bin);
+    if (target <= e->wah_done) return XSI_OK;
+    const uint8_t* img;
+    uint64_t len, blk;
+    int rc = accessor_block_image(a, (uint64_t)a->cur_block, &img, &len, &blk);
+    if (rc) return rc;
+    DecodePlan Pt;
+    rc = decode_prepare(a->ctx, img, len, blk, 1, &Pt);
+    if (rc) return rc;
+    Pt.L.ones = e->P.L.ones;  // the expansion writes the new lines' counts next to the ones already there
+    PartialDecode pd{e->wah_done, target, e->d_state, false, bin_valid_of(e->wah_before, n_wah, e->wah_done),
+                     bin_valid_of(e->wah_before, n_wah, target), e->d_walk};
+    DecodedPlanes Dv = e->D;
+    rc = decode_all_planes(a->ctx, img, Pt, &Dv, &pd);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    e->wah_done = target;
+    if (target == n_wah) e->partial = false;
+    ++a->prefix_extensions;
+    return XSI_OK;
+}
+
+// need_bin: the binary lines below it are what the caller reads first (0: the whole block); a cold block is decoded up
+// to there (prefix decode) when the ranged chain takes it and the cache can hold it
+static int accessor_load_block(xsi_accessor* a, uint64_t block, uint32_t need_bin = 0) {
     for (auto& e : a->cache)
         if (e.block == block) {
             e.last_use = ++a->tick;
@@ -707,9 +785,29 @@ static int accessor_load_block(xsi_accessor* a, uint64_t block) {
             a->cur_in_workspace = false;
             a->win_n = 0;
             ++a->cache_hits;
-            return XSI_OK;
+            return e.partial ? accessor_ensure_lines(a, need_bin) : XSI_OK;
         }
     ++a->cache_misses;
+    // XSI_ACCESSOR_PROF=1: wall clock of the pieces of a first touch (synchronising between them) on stderr
+    const bool prof = getenv("XSI_ACCESSOR_PROF") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prof = prof ? now() : 0.0;
+    auto lap = [&](const char* what) {
+        if (!prof) return;
+        (void)hipStreamSynchronize(a->ctx->stream);
+        const double t = now();
+        fprintf(stderr, "[xsi accessor prof] block %llu %-28s %8.3f ms\n", (unsigned long long)block, what, t - t_prof);
+        stage_collect(a->ctx);
+        for (int i = 0; i < XSI_STAGE_COUNT; ++i)
+            if (a->ctx->stage_n[i]) {
+                fprintf(stderr, "[xsi accessor prof]     stage %-20s %8.3f ms (%llu)\n", xsi_hip_stage_name(i), a->ctx->stage_ms[i],
+                        (unsigned long long)a->ctx->stage_n[i]);
+                a->ctx->stage_ms[i] = 0;
+                a->ctx->stage_n[i] = 0;
+            }
+        t_prof = now();
+    };
+    if (prof) a->ctx->timing = true;
     const uint8_t* img;
     uint64_t len, blk;
     int rc = accessor_block_image(a, block, &img, &len, &blk);
@@ -717,13 +815,59 @@ static int accessor_load_block(xsi_accessor* a, uint64_t block) {
     a->cur_block = -1;
     rc = decode_prepare(a->ctx, img, len, blk, 1, &a->P);
     if (rc) return rc;
-    rc = decode_all_planes(a->ctx, img, a->P, &a->D);
-    if (rc) return rc;
-    a->biallelic = a->P.n_bin == a->P.n_bcf;
-    a->cur_in_workspace = !accessor_cache_store(a, block);
-    a->cur_block = (int64_t)block;
+    lap("decode_prepare");
     a->cnt_block = -1;
     a->win_n = 0;
+    const bool want_prefix = need_bin && need_bin < a->P.n_bin && a->P.n_wah >= 64u && decode_partial_supported(a->P) &&
+                             !getenv("XSI_ACCESSOR_FULL_DECODE");
+    if (want_prefix) {
+        hipStream_t s = a->ctx->stream;
+        std::vector<uint8_t> kind(a->P.n_bin);
+        HIP_TRY(hipMemcpyAsync(kind.data(), a->P.L.kind, a->P.n_bin, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<uint32_t> wah_before(a->P.n_bin + 1u);
+        for (uint32_t i = 0; i < a->P.n_bin; ++i) wah_before[i + 1u] = wah_before[i] + ((kind[i] & KIND_WAH) ? 1u : 0u);
+        const uint32_t target = prefix_target(wah_before, a->P.n_wah, 0u, need_bin);
+        if (target < a->P.n_wah) {
+            const size_t state_bytes = 4ull * (size_t)rank_decode_state_words(a->P.L.N, 1u) + 64u;  // + the side matrices' cursors
+            void* st;
+            rc = ws_ensure(a->ctx, "acc.rank_state", state_bytes, &st);
+            if (rc) return rc;
+            uint64_t* const d_walk = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(st) + state_bytes - 64u);
+            PartialDecode pd{0u, target, static_cast<uint32_t*>(st), true, 0u, bin_valid_of(wah_before, a->P.n_wah, target), d_walk};
+            rc = decode_all_planes(a->ctx, img, a->P, &a->D, &pd);
+            if (rc) return rc;
+            lap("prefix decode (planes + side)");
+            a->biallelic = a->P.n_bin == a->P.n_bcf;
+            PartialInfo pi;
+            pi.wah_done = target;
+            pi.ws_state = static_cast<const uint32_t*>(st);
+            pi.state_bytes = state_bytes;
+            pi.wah_before = &wah_before;
+            if (accessor_cache_store(a, block, &pi)) {
+                lap("cache store (malloc + copy)");
+                a->cur_in_workspace = false;
+                a->cur_block = (int64_t)block;
+                ++a->prefix_decodes;
+                return XSI_OK;
+            }
+            // the cache cannot hold the block: finish it in the workspace (a->P still describes this decode)
+            PartialDecode rest{target, a->P.n_wah, static_cast<uint32_t*>(st), false, bin_valid_of(wah_before, a->P.n_wah, target),
+                               a->P.n_bin, d_walk};
+            rc = decode_all_planes(a->ctx, img, a->P, &a->D, &rest);
+            if (rc) return rc;
+            a->cur_in_workspace = true;
+            a->cur_block = (int64_t)block;
+            return XSI_OK;
+        }
+    }
+    rc = decode_all_planes(a->ctx, img, a->P, &a->D);
+    if (rc) return rc;
+    lap("full decode (planes + side)");
+    a->biallelic = a->P.n_bin == a->P.n_bcf;
+    a->cur_in_workspace = !accessor_cache_store(a, block);
+    lap("cache store (malloc + copy)");
+    a->cur_block = (int64_t)block;
     return XSI_OK;
 }
 
@@ -964,6 +1108,13 @@ int xsi_accessor_cache_stats(const xsi_accessor* a, uint64_t* blocks, uint64_t* 
     return XSI_OK;
 }
 
+int xsi_accessor_prefix_stats(const xsi_accessor* a, uint64_t* prefix_decodes, uint64_t* extensions) {
+    if (!a) return set_error(XSI_ERR_ARG, "prefix_stats: null accessor");
+    if (prefix_decodes) *prefix_decodes = a->prefix_decodes;
+    if (extensions) *extensions = a->prefix_extensions;
+    return XSI_OK;
+}
+
 // the line's values in the accessor's pinned window (valid until the next call on the accessor) and their number
 static int64_t accessor_line_view(xsi_accessor* a, uint32_t n_alleles, uint64_t position, const int32_t** view);
 
@@ -1046,7 +1197,7 @@ static int64_t accessor_line_view(xsi_accessor* a, uint32_t n_alleles, uint64_t 
     const uint64_t block = (position & 0xFFFFFFFFull) >> BM_BLOCK_BITS;
     const uint32_t offset = (uint32_t)(position & ((1u << BM_BLOCK_BITS) - 1u));
     if (a->cur_block < 0 || (uint64_t)a->cur_block != block) {
-        int rc = accessor_load_block(a, block);
+        int rc = accessor_load_block(a, block, offset + (n_alleles - 1u));
         if (rc) return rc;
     }
     if (offset + (n_alleles - 1) > a->P.n_bin)
@@ -1054,6 +1205,10 @@ static int64_t accessor_line_view(xsi_accessor* a, uint32_t n_alleles, uint64_t 
                          n_alleles - 1, a->P.n_bin, (unsigned long long)block);
     const uint32_t N = a->P.L.N;
     uint32_t row = 0;
+    {   // a prefix-decoded block: the chain runs on to the lines this call reads (no-op for a complete block)
+        int rc = accessor_ensure_lines(a, offset + (n_alleles - 1u));
+        if (rc) return rc;
+    }
     if (a->biallelic && n_alleles == 2) {
         if (!(a->win_n && a->win_in_rows && offset >= a->win_first && offset < a->win_first + a->win_n)) {
             // window length follows the access pattern: a request that continues the previous window
@@ -1064,7 +1219,9 @@ static int64_t accessor_line_view(xsi_accessor* a, uint32_t n_alleles, uint64_t 
             a->win_block = (int64_t)block;
             uint32_t n = a->P.n_bin - offset;
             if (n > a->win_target) n = a->win_target;
-            int rc = accessor_compose(a, offset, n, 2);
+            int rc = accessor_ensure_lines(a, offset + n);
+            if (rc) return rc;
+            rc = accessor_compose(a, offset, n, 2);
             if (rc) return rc;
             a->win_first = offset;
             a->win_n = n;
@@ -1144,9 +1301,10 @@ int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint
                 // a block that lives in the context workspace (cache too small) is overwritten by the next decode:
                 // the composes that read it must have finished
                 if (a->cur_in_workspace) HIP_TRY(hipStreamSynchronize(s));
-                int rc = accessor_load_block(a, block);
+                int rc = accessor_load_block(a, block, 0);
                 if (rc) return rc;
             }
+            uint32_t need = 0;
             for (uint32_t g = g0; g < g1; ++g) {
                 const uint64_t q = c0 + order[g];
                 const uint32_t offset = (uint32_t)(positions[q] & ((1u << BM_BLOCK_BITS) - 1u));
@@ -1157,8 +1315,11 @@ int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint
                 fb[g] = offset;
                 na[g] = n_alleles[q];
                 oi[g] = order[g];
+                if (offset + (n_alleles[q] - 1u) > need) need = offset + (n_alleles[q] - 1u);
             }
-            int rc = compose_lines(a->ctx, a->P, a->D, fb + g0, na + g0, g1 - g0, d_dst, d_stride, ng, nullptr, 0, oi + g0);
+            int rc = accessor_ensure_lines(a, need);
+            if (rc) return rc;
+            rc = compose_lines(a->ctx, a->P, a->D, fb + g0, na + g0, g1 - g0, d_dst, d_stride, ng, nullptr, 0, oi + g0);
             if (rc) return rc;
             g0 = g1;
         }
@@ -1212,12 +1373,16 @@ int64_t xsi_accessor_fill_selected_genotypes(xsi_accessor* a, int32_t* h_gt, uin
     const uint64_t block = (position & 0xFFFFFFFFull) >> BM_BLOCK_BITS;
     const uint32_t offset = (uint32_t)(position & ((1u << BM_BLOCK_BITS) - 1u));
     if (a->cur_block < 0 || (uint64_t)a->cur_block != block) {
-        int rc = accessor_load_block(a, block);
+        int rc = accessor_load_block(a, block, offset + (n_alleles - 1u));
         if (rc) return rc;
     }
     if (offset + (n_alleles - 1) > a->P.n_bin)
         return set_error(XSI_ERR_ARG, "position offset %u (+%u alleles) beyond the %u binary lines of block %llu", offset,
                          n_alleles - 1, a->P.n_bin, (unsigned long long)block);
+    {
+        int rc = accessor_ensure_lines(a, offset + (n_alleles - 1u));
+        if (rc) return rc;
+    }
     hipStream_t s = a->ctx->stream;
     // compose the full line on the device (no copy to the host), gather the selected samples there
     if ((uint64_t)n_alleles > a->counts_cap) {
@@ -1353,9 +1518,13 @@ int xsi_accessor_get_internal_access(xsi_accessor* a, uint32_t n_alleles, uint64
     info->n_a = (uint32_t)a->hap_samples;
     if (n_alleles < 2) return XSI_OK;  // the reference returns the bare header for n_alleles == 0
     hipStream_t s = a->ctx->stream;
-    // the arrangement first: it needs the decoded lines of the block (cache or workspace)
+    // the arrangement first: it needs the decoded lines of the block (cache or workspace) up to the record's last line
     if (a->cur_block < 0 || (uint64_t)a->cur_block != block) {
-        int rc = accessor_load_block(a, block);
+        int rc = accessor_load_block(a, block, offset + (n_alleles - 1u));
+        if (rc) return rc;
+    }
+    {
+        int rc = accessor_ensure_lines(a, offset + (n_alleles - 1u));
         if (rc) return rc;
     }
     const uint32_t n_lines = n_alleles - 1u;

@@ -2745,14 +2745,20 @@ __global__ void __launch_bounds__(64) k_sparse_walk(const uint8_t* __restrict__ 
     const uint32_t lane = lane_id();
     uint64_t pos = 0;  // in uint16 units
     uint32_t k = 0;
+    uint32_t k_end = D.n_sparse;
+    if (L.sp_state) {  // ranged walk (one block)
+        k = L.sp_lo < D.n_sparse ? L.sp_lo : D.n_sparse;
+        k_end = L.sp_hi < D.n_sparse ? L.sp_hi : D.n_sparse;
+        if (k) pos = L.sp_state[0];
+    }
     const uint64_t sm_at = D.gt_off + D.off_sparse;
     const uint64_t sm_units = sm_at < L.file_len ? (L.file_len - sm_at) / 2u : 0u;  // never read past the image
-    while (k < D.n_sparse) {
+    while (k < k_end) {
         const uint64_t t0 = pos;
         for (uint32_t i = lane; i < TILE; i += 64u) s_tile[i] = (t0 + i < sm_units) ? sm[t0 + i] : (uint16_t)0;
         __syncthreads();
         if (lane == 0) {
-            while (k < D.n_sparse && pos + units <= t0 + TILE) {
+            while (k < k_end && pos + units <= t0 + TILE) {
                 uint32_t num = s_tile[pos - t0];
                 if (units == 2u) num |= (uint32_t)s_tile[pos - t0 + 1] << 16;
                 num &= (units == 2u) ? 0x7FFFFFFFu : 0x7FFFu;
@@ -2766,6 +2772,7 @@ __global__ void __launch_bounds__(64) k_sparse_walk(const uint8_t* __restrict__ 
         k = __shfl(k, 0, 64);
         __syncthreads();
     }
+    if (L.sp_state && lane == 0) L.sp_state[0] = pos;
 }
 
 hipError_t launch_sparse_walk(hipStream_t s, const uint8_t* file, const DecBlock* blocks, uint32_t n_blocks,
@@ -3192,7 +3199,7 @@ __global__ void __launch_bounds__(T) k_sparse_fill(const uint8_t* __restrict__ f
                                                     int apply_negation) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* row = reinterpret_cast<uint32_t*>(smem);
-    const uint32_t k = blockIdx.x;
+    const uint32_t k = blockIdx.x + (L.sp_state ? L.sp_lo : 0u);
     if (k >= d_totals[2] || d_totals[3]) return;
     const uint32_t l = L.sparse_lines[k];
     const DecBlock& D = blocks[L.line_block[l]];
@@ -3241,7 +3248,7 @@ __global__ void __launch_bounds__(256) k_sparse_fill_direct(const uint8_t* __res
                                                             DecLines L, const uint32_t* __restrict__ d_totals,
                                                             uint32_t* __restrict__ out_rows, uint32_t out_stride_w,
                                                             int apply_negation) {
-    const uint32_t k = blockIdx.x;
+    const uint32_t k = blockIdx.x + (L.sp_state ? L.sp_lo : 0u);
     if (k >= d_totals[2] || d_totals[3]) return;
     const uint32_t l = L.sparse_lines[k];
     const DecBlock& D = blocks[L.line_block[l]];

@@ -131,6 +131,11 @@ struct DecLines {
     uint64_t* tile_base;   // [block][max_tiles] groups before the tile
     uint32_t max_tiles;
     uint64_t file_len;     // bytes of the file image (bounds every read)
+    // ranged sparse lists (the accessor's prefix decode, one block): the sparse lines of rank [sp_lo, sp_hi) only; the
+    // walk's cursor behind rank sp_hi - 1 is left in sp_state[0] and picked up from there when sp_lo > 0.
+    // sp_state == nullptr: every sparse line (everything else).
+    uint32_t sp_lo, sp_hi;
+    uint64_t* sp_state;
 };
 
 hipError_t launch_parse_blocks(hipStream_t s, const uint8_t* file, uint64_t file_len, uint64_t indices_offset,
