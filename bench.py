@@ -701,7 +701,7 @@ def run_roundtrip(args, emit=True):
         ms_per_step = dt / steps * 1e3
         value = cells_job / (dt / steps)
         # Dominant kernel: the slower of the two PBWT chains.  Algorithmic bytes of its launch
-        # (DESIGN.md §6): encode = packed input read + .xsi written = cells/8 + xsi_bytes;
+        # (DESIGN.md §7): encode = packed input read + .xsi written = cells/8 + xsi_bytes;
         # the decode launch mirrors it.  One launch processes the whole batch of this rank.
         enc_ms, enc_n = timing.get("chain_encode", (0.0, 0))
         dec_ms, dec_n = timing.get("chain_decode", (0.0, 0))

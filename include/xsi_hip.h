@@ -351,7 +351,7 @@ int xsi_writer_append(xsi_writer* w, const int32_t* h_gt, uint32_t ngt, uint32_t
  * (room for 2 * n_samples int32 values; NULL on error) for the caller to fill - e.g. as the destination array of
  * bcf_get_genotypes, which GtCompressorStream otherwise fills and hands to append - and xsi_writer_commit_row
  * appends it.  One buffer is outstanding at a time.  The per-line memcpy of xsi_writer_append is what bounds the
- * file-level write rate on one host core (DESIGN.md section 6). */
+ * file-level write rate on one host core (DESIGN.md section 7). */
 int32_t* xsi_writer_row_buffer(xsi_writer* w);
 int xsi_writer_commit_row(xsi_writer* w, uint32_t ngt, uint32_t n_allele);
 /* XsiFactoryInterface::finalize_file(max_ploidy); max_ploidy = 0 -> use the maximum seen. */

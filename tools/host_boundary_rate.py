@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive rate of the file-level boundary (host int32 rows in / out), for DESIGN.md §6.
+"""PCIe-inclusive rate of the file-level boundary (host int32 rows in / out), for DESIGN.md §7.
 
 xsi_writer_append takes one host int32 row per BCF line (XsiFactoryInterface::append) and
 xsi_accessor_fill_genotype_array returns one (Accessor::fill_genotype_array); both cross PCIe with

@@ -149,7 +149,7 @@ def main():
             rows, counts = G.decode_gt(got, nal)
             ok2 = all(np.array_equal(rows[i][:len(lines[i][0])], lines[i][0]) for i in range(n_lines))
             # the same lines as a WS_PBWT_WAH file (version-4 missing-data strategy, written by the oracle): decode only;
-            # not with fully haploid lines (refused, DESIGN.md section 9)
+            # not with fully haploid lines (refused, DESIGN.md section 13)
             if ok2 and (kw["missing"] or kw["eov"]) and all(len(g) == 2 * n for g, _ in lines):
                 ref_pw = oracle.encode_file(lines, n, block_len=block_len, mac_thr=thr, default_phased=dp, wah_encode_missing=2)
                 rows_pw, _ = G.decode_gt(ref_pw, nal)
