@@ -344,6 +344,8 @@ struct RankEncMultiArgs {
     uint32_t prof;          // XSI_MULTI_PROF: phase times of workgroup 0 into sync[2..]
     uint32_t* xcc_ids;      // [group][8]: 1 + XCC_ID of each member (handshake at the start of the launch)
     uint64_t timeout_ticks;
+    uint32_t wave_flags;    // every wave flags its own list (8 bytes: seq << 32 | length) as soon as its stores have drained,
+                            // and starts on the lists it applies without waiting for the rest of its workgroup
 };
 
 __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* __restrict__ eblocks, RankEncMultiArgs A) {
@@ -417,6 +419,37 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
     auto exchange = [&](uint32_t rank, uint32_t seq, bool dense, uint32_t& Zout) -> bool {
         const uint32_t par = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seq & 1u));
         prof(0);  // main phase + publish
+        uint32_t cnt_l = 0;
+        if (A.wave_flags) {
+            // Per-wave hand-off (round 4): this wave's list is complete in L2 (publish waited for its stores), so it is
+            // flagged at once - 8 bytes, sequence number and length - and the lists this wave applies, list w of every
+            // member, are written by the waves with the same place in their workgroups' issue order: the waves that
+            // finish their main phase early (the arbiter serves the oldest wave first) apply their lists while the late
+            // ones are still gathering, instead of waiting for them at a workgroup barrier in front of a flag record.
+            // 357.5 -> 345.7 ms over the configs[3] shard (same build); the wait moves behind the lists (the barrier in
+            // front of the slice scan), the flag record's round trip is gone.  Dealing the 16 S lists out in the order
+            // they are published, so that every wave holds early and late lists and applies them batch by batch as they
+            // arrive, measured 441 ms: every batch pays the lists' round trip to L2 again (apply 60 -> 130 ms).
+            const uint32_t my_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)wtot[32u + w]);
+            if (lane == 0u) {
+                u32x2 fl;
+                fl[0] = my_len;
+                fl[1] = seq;
+                __builtin_amdgcn_raw_buffer_store_b64(fl, rs_lflags, w * 8u, (par * A.S + member) * 128u, 0);
+            }
+            const uint32_t ml = lane < A.S ? lane : 0u;
+            uint32_t spins = 0;
+            t_start = 0;
+            for (;;) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_lflags, ml * 128u + w * 8u, par * A.S * 128u, 16);
+                if (__builtin_amdgcn_ballot_w64(v[1] != seq) == 0ull) {
+                    cnt_l = lane < A.S ? v[0] : 0u;
+                    break;
+                }
+                if (give_up(spins)) return false;
+                __builtin_amdgcn_s_sleep(0);
+            }
+        } else {
         lds_barrier();  // every wave's list stores have been waited for (publish), its length is in wtot[32 + wave]
         if (w == 0u && lane < 6u) {
             v4u rec;
@@ -430,7 +463,6 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
         // same stretch of its member's haplotypes, so the 16 waves get lists of about equal length; S consecutive
         // lists = eight waves of one member measured 8 ms slower over the configs[3] shard: the waves of a workgroup
         // finish their main phase in issue order and the late ones' lists were also the long-waited ones)
-        uint32_t cnt_l = 0;
         {
             const uint32_t ml = lane < A.S ? lane : 0u, wl = w, rq = wl / 3u, rc = wl - 3u * rq;  // list w of member `lane`
             uint32_t spins = 0;
@@ -444,6 +476,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                 if (give_up(spins)) return false;
                 __builtin_amdgcn_s_sleep(0);  // (s_sleep 1 between polls: 4 ms slower over the configs[3] shard)
             }
+        }
         }
         prof(1);  // barrier + wait for the lists
         // ---- A: all lists, my slice's ranks only
@@ -529,6 +562,8 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
             ent[1] = pre0;
             ent[2] = v.y;
             ent[3] = pre0 + (uint32_t)__popc(v.x);
+            // (whole table entries travel: 12-byte {64 bits, prefix} records - a quarter fewer bytes through L2 - measured
+            // slower, table copy 43.4 -> 49.7 ms over the configs[3] shard: 12-byte accesses run below the 16-byte rate)
             __builtin_amdgcn_raw_buffer_store_b128(ent, rs_slices, tid_here * 16u, (par * A.S + member) * 16384u, 0);
             row_words = v;
         }
@@ -770,6 +805,7 @@ static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* b
     A.slices = reinterpret_cast<v4u*>(L.chain_slices);
     A.test_desert = getenv("XSI_MULTI_TEST_DESERT") ? 1u : 0u;
     A.prof = getenv("XSI_MULTI_PROF") ? 1u : 0u;
+    A.wave_flags = getenv("XSI_MULTI_RECORD_FLAGS") ? 0u : 1u;  // (0: the workgroup-wide flag record of round 3, testing)
     A.xcc_ids = L.chain_sync + CHAIN_SYNC_WORDS + CHAIN_LISTFLAG_WORDS + CHAIN_SLICEFLAG_WORDS;
     // wall_clock64 ticks at 100 MHz; a healthy exchange takes microseconds
     const char* tmo = getenv("XSI_MULTI_TIMEOUT_MS");
