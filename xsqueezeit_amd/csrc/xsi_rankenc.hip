@@ -348,6 +348,7 @@ struct RankEncMultiArgs {
                             // and starts on the lists it applies without waiting for the rest of its workgroup
 };
 
+template <bool WAVE_FLAGS>
 __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* __restrict__ eblocks, RankEncMultiArgs A) {
     constexpr uint32_t T = 1024, W = 16;
     constexpr int E = 64, G = 8, SMAX = 8;
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
         const uint32_t par = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seq & 1u));
         prof(0);  // main phase + publish
         uint32_t cnt_l = 0;
-        if (A.wave_flags) {
+        if constexpr (WAVE_FLAGS) {
             // Per-wave hand-off (round 4): this wave's list is complete in L2 (publish waited for its stores), so it is
             // flagged at once - 8 bytes, sequence number and length - and the lists this wave applies, list w of every
             // member, are written by the waves with the same place in their workgroups' issue order: the waves that
@@ -813,9 +814,10 @@ static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* b
     hipError_t e = hipMemsetAsync(L.chain_sync, 0, 4ull * CHAIN_SYNC_TOTAL_WORDS, s);
     if (e != hipSuccess) return e;
     const uint32_t lds = A.S * 16384u + 8192u + 256u + 16u * 128u * 4u;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_rank_enc_multi), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = A.wave_flags ? &k_chain_rank_enc_multi<true> : &k_chain_rank_enc_multi<false>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_chain_rank_enc_multi<<<dim3(8u * A.gpx * A.S), dim3(1024), lds, s>>>(blocks, A);
+    kern<<<dim3(8u * A.gpx * A.S), dim3(1024), lds, s>>>(blocks, A);
     return hipGetLastError();
 }
 
