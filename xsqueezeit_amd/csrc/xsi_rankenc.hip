@@ -348,7 +348,7 @@ struct RankEncMultiArgs {
                             // and starts on the lists it applies without waiting for the rest of its workgroup
 };
 
-template <bool WAVE_FLAGS>
+template <bool WAVE_FLAGS, bool PROF>
 __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* __restrict__ eblocks, RankEncMultiArgs A) {
     constexpr uint32_t T = 1024, W = 16;
     constexpr int E = 64, G = 8, SMAX = 8;
@@ -409,6 +409,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
     // XSI_MULTI_PROF: wave 0 of workgroup 0 adds the 100 MHz ticks of every phase to sync[2 + 2 i] (64-bit)
     uint64_t t_prof = 0;
     auto prof = [&](uint32_t i) {
+        if constexpr (!PROF) return;  // (the phase clocks are compiled out of the production instantiations)
         if (A.prof && blockIdx.x == 0 && w == 0u) {
             const uint64_t now = wall_clock64();
             if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<uint64_t*>(A.sync + 2u) + i, now - t_prof, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -814,7 +815,8 @@ static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* b
     hipError_t e = hipMemsetAsync(L.chain_sync, 0, 4ull * CHAIN_SYNC_TOTAL_WORDS, s);
     if (e != hipSuccess) return e;
     const uint32_t lds = A.S * 16384u + 8192u + 256u + 16u * 128u * 4u;
-    auto kern = A.wave_flags ? &k_chain_rank_enc_multi<true> : &k_chain_rank_enc_multi<false>;
+    auto kern = A.prof ? (A.wave_flags ? &k_chain_rank_enc_multi<true, true> : &k_chain_rank_enc_multi<false, true>)
+                       : (A.wave_flags ? &k_chain_rank_enc_multi<true, false> : &k_chain_rank_enc_multi<false, false>);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     kern<<<dim3(8u * A.gpx * A.S), dim3(1024), lds, s>>>(blocks, A);
