@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
 // the same XCD, and share the row through that XCD's L2 (see the kernel's first lines).
 __device__ unsigned long long g_big_prof[4];  // XSI_BIG_PROF: 100 MHz ticks of workgroup 0, wave 0: main, barrier, row to LDS + stores + barrier
 
-template <int E, int RP>
+template <int E, int RP, bool PROF = false>
 __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
     constexpr int T = 1024, W = 16, G = 8;  // G: gathers in flight per wave
     static_assert(E % G == 0, "E must be a multiple of the gather group");
@@ -360,9 +360,10 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
     store_row();
     uint32_t line = A.wah_lines[wah_first], Z = A.wah_z[wah_first];
     __syncthreads();
-    const bool prof_on = A.big_prof && blockIdx.x == 0 && w == 0u;
+    const bool prof_on = PROF && A.big_prof && blockIdx.x == 0 && w == 0u;  // (compiled out of the production instantiations)
     uint64_t t_prof = prof_on ? wall_clock64() : 0;
     auto prof = [&](int i) {
+        if constexpr (!PROF) return;
         if (prof_on) {
             const uint64_t now = wall_clock64();
             if (lane == 0) atomicAdd(&g_big_prof[i], (unsigned long long)(now - t_prof));
@@ -701,7 +702,13 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) 
         A.big_splits = splits_of(EE);                                                                        \
         A.big_n_blocks = n_blocks;                                                                           \
         A.big_prof = getenv("XSI_BIG_PROF") ? 1u : 0u;                                                       \
-        k_chain_decode_rank_big<EE, RR><<<dim3(splits_of(EE) * ((n_blocks + 7u) & ~7u)), dim3(1024), lds, s>>>(A); \
+        if (A.big_prof) {                                                                                    \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank_big<EE, RR, true>),   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+            if (e != hipSuccess) return e;                                                                   \
+            k_chain_decode_rank_big<EE, RR, true><<<dim3(splits_of(EE) * ((n_blocks + 7u) & ~7u)), dim3(1024), lds, s>>>(A); \
+        } else                                                                                               \
+            k_chain_decode_rank_big<EE, RR><<<dim3(splits_of(EE) * ((n_blocks + 7u) & ~7u)), dim3(1024), lds, s>>>(A); \
         if (A.big_prof) {                                                                                    \
             unsigned long long pr[4] = {0, 0, 0, 0};                                                         \
             (void)hipStreamSynchronize(s);                                                                   \
