@@ -348,6 +348,97 @@ def test_allele_counts_without_expansion(tmp_path):
     L.xsi_accessor_close(a)
 
 
+@pytest.mark.parametrize("zstd", [False, True])
+def test_prefix_decode_in_the_accessor(tmp_path, zstd):
+    """Round 4: a cold query decodes its block only up to the requested line (the chain over the WAH lines in front of
+    it, the sparse lists and side matrices up to it) and later queries further in continue from the parked state -
+    the reference's seek replays the same prefix on the host (accessor_internals_new.hpp:154-196).  25 000 samples
+    (50 000 haplotypes: the ranged chain's domain), multi-allelic + missing + end-of-vector + phase lines, plain and
+    zstd file (a continuation inflates the block again); queries: late in a block first?  No - early first, then
+    further in (continuation), then backwards (already decoded), then the other block, then a batch across both;
+    rows and allele counts against the oracle's reader and the source."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    if zstd:
+        try:
+            ctypes.CDLL("libzstd.so.1")
+        except OSError:
+            pytest.skip("no libzstd.so.1 on this box")
+    rng = np.random.default_rng(4100 + int(zstd))
+    n, n_lines, block_len = 25000, 400, 200
+    lines = _random_lines(rng, n, n_lines, multi=True, missing=True, eov=True, phase=True)
+    dp = oracle.default_phased_of(lines, n)
+    names = ["s%d" % i for i in range(n)]
+    path = str(tmp_path / "p.xsi").encode()
+    p = G.params(n, block_len, 50, dp)
+    p.zstd_level = 3 if zstd else 0
+    w = ctypes.c_void_p()
+    arr = (ctypes.c_char_p * n)(*[x.encode() for x in names])
+    binding.check(L.xsi_writer_open(ctypes.byref(w), G.ctx().handle, path, ctypes.byref(p), arr))
+    for gt, na in lines:
+        gt = np.ascontiguousarray(gt, dtype=np.int32)
+        binding.check(L.xsi_writer_append(w, gt.ctypes.data, gt.size, na))
+    binding.check(L.xsi_writer_finalize(w, 0))
+    L.xsi_writer_close(w)
+    plain = oracle.encode_file(lines, n, block_len=block_len, mac_thr=50, default_phased=dp, sample_names=names)
+    if not zstd:
+        assert open(path, "rb").read() == plain
+    rd = oracle.Reader(plain)
+    bms, block, off = [], 0, 0
+    for i, (_, na) in enumerate(lines):
+        if i and i % block_len == 0:
+            block, off = block + 1, 0
+        bms.append((block << 15) | off)
+        off += na - 1
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, path))
+    buf = np.zeros(2 * n, dtype=np.int32)
+    cnt = np.zeros(8, dtype=np.uint64)
+    pd, ext = ctypes.c_uint64(0), ctypes.c_uint64(0)
+
+    def check(i):
+        na = lines[i][1]
+        r = L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, na, bms[i])
+        assert r == len(lines[i][0]), L.xsi_hip_last_error()
+        egt, ecnt = rd.fill_genotype_array(na, bms[i])
+        assert np.array_equal(buf[:r], lines[i][0]), "line %d vs source" % i
+        assert np.array_equal(buf[:r], egt), "line %d vs oracle reader" % i
+        binding.check(L.xsi_accessor_allele_counts(a, cnt.ctypes.data, na))
+        assert np.array_equal(cnt[:na], ecnt), "allele counts of line %d" % i
+
+    check(7)                                   # cold block 0: prefix up to line 7
+    binding.check(L.xsi_accessor_prefix_stats(a, ctypes.byref(pd), ctypes.byref(ext)))
+    assert pd.value == 1 and ext.value == 0
+    check(8)                                   # inside the rounded-up prefix or a first continuation
+    check(60)                                  # continuation
+    check(3)                                   # backwards: already there
+    check(150)                                 # continuation
+    check(199)                                 # to the block's end
+    binding.check(L.xsi_accessor_prefix_stats(a, ctypes.byref(pd), ctypes.byref(ext)))
+    assert ext.value >= 2
+    check(399)                                 # cold block 1, last line: (nearly) the whole block
+    check(200)
+    for i in [int(x) for x in rng.integers(0, n_lines, 12)]:
+        check(i)
+    # a fresh accessor, one batch over both cold blocks, unordered
+    L.xsi_accessor_close(a)
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, path))
+    q = np.asarray([250, 12, 13, 390, 101, 12, 201], dtype=np.int64)
+    q_na = np.asarray([lines[i][1] for i in q], dtype=np.uint32)
+    q_bm = np.asarray([bms[i] for i in q], dtype=np.uint64)
+    rows2 = np.full((len(q), 2 * n), -9, dtype=np.int32)
+    ngt2 = np.zeros(len(q), dtype=np.uint32)
+    tot = L.xsi_accessor_get_genotypes_batch(a, len(q), q_na.ctypes.data, q_bm.ctypes.data, rows2.ctypes.data, 2 * n, ngt2.ctypes.data)
+    assert tot == int(sum(len(lines[i][0]) for i in q)), L.xsi_hip_last_error()
+    for k, i in enumerate(q):
+        assert np.array_equal(rows2[k, :ngt2[k]], lines[i][0]), "batched query %d (line %d)" % (k, i)
+    binding.check(L.xsi_accessor_prefix_stats(a, ctypes.byref(pd), ctypes.byref(ext)))
+    assert pd.value >= 1
+    L.xsi_accessor_close(a)
+
+
 def test_zstd_layer_roundtrip(tmp_path):
     """--zstd files (BlockWithZstdCompressor, interfaces.hpp:288-315): u64 sizes + one zstd frame per
     block.  The inflated blocks equal the plain file's blocks byte for byte, and the accessor reads

@@ -1297,14 +1297,19 @@ int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint
             const uint64_t block = (positions[c0 + order[g0]] & 0xFFFFFFFFull) >> BM_BLOCK_BITS;
             uint32_t g1 = g0;
             while (g1 < m && ((positions[c0 + order[g1]] & 0xFFFFFFFFull) >> BM_BLOCK_BITS) == block) ++g1;
+            uint32_t need = 0;  // binary lines of this block the group reads: what a cold block is decoded up to
+            for (uint32_t g = g0; g < g1; ++g) {
+                const uint64_t q = c0 + order[g];
+                const uint32_t end = (uint32_t)(positions[q] & ((1u << BM_BLOCK_BITS) - 1u)) + (n_alleles[q] > 1u ? n_alleles[q] - 1u : 1u);
+                if (end > need) need = end;
+            }
             if (a->cur_block < 0 || (uint64_t)a->cur_block != block) {
                 // a block that lives in the context workspace (cache too small) is overwritten by the next decode:
                 // the composes that read it must have finished
                 if (a->cur_in_workspace) HIP_TRY(hipStreamSynchronize(s));
-                int rc = accessor_load_block(a, block, 0);
+                int rc = accessor_load_block(a, block, need);
                 if (rc) return rc;
             }
-            uint32_t need = 0;
             for (uint32_t g = g0; g < g1; ++g) {
                 const uint64_t q = c0 + order[g];
                 const uint32_t offset = (uint32_t)(positions[q] & ((1u << BM_BLOCK_BITS) - 1u));
@@ -1315,7 +1320,6 @@ int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint
                 fb[g] = offset;
                 na[g] = n_alleles[q];
                 oi[g] = order[g];
-                if (offset + (n_alleles[q] - 1u) > need) need = offset + (n_alleles[q] - 1u);
             }
             int rc = accessor_ensure_lines(a, need);
             if (rc) return rc;
