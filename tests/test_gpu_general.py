@@ -436,6 +436,11 @@ def test_prefix_decode_in_the_accessor(tmp_path, zstd):
         assert np.array_equal(rows2[k, :ngt2[k]], lines[i][0]), "batched query %d (line %d)" % (k, i)
     binding.check(L.xsi_accessor_prefix_stats(a, ctypes.byref(pd), ctypes.byref(ext)))
     assert pd.value >= 1
+    # a cache that cannot hold a block: the prefix is decoded, cannot be stored, and the block is finished in the
+    # context's workspace (every switch of block decodes again)
+    binding.check(L.xsi_accessor_set_cache_bytes(a, 1))
+    for i in (10, 210, 11, 399, 0):
+        check(i)
     L.xsi_accessor_close(a)
 
 
