@@ -896,7 +896,8 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
     L.y_stride64 = (L.N + 63u) / 64u;
     L.yp_stride = L.y_stride64 * 2u;
     if (counts_only) return XSI_OK;  // the caller only wants blocks_h: nothing sized by the WAH lines is allocated
-    WS(L.yp, "ws.rows", 8ull * L.yp_stride * (size_t)(P->n_wah ? P->n_wah : 1));  // shared with the encode's permuted rows
+    // shared with the encode's permuted rows; 16 KiB of slack: the long-row chain reads a row in whole 1024-unit pieces
+    WS(L.yp, "ws.rows", 8ull * L.yp_stride * (size_t)(P->n_wah ? P->n_wah : 1) + 16384ull);
     WS(L.wah_z, "dec.wah_z", 4ull * (P->n_wah ? P->n_wah : 1) + 64);
     {
         // tiles of the boundary scan (2048 WAH words each)

@@ -275,7 +275,8 @@ __device__ unsigned long long g_big_prof[4];  // XSI_BIG_PROF: 100 MHz ticks of 
 
 template <int E, int RP, bool PROF = false>
 __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
-    constexpr int T = 1024, W = 16, G = 8;  // G: gathers in flight per wave
+    // G: gathers in flight per wave (4 where 64 ranks and 32 prefetch registers leave no room for 8 pairs)
+    constexpr int T = 1024, W = 16, G = (E == 64 && RP >= 16) ? 4 : 8;
     static_assert(E % G == 0, "E must be a multiple of the gather group");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has its own L2.  The splits of
@@ -336,25 +337,30 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
     const bool pad_writer = blk_split == 0 && A.out_stride_w > row_words && !tail_fits;
 
     // the row travels as 16-byte pieces (two pairs): 8-byte accesses reach 0.54-0.70 of the 16-byte rate on this chip
-    // (MI355X_MICROARCH.md); rows are whole 16-byte units (yp_stride is even)
+    // (MI355X_MICROARCH.md); rows are whole 16-byte units (yp_stride is even).  Piece q of a row = units q T .. q T + T - 1,
+    // one per thread; only the last piece of a row is partial.  No per-piece offset registers, no exec masks (8 + 5 VGPRs
+    // and 8 saved exec masks before): a piece's base is scalar arithmetic over ONE lane offset, the threads beyond the
+    // row's end read on into what follows it (the next row; the buffer ends with 16 KiB of slack, decode_prepare) and
+    // store that behind the row's end in LDS (the launch sizes LDS in whole pieces); an instantiation with more pieces
+    // than the row has fetches the last one again (unconditional loads stay in flight across the line).
     static_assert(RP % 2 == 0, "pairs are staged two at a time");
     typedef uint32_t row_u32x4 __attribute__((ext_vector_type(4)));
     row_u32x4 R[RP / 2];
     const uint32_t CWP2 = CWP / 2u;
+    const uint32_t q_last = (CWP2 - 1u) / T;  // uniform: the partial (or last whole) piece
+    const uint32_t voff_tid = tid * 16u;
     auto load_row = [&](uint32_t j) {
-        const row_u32x4* src = reinterpret_cast<const row_u32x4*>(A.yp + (size_t)(wah_first + j) * CWP);
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(A.yp + (size_t)(wah_first + j) * CWP);
 #pragma unroll
         for (int q = 0; q < RP / 2; ++q) {
-            const uint32_t idx = (uint32_t)q * T + tid;
-            R[q] = src[idx < CWP2 ? idx : 0u];  // unconditional: stays in flight across the line; store_row keeps to the row
+            const unsigned char* sq = src + (size_t)((uint32_t)q < q_last ? (uint32_t)q : q_last) * (T * 16u);  // scalar
+            R[q] = *reinterpret_cast<const row_u32x4*>(sq + voff_tid);  // scalar base + 32-bit lane offset
         }
     };
     auto store_row = [&]() {
 #pragma unroll
-        for (int q = 0; q < RP / 2; ++q) {
-            const uint32_t idx = (uint32_t)q * T + tid;
-            if (idx < CWP2) reinterpret_cast<row_u32x4*>(row)[idx] = R[q];
-        }
+        for (int q = 0; q < RP / 2; ++q)
+            if ((uint32_t)q <= q_last) reinterpret_cast<row_u32x4*>(row)[(uint32_t)q * T + tid] = R[q];  // uniform condition
     };
     load_row(0);
     store_row();
@@ -389,6 +395,10 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
                 constexpr int e = decltype(ecn)::value;
                 pr[e] = *reinterpret_cast<const LdsPairBig*>((uintptr_t)(((r[g0 + e] >> 2) & 0x3FFF8u) + tbase));
             });
+            // all G gathers are issued before the first update: left to itself the scheduler interleaves them one by one
+            // (ds_read, s_waitcnt lgkmcnt(0), update, ds_read, ...) in some instantiations - <64, 16> among them - and
+            // every chunk then waits out a whole LDS round trip
+            __builtin_amdgcn_sched_barrier(0);
             static_for<0, G>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
                 const uint32_t rr = r[g0 + e];
@@ -677,7 +687,7 @@ static hipError_t launch_rank(hipStream_t s, const RankGeom& g, uint32_t n_block
 // (and by what still fits 128 VGPRs next to the RP prefetch registers).
 static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) {
     const uint32_t nch = (A.N + 63u) / 64u;
-    const uint32_t lds = A.yp_stride * 8u;
+    const uint32_t lds = ((A.yp_stride / 2u + 1023u) / 1024u) * 16384u;  // whole 1024-unit pieces (see the kernel's store_row)
     auto splits_of = [&](uint32_t e) { return (nch + 16u * e - 1u) / (16u * e); };
     static const int env_e = [] {
         const char* e = getenv("XSI_DEC_BIG_E");
