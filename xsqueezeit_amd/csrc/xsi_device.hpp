@@ -459,6 +459,51 @@ __device__ __forceinline__ uint32_t wave_wah_expand_row(const uint16_t* __restri
     return wbase;
 }
 
+// ---- expansion by TOGGLES (round 4) -------------------------------------------------------------------------------
+// A WAH16 line is runs; painting every ones-fill into the row (wave_wah_expand_row: a serial loop over the fills of
+// each 64 words, two v_readlane and a store loop per fill) is what bounded the expansion.  Here a word only marks
+// where the row CHANGES: bit p of the toggle row = line bit p XOR line bit p - 1 (bit -1 = 0).  The map is linear
+// over GF(2), so every word deposits its own contribution with LDS atomic XORs and contributions of neighbouring
+// words cancel where they should: a ones-fill of groups [s, s + n) flips bits 15 s and 15 (s + n); a literal v of
+// group s flips the 16 bits (v ^ v << 1) << 15 s; a zero fill flips nothing.  The line is then the running XOR of
+// the toggle row: inside a 32-bit word five shift-xor steps (prefix_xor32), across words a carry = the word's top
+// bit, across lanes the parity of a ballot.  No loop over fills, no cross-lane reads, cost independent of the runs.
+// Used by k_wah_expand_wide_t (rows above 16 KiB: 37.9 -> 29.7 ms for the WAH lines of a configs[3] shard).  The
+// one-wave kernel for short rows keeps painting: its toggle twin ran 7.05 against 8.30 ms by itself at configs[2] but
+// beside the decode chain - where that expansion runs - it cost the chain 0.7 ms MORE (27.6 against 26.9): it trades
+// the painter's scalar instructions, which are free next to a chain that is bound by vector issue, for vector ones.
+
+__device__ __forceinline__ uint32_t prefix_xor32(uint32_t x) {  // bit i of the result = x[0] ^ ... ^ x[i]
+    x ^= x << 1;
+    x ^= x << 2;
+    x ^= x << 4;
+    x ^= x << 8;
+    x ^= x << 16;
+    return x;
+}
+
+// One word's toggles into the zeroed row `trow` of `rw` words.  `s` = first group the word covers, `ng` its groups
+// (1 for a literal); inactive lanes pass active = false.  Returns the word's ones counted like the reference
+// (wah2_extract_count_ones, wah.hpp:232-235: fills count whole groups).
+__device__ __forceinline__ uint32_t wah_word_toggles(uint32_t word, uint32_t s, uint32_t ng, bool active, uint32_t* trow /*LDS*/,
+                                                     uint32_t rw) {
+    const bool fill = (word & 0x8000u) != 0u;
+    const bool ones_fill = fill && (word & 0x4000u) != 0u;
+    const uint32_t v = word & 0x7FFFu;
+    const uint32_t b0 = s * WAH_BITS;
+    // literal: 16 toggle bits from bit b0 on (they reach into the next 32-bit word when b0 % 32 > 16);
+    // ones-fill: bit b0 and bit b0 + 15 ng; zero fill, inactive lane: nothing
+    const uint64_t lit = (uint64_t)(v ^ (v << 1)) << (b0 & 31u);
+    const uint32_t b1 = b0 + ng * WAH_BITS;
+    uint32_t va = fill ? (ones_fill ? 1u << (b0 & 31u) : 0u) : (uint32_t)lit;
+    uint32_t vb = fill ? (ones_fill ? 1u << (b1 & 31u) : 0u) : (uint32_t)(lit >> 32);
+    const uint32_t wa = b0 >> 5, wb = fill ? b1 >> 5 : wa + 1u;
+    if (!active) va = vb = 0u;
+    if (va && wa < rw) atomicXor(&trow[wa], va);
+    if (vb && wb < rw) atomicXor(&trow[wb], vb);
+    return active ? (fill ? (ones_fill ? ng * WAH_BITS : 0u) : (uint32_t)__popc(v)) : 0u;
+}
+
 // Same, fetching the first words itself.
 __device__ __forceinline__ uint32_t wave_wah_expand_row(const uint16_t* __restrict__ src, uint32_t max_words,
                                                         uint32_t nbits, uint32_t* row /*LDS*/, uint32_t* ones) {

@@ -3097,17 +3097,281 @@ __global__ void __launch_bounds__(1024) k_wah_expand_wide(const uint8_t* __restr
         }
 }
 
+// Rows above 16 KiB by TOGGLES (round 4; see "expansion by TOGGLES" in xsi_device.hpp for the idea): one 1024-thread
+// workgroup walks WAH_WIDE_LPG consecutive lines.  Per line: (A) a thread takes four consecutive words of a round of
+// 4096 (one 8-byte load; a line of 500 000 bits has some 2500 words, so one round as a rule), the groups in front of
+// each word come from one workgroup scan, every word deposits its toggles with at most two LDS atomic XORs - no loop
+// over the fills, which is what the painting kernel above spends its time in; (B) thread t turns words 2 t, 2 t + 1 of
+// every 2048-word stripe into the line's bits (prefix_xor32, a ballot's parity from lane to lane) and counts them AS IF
+// its wave started outside a run; a wave that starts inside one has exactly the complement (64 - c ones per lane), so
+// one pass of wave 0 over the (stripe, wave) parities and totals settles both the carries and the "ones before" of
+// every wave, and the pairs leave as 16-byte stores.  Five barriers a line (a dozen before), the next line's metadata
+// and first words already in flight.
+constexpr uint32_t WAH_WIDE_LPG = 4;
+typedef uint32_t u32_align2 __attribute__((aligned(2)));
+__device__ unsigned long long g_wide_prof[8];  // XSI_WIDE_PROF: 100 MHz ticks of wave 0 of workgroup 0 per phase
+template <bool PROF>
+__global__ void __launch_bounds__(1024) k_wah_expand_wide_t(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
+                                                            DecLines L, const uint32_t* __restrict__ d_totals,
+                                                            const uint32_t* __restrict__ ph_start, const uint32_t* __restrict__ ph_cnt,
+                                                            const uint32_t* __restrict__ ph_gpre, uint32_t n_blocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int STR2 = WAH_WIDE_STRIPES / 2;
+    uint32_t* row = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t rw = L.y_stride64 * 2u;
+    uint32_t* a_tot = row + rw;           // [16] groups per wave of a round of words
+    uint32_t* a_ones = a_tot + 16;        // [16] ones per wave (counted like the reference)
+    uint32_t* b_info = a_ones + 16;       // [STR2 * 16] per (stripe, wave): ones if the wave starts outside a run | parity << 31
+    uint32_t* b_base = b_info + STR2 * 16;  // [STR2 * 16 + 1] ones before the wave | "starts inside a run" << 31; [last] the row's ones
+    uint32_t j0 = blockIdx.x * WAH_WIDE_LPG;
+    uint32_t total = d_totals[1];
+    if (ph_start) {  // one range of every block's lines (phased decode): see k_wah_expand
+        const uint32_t g = blockIdx.x;
+        uint32_t lo = 0, hi = n_blocks;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ph_gpre[mid] <= g) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t first = (g - ph_gpre[lo]) * WAH_WIDE_LPG;
+        if (first >= ph_cnt[lo]) return;
+        j0 = ph_start[lo] + first;
+        const uint32_t end = ph_start[lo] + ph_cnt[lo];
+        total = end < total ? end : total;
+    }
+    if (j0 >= total || d_totals[3]) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    uint64_t t_prof = PROF ? wall_clock64() : 0;
+    auto prof = [&](int i) {
+        if constexpr (!PROF) return;
+        if (blockIdx.x == gridDim.x / 2u && w == 0u) {
+            const uint64_t now = wall_clock64();
+            if (lane == 0) atomicAdd(&g_wide_prof[i], (unsigned long long)(now - t_prof));
+            t_prof = now;
+        }
+    };
+    // lane k of every wave fetches the metadata of line j0 + k (a chain of four dependent loads, paid once per workgroup)
+    uint32_t m_l = 0, m_nbits = 0, m_maxw = 0, m_safe = 0;
+    uint64_t m_src = 0;
+    if (lane < WAH_WIDE_LPG && j0 + lane < total) {
+        m_l = L.wah_lines[j0 + lane];
+        const DecBlock& D = blocks[L.line_block[m_l]];
+        const uint32_t start = L.wah_start[j0 + lane];
+        m_nbits = (L.kind[m_l] & KIND_HAPLOID) ? L.n_samples : L.N;
+        m_maxw = D.wah_words - start;
+        m_src = reinterpret_cast<uint64_t>(file + D.gt_off + D.off_wah) + 2ull * start;
+        const uint64_t at = D.gt_off + D.off_wah + 2ull * start;
+        const uint64_t sw = at < L.file_len ? (L.file_len - at) / 2u : 0u;
+        m_safe = sw < 0xFFFFFFFFull ? (uint32_t)sw : 0xFFFFFFFFu;
+    }
+    using GlobU16W = const __attribute__((address_space(1))) uint16_t;
+    using GlobU32A2 = const __attribute__((address_space(1))) u32_align2;
+    auto src_of = [&](uint32_t k) -> GlobU16W* {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m_src, (int)k);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m_src >> 32), (int)k);
+        return (GlobU16W*)(((uint64_t)hi << 32) | lo);  // global, not flat (see wave_wah_expand_row)
+    };
+    // The four words 4 t .. 4 t + 3 of the round that starts at word `wbase`, as ONE unconditional 8-byte load that
+    // stays in flight until unpack4 (a load under a branch, or selected against a default, is waited for where it is
+    // issued).  Words behind a line's last one are never used (their groups lie beyond the line), so the load may run
+    // past the block's WAH matrix - but not past the image: `safe` = words from the line's first to the image's end
+    // (a thread whose four words would cross that end reads the line's first words again and reports "no word").
+    auto load4 = [&](GlobU16W* src, uint32_t wbase, uint32_t safe, uint32_t (&raw)[2]) {
+        const uint32_t w4 = wbase + 4u * tid;
+        const GlobU32A2* q = (const GlobU32A2*)(src + (w4 + 4u <= safe ? w4 : 0u));  // 2-byte aligned: gfx950 global loads take that
+        raw[0] = q[0];
+        raw[1] = q[1];
+    };
+    auto unpack4 = [&](const uint32_t (&raw)[2], uint32_t wbase, uint32_t max_words, uint32_t safe, uint32_t (&wd)[4]) {
+        const uint32_t w4 = wbase + 4u * tid;
+        const bool ok = w4 + 4u <= safe;
+        wd[0] = ok && w4 < max_words ? raw[0] & 0xFFFFu : 0x10000u;  // 0x10000 = no word
+        wd[1] = ok && w4 + 1u < max_words ? raw[0] >> 16 : 0x10000u;
+        wd[2] = ok && w4 + 2u < max_words ? raw[1] & 0xFFFFu : 0x10000u;
+        wd[3] = ok && w4 + 3u < max_words ? raw[1] >> 16 : 0x10000u;
+    };
+    for (uint32_t i = tid; i < rw; i += 1024u) row[i] = 0;
+    GlobU16W* src = src_of(0);
+    uint32_t maxw = (uint32_t)__builtin_amdgcn_readlane((int)m_maxw, 0);
+    uint32_t safe = (uint32_t)__builtin_amdgcn_readlane((int)m_safe, 0);
+    if (maxw > safe) maxw = safe;  // (a block that claims words beyond the image: parse_blocks flags it; never read them)
+    uint32_t raw[2];
+    load4(src, 0u, safe, raw);
+    __syncthreads();
+    prof(0);  // metadata, first words, row cleared
+    const uint32_t stripes = (L.yp_stride + 2047u) / 2048u;  // <= STR2
+    for (uint32_t k = 0; k < WAH_WIDE_LPG && j0 + k < total; ++k) {
+        const uint32_t j = j0 + k;
+        const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)m_l, (int)k);
+        const uint32_t nbits = (uint32_t)__builtin_amdgcn_readlane((int)m_nbits, (int)k);
+        const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
+        // ---- A: words -> toggles
+        uint32_t gbase = 0, cnt1 = 0;
+        for (uint32_t wbase = 0; wbase < maxw && gbase < G; wbase += 4096u) {
+            // the next round's words travel while this one is scanned (the first lines of a block, hardly sorted yet,
+            // are literal after literal: up to nine rounds); unconditional - the last round fetches what follows the line
+            uint32_t wd[4], rawn[2];
+            unpack4(raw, wbase, maxw, safe, wd);
+            load4(src, wbase + 4096u, safe, rawn);
+            uint32_t ng[4], tsum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ng[q] = wd[q] < 0x10000u ? wah_groups_of(wd[q]) : 0u;
+                tsum += ng[q];
+            }
+            const uint32_t inc = wave_scan_incl_dpp(tsum);
+            if (lane == 63u) a_tot[w] = inc;
+            __syncthreads();
+            const uint32_t sc = row16_scan_incl(lane < 16u ? a_tot[lane] : 0u);
+            const uint32_t wave_base = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
+            const uint32_t round_groups = (uint32_t)__builtin_amdgcn_readlane((int)sc, 15);
+            uint32_t sg = gbase + wave_base + inc - tsum;  // first group covered by my first word
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cnt1 += wah_word_toggles(wd[q] & 0xFFFFu, sg, ng[q], ng[q] != 0u && sg < G, row, rw);
+                sg += ng[q];
+            }
+            gbase += round_groups;
+            raw[0] = rawn[0];
+            raw[1] = rawn[1];
+            __syncthreads();  // a_tot is reused by the next round; the toggles are in the row
+        }
+        {
+            const uint32_t wsum = wave_sum(cnt1);
+            if (lane == 0) a_ones[w] = wsum;
+        }
+        prof(1);  // A: scan + toggles
+        // the next line's metadata and first words travel while this line's row is formed
+        if (k + 1u < WAH_WIDE_LPG && j + 1u < total) {
+            src = src_of(k + 1u);
+            maxw = (uint32_t)__builtin_amdgcn_readlane((int)m_maxw, (int)(k + 1u));
+            safe = (uint32_t)__builtin_amdgcn_readlane((int)m_safe, (int)(k + 1u));
+            if (maxw > safe) maxw = safe;
+            load4(src, 0u, safe, raw);
+        }
+        // ---- B1: toggles -> bits as if every wave started outside a run, back into the row; ones and parity per wave
+        for (uint32_t i = 0; i < stripes; ++i) {
+            const uint32_t idx = i * 2048u + 2u * tid;
+            const bool in = idx < rw;  // rw is even; the in-range lanes of a wave are its first ones
+            uint2 t = make_uint2(0u, 0u);
+            if (in) t = *reinterpret_cast<const uint2*>(row + idx);
+            const uint32_t p0 = prefix_xor32(t.x);
+            const uint32_t p1 = prefix_xor32(t.y) ^ (uint32_t)((int32_t)p0 >> 31);
+            const uint64_t M = __ballot((int32_t)p1 < 0);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+            const uint32_t flip = 0u - (before & 1u);
+            const uint32_t a0 = in ? p0 ^ flip : 0u, a1 = in ? p1 ^ flip : 0u;
+            if (in) *reinterpret_cast<uint2*>(row + idx) = make_uint2(a0, a1);
+            const uint32_t csum = wave_sum((uint32_t)__popc(a0) + (uint32_t)__popc(a1));
+            if (lane == 0u) b_info[i * 16u + w] = csum | (((uint32_t)__popcll(M) & 1u) << 31);
+        }
+        prof(2);  // B1
+        __syncthreads();
+        prof(3);  // barrier behind B1
+        if (w == 0) {
+            // entries in row order: idx = stripe * 16 + wave.  carry into an entry = parity of the toggles in front of it;
+            // its ones = S0 outside a run, 32 * (its words inside the row) - S0 inside one
+            constexpr int PER = (STR2 * 16 + 63) / 64;
+            uint32_t tot[PER], par[PER];
+            uint32_t lane_par = 0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const uint32_t idx = lane * (uint32_t)PER + (uint32_t)q;
+                const uint32_t v = idx < stripes * 16u ? b_info[idx] : 0u;
+                tot[q] = v & 0x7FFFFFFFu;
+                par[q] = v >> 31;
+                lane_par ^= par[q];
+            }
+            const uint64_t M = __ballot(lane_par != 0u);
+            uint32_t cin = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u)) & 1u;
+            uint32_t sum = 0, inside[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const uint32_t idx = lane * (uint32_t)PER + (uint32_t)q;
+                inside[q] = cin;
+                if (cin) {
+                    const uint32_t first = (idx >> 4) * 2048u + (idx & 15u) * 128u;
+                    const uint32_t words = first >= rw ? 0u : (rw - first < 128u ? rw - first : 128u);
+                    tot[q] = words * 32u - tot[q];
+                }
+                sum += tot[q];
+                cin ^= par[q];
+            }
+            uint32_t run = wave_scan_incl_dpp(sum) - sum;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const uint32_t idx = lane * (uint32_t)PER + (uint32_t)q;
+                if (idx < stripes * 16u) b_base[idx] = run | (inside[q] << 31);
+                run += tot[q];
+            }
+            if (lane == 63u) {
+                b_base[STR2 * 16] = run;
+                L.wah_z[j] = nbits - run;
+                uint32_t ones = 0;
+                for (int i = 0; i < 16; ++i) ones += a_ones[i];
+                L.ones[l] = ones;
+            }
+        }
+        prof(4);  // wave 0's pass
+        __syncthreads();
+        prof(5);  // barrier behind it
+        // ---- B2: the waves' carries and bases are known: final words, "ones before", 16-byte stores; the row is left zero
+        uint4* dst = reinterpret_cast<uint4*>(L.yp + (size_t)j * L.yp_stride);
+        const uint32_t row_ones = b_base[STR2 * 16];
+        for (uint32_t i = 0; i < stripes; ++i) {
+            const uint32_t idx = i * 2048u + 2u * tid;
+            const bool in = idx < rw;
+            uint2 a = make_uint2(0u, 0u);
+            if (in) {
+                a = *reinterpret_cast<const uint2*>(row + idx);
+                *reinterpret_cast<uint2*>(row + idx) = make_uint2(0u, 0u);  // ready for the next line
+            }
+            const uint32_t info = b_base[i * 16u + w];
+            const uint32_t flip = in ? 0u - (info >> 31) : 0u;
+            const uint32_t f0 = a.x ^ flip, f1 = a.y ^ flip;
+            const uint32_t c = (uint32_t)__popc(f0) + (uint32_t)__popc(f1);
+            const uint32_t inc = wave_scan_incl_dpp(c);
+            const uint32_t pre0 = in ? (info & 0x7FFFFFFFu) + inc - c : row_ones;
+            if (idx < L.yp_stride) dst[idx >> 1] = make_uint4(f0, pre0, f1, pre0 + (uint32_t)__popc(f0));
+        }
+        prof(6);  // B2
+        // (b_info / b_base / a_ones of the next line are written behind at least one more barrier)
+    }
+}
+
 static bool wah_expand_is_wide(const DecLines& L) {
     return L.y_stride64 * 8u > 16384u && L.yp_stride <= 1024u * (uint32_t)WAH_WIDE_STRIPES && !getenv("XSI_NO_WIDE_EXPAND");
 }
 
-uint32_t wah_expand_lines_per_group(const DecLines& L) { return wah_expand_is_wide(L) ? 1u : WAH_LINES_PER_WAVE; }
+static bool wah_expand_paints() { return getenv("XSI_WAH_EXPAND_PAINT") != nullptr; }  // read per call (tests and A/B runs switch)
+
+uint32_t wah_expand_lines_per_group(const DecLines& L) {
+    return wah_expand_is_wide(L) ? (wah_expand_paints() ? 1u : WAH_WIDE_LPG) : WAH_LINES_PER_WAVE;
+}
 
 // ph_start == nullptr: all WAH lines of the batch (n_groups ignored); else one range of every block's lines
 static hipError_t launch_wah_expand_any(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
                                         uint32_t max_wah, const uint32_t* d_totals, const uint32_t* ph_start,
                                         const uint32_t* ph_cnt, const uint32_t* ph_gpre, uint32_t n_blocks, uint32_t n_groups) {
     const uint32_t lds = L.y_stride64 * 8u;
+    if (wah_expand_is_wide(L) && !wah_expand_paints()) {
+        const uint32_t lds_w = lds + 4u * (32u + 2u * (uint32_t)(WAH_WIDE_STRIPES / 2) * 16u + 1u);
+        const bool prof = getenv("XSI_WIDE_PROF") != nullptr;
+        auto kern = prof ? &k_wah_expand_wide_t<true> : &k_wah_expand_wide_t<false>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
+        if (e != hipSuccess) return e;
+        const uint32_t grid = ph_start ? n_groups : (max_wah + WAH_WIDE_LPG - 1u) / WAH_WIDE_LPG;
+        kern<<<dim3(grid), dim3(1024), lds_w, s>>>(file, blocks, L, d_totals, ph_start, ph_cnt, ph_gpre, n_blocks);
+        if (prof) {
+            unsigned long long pr[8] = {};
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_wide_prof), sizeof(pr));
+            fprintf(stderr, "[xsi wide prof] cumulative us of wave 0 of the middle workgroup: start %.1f, A %.1f, B1 %.1f, barrier %.1f, wave-0 pass %.1f, barrier %.1f, B2 %.1f\n",
+                    pr[0] * 1e-2, pr[1] * 1e-2, pr[2] * 1e-2, pr[3] * 1e-2, pr[4] * 1e-2, pr[5] * 1e-2, pr[6] * 1e-2);
+        }
+        return hipGetLastError();
+    }
     if (wah_expand_is_wide(L)) {
         const uint32_t lds_w = lds + 4u * ((uint32_t)WAH_WIDE_STRIPES * 16u + 16u);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_expand_wide),
