@@ -532,3 +532,51 @@ def test_incompressible_lines_and_words_kept_in_the_row(n_haps, n_lines, block_l
     assert got == ref
     out, _ = G.decode_packed(got, n_haps, stride)
     assert np.array_equal(out, packed)
+
+
+@pytest.mark.parametrize("n_haps", [131074, 140002, 262144])
+@pytest.mark.parametrize("paint", [False, True])
+def test_long_row_expansion_on_adversarial_rows(n_haps, paint, monkeypatch):
+    """Rows above 16 KiB are expanded by toggles (k_wah_expand_wide_t: every WAH16 word flips the bits where the row
+    changes, the row is the running XOR): runs that start and end on 15-bit group, 32-bit word and 64-bit chunk
+    boundaries, fills next to literals, literal after literal (lines of several 4096-word rounds), all ones, a single
+    bit at either end - decoded rows against the source, and the same file through round 1's painting kernel
+    (XSI_WAH_EXPAND_PAINT=1).  MAC threshold 0 and one line per block keep every line a WAH line in identity order, so
+    the WAH words are exactly the rows' runs."""
+    import gpu_util as G
+    if paint:
+        monkeypatch.setenv("XSI_WAH_EXPAND_PAINT", "1")
+    rng = np.random.default_rng(n_haps + 7)
+    rows = []
+    def row():
+        rows.append(np.zeros(n_haps, dtype=np.uint8))
+        return rows[-1]
+    row()[:] = 1                                            # one ones-fill (+ a literal for the tail)
+    r = row(); r[0] = 1                                     # a literal, then a zero fill
+    r = row(); r[-1] = 1
+    r = row(); r[15 * 7:15 * 9000] = 1                      # a fill from group to group
+    r = row(); r[32 * 100:32 * 3000] = 1                    # ... from word boundary to word boundary
+    r = row(); r[64 * 11 + 63:64 * 1500 + 1] = 1            # ... across chunk boundaries
+    r = row(); r[14::15] = 1                                # every group a literal with its top bit: toggles that cancel
+    r = row(); r[::15] = 1
+    r = row(); r[:] = 1; r[15 * 400 + 7] = 0                # fill, literal, fill
+    r = row(); r[:] = 1; r[::4097] = 0
+    r = row(); r[:] = rng.integers(0, 2, n_haps)            # literal after literal: ceil(n / 15) words, several rounds
+    r = row(); r[:] = (rng.random(n_haps) < 0.001)
+    r = row()                                               # runs of random lengths
+    pos, v = 0, 0
+    while pos < n_haps:
+        ln = int(rng.integers(1, 700))
+        r[pos:pos + ln] = v
+        pos, v = pos + ln, v ^ 1
+    r = row(); r[n_haps - 15 * 3:] = 1                      # ones up to the very end
+    bits = np.stack(rows)
+    stride = synth.row_stride_bytes(n_haps)
+    packed = synth.pack_rows(bits, stride)
+    p = G.params(n_haps // 2, 1, 0)                         # every line its own block: identity order, thr 0
+    names = ["S%d" % i for i in range(n_haps // 2)]
+    # rows with no minor allele (all ones / all zeros) are sparse lines whatever the threshold: they ride along
+    ref = G.oracle_file_from_bits(bits, p, names)
+    out, counts = G.decode_packed(ref, n_haps, stride)
+    assert np.array_equal(out, packed)
+    assert np.array_equal(counts, bits.sum(1).astype(np.int32))
