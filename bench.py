@@ -191,10 +191,13 @@ def run_config4(args, real_stdout, emit=True):
     all_na = nal[all_lines]
     a = ctypes.c_void_p()
     binding.check(L.xsi_accessor_open(ctypes.byref(a), ctx.handle, tmp.name.encode()))
-    buf = np.zeros(N, dtype=np.int32)
-    pbuf = ctypes.c_void_p(buf.ctypes.data)
+    # the caller reuses one destination array (an htslib caller's gt_arr): page-locked memory from the accessor
+    # (xsi_accessor_alloc_array) opts in to the direct path - the accessor does not page-lock pageable caller memory
+    pbuf = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_alloc_array(a, N, ctypes.byref(pbuf)))
+    buf = np.ctypeslib.as_array(ctypes.cast(pbuf, ctypes.POINTER(ctypes.c_int32)), shape=(N,))
+    buf[:] = 0
     nout = ctypes.c_int(0)
-    # the caller reuses one destination array (an htslib caller's gt_arr): opt in to the direct path
     binding.check(L.xsi_accessor_register_array(a, buf.ctypes.data, buf.size))
     get = L.xsi_accessor_get_genotypes
     u64 = ctypes.c_uint64

@@ -371,17 +371,24 @@ int xsi_accessor_open(xsi_accessor** a, xsi_hip_ctx* ctx, const char* path);
  * behind the caller's back; the fast path is the opt-in below. */
 int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_t gt_size, uint32_t n_alleles,
                                          uint64_t position);
-/* Opt-in fast path for a caller that reuses ONE destination array (what an htslib caller's gt_arr is): the accessor
- * page-locks h_gt (hipHostRegister; an array the caller page-locked itself is taken as it is) and single-line
- * fills into exactly this pointer are stored there by the compose kernel itself (posted PCIe writes: one launch,
- * one completion, no window copy; 33 instead of 73 us per line at 200 000 haplotypes).
+/* Opt-in fast path for a caller that reuses ONE destination array (what an htslib caller's gt_arr is): single-line
+ * fills into exactly the registered pointer are stored there by the compose kernel itself (posted PCIe writes: one
+ * launch, one completion, no window copy; 33 instead of 73 us per line at 200 000 haplotypes), and rows inside it
+ * serve xsi_accessor_get_genotypes_batch the same way.
+ * The array must be PAGE-LOCKED memory: take it from xsi_accessor_alloc_array (hipHostMalloc; freed by
+ * xsi_accessor_free_array or, at the latest, by xsi_accessor_close), or hand in an allocation you page-locked yourself
+ * (hipHostMalloc, a framework's pinned allocator).  Pageable memory is refused with XSI_ERR_ARG: the accessor never
+ * page-locks caller memory behind an unregister of its own - on this runtime the hipHostUnregister of a range that is
+ * not page-aligned also revokes the device's access to neighbouring pages that the runtime keeps pinned for other host
+ * allocations, and an unrelated asynchronous copy faults later (round 4: an intermittent "Memory access fault by GPU").
  * n_values must be at least 2 * num_samples - the width of a composed row whatever a line's ploidy; a smaller array
- * is refused (XSI_ERR_CAPACITY) and keeps working through the ordinary path.  All n_values are page-locked, so an
- * array of many rows serves xsi_accessor_get_genotypes_batch as well.
- * LIFETIME: the array must stay allocated, at this address, until xsi_accessor_unregister_array, the next
- * xsi_accessor_register_array or xsi_accessor_close returns; freeing it earlier leaves the device with a mapping of
- * freed pages.  One array per accessor.  XSI_ACCESSOR_NO_REGISTER=1 makes this call a no-op (measurement);
- * XSI_ACCESSOR_NO_ZEROCOPY=1 keeps the page-locking but fills the array with the copy engine. */
+ * is refused (XSI_ERR_CAPACITY) and keeps working through the ordinary path.
+ * LIFETIME: the array must stay allocated until xsi_accessor_unregister_array, the next xsi_accessor_register_array,
+ * xsi_accessor_free_array of it, or xsi_accessor_close returns.  One registered array per accessor.
+ * XSI_ACCESSOR_NO_REGISTER=1 makes the registration a no-op (measurement); XSI_ACCESSOR_NO_ZEROCOPY=1 keeps it but
+ * fills the array with the copy engine. */
+int xsi_accessor_alloc_array(xsi_accessor* a, uint64_t n_values, int32_t** h_gt);
+int xsi_accessor_free_array(xsi_accessor* a, int32_t* h_gt);
 int xsi_accessor_register_array(xsi_accessor* a, int32_t* h_gt, uint64_t n_values);
 int xsi_accessor_unregister_array(xsi_accessor* a);
 /* Accessor::get_genotypes without the htslib record: mallocs *h_gt when NULL (hap_samples ints),

@@ -38,6 +38,22 @@ def dev_u8(arr):
     return torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).cuda()
 
 
+def accessor_array(a, shape, fill=0):
+    """An int32 numpy array over page-locked memory from xsi_accessor_alloc_array (what xsi_accessor_register_array
+    takes); free it with accessor_array_free before the accessor is closed, or leave it to xsi_accessor_close."""
+    L = binding.lib()
+    n = int(np.prod(shape))
+    p = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_alloc_array(a, n, ctypes.byref(p)))
+    arr = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_int32)), shape=(n,)).reshape(shape)
+    arr[...] = fill
+    return arr
+
+
+def accessor_array_free(a, arr):
+    binding.check(binding.lib().xsi_accessor_free_array(a, arr.ctypes.data))
+
+
 def dev_empty(nbytes):
     torch = torch_mod()
     ctx()

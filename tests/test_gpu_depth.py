@@ -379,34 +379,36 @@ def test_config4_shape_against_oracle(tmp_path):
     pd, ext = ctypes.c_uint64(0), ctypes.c_uint64(0)
     binding.check(L.xsi_accessor_prefix_stats(a, ctypes.byref(pd), ctypes.byref(ext)))
     assert pd.value >= 1 and ext.value >= 1, (pd.value, ext.value)
-    # a REGISTERED caller array (xsi_accessor_register_array) is page-locked and the compose kernel stores single lines
-    # into it: the same line twice, a sequential run (which goes back through the window), another (unregistered)
-    # array in between, then the first again; a too-small array is refused and nothing is locked
+    # a REGISTERED page-locked array (xsi_accessor_alloc_array + xsi_accessor_register_array): the compose kernel stores
+    # single lines into it: the same line twice, a sequential run (which goes back through the window), another
+    # (unregistered, pageable) array in between, then the first again; a too-small array and pageable memory are refused
     small = np.zeros(n_haps - 2, dtype=np.int32)
     assert L.xsi_accessor_register_array(a, small.ctypes.data, small.size) == binding.XSI_ERR_CAPACITY
-    binding.check(L.xsi_accessor_register_array(a, buf.ctypes.data, buf.size))
+    assert L.xsi_accessor_register_array(a, buf.ctypes.data, buf.size) == binding.XSI_ERR_ARG  # pageable: not taken
+    assert b"pageable" in L.xsi_hip_last_error()
+    pbuf = G.accessor_array(a, (n_haps,))
+    binding.check(L.xsi_accessor_register_array(a, pbuf.ctypes.data, pbuf.size))
     buf2 = np.zeros(n_haps, dtype=np.int32)
     seq = [77, 77, 78, 79, 80, 81, 77, 3000, 3000]
     for k, i in enumerate(seq):
-        dst = buf2 if k == 4 else buf
+        dst = buf2 if k == 4 else pbuf
         dst[:] = -5
         assert L.xsi_accessor_fill_genotype_array(a, dst.ctypes.data, dst.size, int(nal[i]), int(bm[i])) == n_haps
         assert np.array_equal(dst, rows[i]), "step %d line %d" % (k, i)
     binding.check(L.xsi_accessor_unregister_array(a))
+    G.accessor_array_free(a, pbuf)
     # batched queries at this shape: 48 random lines of all blocks in one call, into a registered 2-D array
     bq = np.asarray([int(x) for x in rng.integers(0, n_lines, 48)], dtype=np.int64)
     b_na = np.ascontiguousarray(nal[bq], dtype=np.uint32)
     b_bm = np.ascontiguousarray(bm[bq], dtype=np.uint64)
-    brow = np.full((len(bq), n_haps), -3, dtype=np.int32)
+    brow = G.accessor_array(a, (len(bq), n_haps), -3)
     binding.check(L.xsi_accessor_register_array(a, brow.ctypes.data, brow.size))
     tot = L.xsi_accessor_get_genotypes_batch(a, len(bq), b_na.ctypes.data, b_bm.ctypes.data, brow.ctypes.data, n_haps, None)
     assert tot == len(bq) * n_haps, L.xsi_hip_last_error()
     for k, i in enumerate(bq):
         assert np.array_equal(brow[k], rows[int(i)]), "batched query %d (line %d)" % (k, int(i))
     binding.check(L.xsi_accessor_unregister_array(a))
-    buf[:] = -5   # unregistered: the ordinary path again
+    buf[:] = -5   # pageable memory: the ordinary path
     assert L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, int(nal[77]), int(bm[77])) == n_haps
     assert np.array_equal(buf, rows[77])
-    L.xsi_accessor_close(a)
-    buf[:] = 1  # the array is unlocked again and ordinary memory
-    assert int(buf.sum()) == n_haps
+    L.xsi_accessor_close(a)  # frees brow (an array of xsi_accessor_alloc_array the caller did not free)

@@ -273,7 +273,9 @@ def test_writer_and_accessor_files(tmp_path, kw):
     for mode in ("plain", "registered", "one-block cache"):
         rows2 = np.full((len(q), stride), -9, dtype=np.int32)
         ngt2 = np.zeros(len(q), dtype=np.uint32)
-        if mode == "registered":
+        if mode == "registered":  # page-locked memory of the accessor's (pageable memory is not taken)
+            assert L.xsi_accessor_register_array(a, rows2.ctypes.data, rows2.size) == binding.XSI_ERR_ARG
+            rows2 = G.accessor_array(a, (len(q), stride), -9)
             binding.check(L.xsi_accessor_register_array(a, rows2.ctypes.data, rows2.size))
         if mode == "one-block cache":
             binding.check(L.xsi_accessor_set_cache_bytes(a, 1))
@@ -286,6 +288,10 @@ def test_writer_and_accessor_files(tmp_path, kw):
         assert np.all(rows2[:, 2 * n:] == -9)
         if mode == "registered":
             binding.check(L.xsi_accessor_unregister_array(a))
+            G.accessor_array_free(a, rows2)
+            assert L.xsi_accessor_free_array(a, rows2.ctypes.data) == binding.XSI_ERR_ARG  # not twice
+            rows2 = None
+    rows2 = np.full((len(q), stride), -9, dtype=np.int32)
     assert L.xsi_accessor_get_genotypes_batch(a, 1, q_na.ctypes.data, q_bm.ctypes.data, rows2.ctypes.data, 2 * n - 1,
                                               None) == binding.XSI_ERR_CAPACITY
     # get_genotypes allocates like Accessor::get_genotypes (accessor.hpp:58-67)
@@ -1112,9 +1118,8 @@ def test_accessor_internal_access_with_haploid_lines(tmp_path):
 
 
 def test_accessor_fills_a_caller_pinned_array(tmp_path):
-    """xsi_accessor_register_array with an array the CALLER has page-locked (torch pinned memory): hipHostRegister
-    refuses it as already registered, the accessor uses it as it is (the kernel stores into it) and leaves it locked at
-    close."""
+    """xsi_accessor_register_array with an array the CALLER has page-locked (torch pinned memory): the accessor uses it
+    as it is (the kernel stores into it) and leaves it alone at close."""
     import gpu_util as G
     from oracle import oracle
     torch = G.torch_mod()
@@ -1189,7 +1194,7 @@ def test_haploid_file_never_overruns_the_callers_array(tmp_path, monkeypatch, no
         assert np.array_equal(buf, lines[i][0]), "line %d" % i
         assert np.all(store[n:] == -99), "values written behind the caller's array (line %d)" % i
     # a registered array that is wide enough takes the direct path and gets the same values
-    wide = np.full(2 * n + guard, -99, dtype=np.int32)
+    wide = G.accessor_array(a, (2 * n + guard,), -99)
     binding.check(L.xsi_accessor_register_array(a, wide.ctypes.data, 2 * n))
     for i in (2, 2, 3):
         wide[:] = -99

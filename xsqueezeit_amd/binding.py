@@ -56,7 +56,7 @@ SYMBOLS = [
     "xsi_hip_shard_blocks", "xsi_hip_shard_of_block", "xsi_hip_comm_unique_id", "xsi_hip_comm_create", "xsi_hip_comm_destroy",
     "xsi_hip_comm_world", "xsi_hip_comm_rank", "xsi_hip_gather_block_streams", "xsi_hip_comm_wait", "xsi_htslib_shim_available", "xsi_debug_pack_bit_row",
     "xsi_hip_encode_packed_counted", "xsi_hip_count_packed_rows",
-    "xsi_accessor_register_array", "xsi_accessor_unregister_array", "xsi_hip_gather_block_streams_round",
+    "xsi_accessor_register_array", "xsi_accessor_unregister_array", "xsi_accessor_alloc_array", "xsi_accessor_free_array", "xsi_hip_gather_block_streams_round",
     "xsi_compress_bcf", "xsi_decompress_bcf", "xsi_hip_ctx_reencode_ranges",
     "xsi_accessor_get_genotypes_batch", "xsi_accessor_prefix_stats",
 ]
@@ -204,6 +204,10 @@ def lib():
     L.xsi_accessor_register_array.argtypes = [vp, vp, u64]
     L.xsi_accessor_unregister_array.restype = c.c_int
     L.xsi_accessor_unregister_array.argtypes = [vp]
+    L.xsi_accessor_alloc_array.restype = c.c_int
+    L.xsi_accessor_alloc_array.argtypes = [vp, u64, c.POINTER(vp)]
+    L.xsi_accessor_free_array.restype = c.c_int
+    L.xsi_accessor_free_array.argtypes = [vp, vp]
     L.xsi_accessor_get_genotypes.restype = c.c_int64
     L.xsi_accessor_get_genotypes.argtypes = [vp, u32, u64, c.POINTER(vp), c.POINTER(c.c_int)]
     L.xsi_accessor_get_genotypes_batch.restype = c.c_int64

@@ -546,14 +546,14 @@ struct xsi_accessor {
     // composed window of a bi-allelic block, or the single last composed line
     int32_t* d_rows = nullptr;
     int32_t* h_rows = nullptr;  // pinned
-    // A caller that hands the SAME array to fill_genotype_array / get_genotypes call after call (the reference's
-    // Accessor::get_genotypes mallocs it once, accessor.hpp:59-62) gets it page-locked on its second appearance: a
-    // single-line request is then copied from HBM straight into it, without the stop in the pinned window (at 200 000
-    // haplotypes that memcpy is a third of a warm random query).  Unregistered when another array shows up and at close.
-    void* reg_dst = nullptr;        // the caller's array registered with xsi_accessor_register_array
+    // A page-locked destination array (xsi_accessor_alloc_array, or memory the caller page-locked by an allocation of
+    // its own) registered with xsi_accessor_register_array: a single-line request is stored by the compose kernel
+    // straight into it, without the stop in the pinned window (at 200 000 haplotypes that memcpy is a third of a warm
+    // random query).  The accessor never page-locks caller memory itself (see xsi_accessor_register_array).
+    void* reg_dst = nullptr;        // the array registered with xsi_accessor_register_array
     size_t reg_bytes = 0;
     int32_t* reg_dev = nullptr;     // the device's address of that array (the compose kernel may store into it)
-    bool reg_owned = false;         // this accessor page-locked it (false: the caller had: it stays locked at unregister)
+    std::vector<void*> owned_arrays;  // xsi_accessor_alloc_array: freed at close at the latest
     uint64_t n_full = 0;            // values of a composed row: 2 * num_samples (hap_samples of a v4 file without the field)
     int32_t* direct_dst = nullptr;  // set for the duration of one call: where a single composed line should land
     bool direct_done = false;       // this call's line went there (not into h_rows)
@@ -1137,11 +1137,48 @@ int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_
 }
 
 static void accessor_drop_registration(xsi_accessor* a) {
-    if (a->reg_dst && a->reg_owned && hipHostUnregister(a->reg_dst) != hipSuccess) (void)hipGetLastError();
     a->reg_dst = nullptr;
     a->reg_dev = nullptr;
     a->reg_bytes = 0;
-    a->reg_owned = false;
+}
+
+// Is [p, p + bytes) page-locked memory the device can address (hipHostMalloc / the caller's own hipHostRegister)?
+static bool page_locked_range(const void* p, size_t bytes) {
+    hipPointerAttribute_t at;
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (const unsigned char* q : {b, b + (bytes ? bytes - 1 : 0)}) {
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (at.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+int xsi_accessor_alloc_array(xsi_accessor* a, uint64_t n_values, int32_t** h_gt) {
+    if (!a || !h_gt) return set_error(XSI_ERR_ARG, "alloc_array: null argument");
+    if (n_values < a->n_full)
+        return set_error(XSI_ERR_CAPACITY, "alloc_array: %llu values asked for, a composed row has %llu",
+                         (unsigned long long)n_values, (unsigned long long)a->n_full);
+    void* p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, (size_t)n_values * sizeof(int32_t), hipHostMallocDefault));
+    a->owned_arrays.push_back(p);
+    *h_gt = static_cast<int32_t*>(p);
+    return XSI_OK;
+}
+
+int xsi_accessor_free_array(xsi_accessor* a, int32_t* h_gt) {
+    if (!a || !h_gt) return set_error(XSI_ERR_ARG, "free_array: null argument");
+    auto it = std::find(a->owned_arrays.begin(), a->owned_arrays.end(), static_cast<void*>(h_gt));
+    if (it == a->owned_arrays.end()) return set_error(XSI_ERR_ARG, "free_array: not an array of xsi_accessor_alloc_array");
+    if (a->ctx) HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(h_gt);
+    const uint8_t* r = reinterpret_cast<const uint8_t*>(a->reg_dst);
+    if (a->reg_dst && r >= b) accessor_drop_registration(a);  // (the registered array, or one inside this allocation: gone with it)
+    a->owned_arrays.erase(it);
+    HIP_TRY(hipHostFree(h_gt));
+    return XSI_OK;
 }
 
 int xsi_accessor_register_array(xsi_accessor* a, int32_t* h_gt, uint64_t n_values) {
@@ -1153,22 +1190,15 @@ int xsi_accessor_register_array(xsi_accessor* a, int32_t* h_gt, uint64_t n_value
     accessor_drop_registration(a);
     if (getenv("XSI_ACCESSOR_NO_REGISTER")) return XSI_OK;  // measurement: every line through the pinned window + memcpy
     const size_t bytes = (size_t)n_values * sizeof(int32_t);  // the whole array: a batch fills many rows of it
-    // an array the caller has page-locked already (hipHostMalloc, its own hipHostRegister) serves as it is:
-    // hipHostRegister refuses such memory (hipHostMalloc'ed pages with "invalid argument" on this runtime)
-    hipPointerAttribute_t attr;
-    bool callers = hipPointerGetAttributes(&attr, h_gt) == hipSuccess && attr.type == hipMemoryTypeHost;
-    if (!callers) {
-        (void)hipGetLastError();
-        const hipError_t re = hipHostRegister(h_gt, bytes, hipHostRegisterDefault);
-        if (re == hipErrorHostMemoryAlreadyRegistered) {
-            (void)hipGetLastError();
-            callers = true;
-        } else if (re != hipSuccess) {
-            (void)hipGetLastError();
-            return set_error(XSI_ERR_HIP, "register_array: hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(re));
-        }
-    }
-    a->reg_owned = !callers;
+    // Only memory that IS page-locked is taken - xsi_accessor_alloc_array's, or an allocation the caller page-locked
+    // itself.  The accessor does not hipHostRegister pageable caller memory any more: on this runtime the unregister
+    // of a range that is not page-aligned takes the device's access to the pages next to it away as well, pages the
+    // runtime itself may hold pinned for some other host allocation (its cache of pins made for asynchronous copies from
+    // and to pageable memory) - the next such copy then faults on the device, in a call that has nothing to do with
+    // this accessor (found as an intermittent "Memory access fault by GPU" one page behind a formerly registered array).
+    if (!page_locked_range(h_gt, bytes))
+        return set_error(XSI_ERR_ARG, "register_array: the array is pageable memory; take it from xsi_accessor_alloc_array "
+                                      "(or page-lock the whole allocation yourself) - see include/xsi_hip.h");
     a->reg_dst = h_gt;
     a->reg_bytes = bytes;
     void* dev = nullptr;
@@ -1618,7 +1648,8 @@ const char* xsi_accessor_sample_name(const xsi_accessor* a, uint64_t i) {
 void xsi_accessor_close(xsi_accessor* a) {
     if (!a) return;
     if (a->ctx) (void)hipStreamSynchronize(a->ctx->stream);
-    accessor_drop_registration(a);  // xsi_hip.h: a registered array must outlive its registration
+    accessor_drop_registration(a);
+    for (void* p : a->owned_arrays) (void)hipHostFree(p);  // (arrays of xsi_accessor_alloc_array the caller did not free)
     for (auto& e : a->cache) (void)hipFree(e.mem);
     if (a->d_file) (void)hipFree(a->d_file);
     if (a->d_mini) (void)hipFree(a->d_mini);
