@@ -601,6 +601,10 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
 #pragma unroll
             for (int k = 0; k < SMAX; ++k)  // slices past S: beyond the descriptor's range or the other parity's, not stored
                 t[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_slices, tid_here * 16u, (par * A.S + (uint32_t)k) * 16384u, 16);
+            // all S loads in flight before the first is consumed: left to itself the scheduler (128 VGPRs, 64 of them
+            // ranks) ran them one after the other through ONE register quad - load, s_waitcnt vmcnt(0), ds_write, load, ...:
+            // eight round trips to L2 per line instead of one
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < SMAX; ++k)
                 if ((uint32_t)k < A.S) {
