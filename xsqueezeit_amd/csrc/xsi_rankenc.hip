@@ -571,7 +571,11 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my entries have left
         __syncthreads();
-        if (tid == 0) *reinterpret_cast<volatile uint64_t*>(gsflags + par * 8u + member) = ((uint64_t)seq << 32) | ones_slice;
+        // (a global store, said so: through a plain pointer it was a FLAT store, and with a flat operation outstanding the
+        // compiler has to wait for ALL loads wherever it waits for one)
+        if (tid == 0)
+            *reinterpret_cast<volatile __attribute__((address_space(1))) uint64_t*>(
+                (__attribute__((address_space(1))) uint64_t*)(gsflags + par * 8u + member)) = ((uint64_t)seq << 32) | ones_slice;
         {   // my part of the row for the WAH pass: behind the flag, nobody in the chain waits for this store
             const uint32_t roww = member * SL_WORDS + 2u * tid_here;  // rows are whole 16-byte units
             if (roww < A.dst_stride_w) *reinterpret_cast<uint2*>(A.dst + (size_t)rank * A.dst_stride_w + roww) = row_words;
