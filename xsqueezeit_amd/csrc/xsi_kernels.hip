@@ -1909,20 +1909,36 @@ __global__ void __launch_bounds__(256) k_wah_write(const EncBlock* __restrict__ 
         const uint16_t* src = L.wah_inplace ? reinterpret_cast<const uint16_t*>(L.yrows + (size_t)j * L.y_stride64)
                                             : L.wah_scratch + (size_t)j * L.wah_scratch_stride;  // 4-byte aligned rows
         const uint32_t head = (uint32_t)((reinterpret_cast<uint64_t>(dst) >> 1) & 1ull);
-        if (head && n && lane == 0) dst[0] = src[0];
-        if (n <= head) continue;
-        const uint32_t m = n - head;  // words from src + head to the 4-byte aligned dst + head
-        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
-        __attribute__((address_space(1))) uint32_t* d32 = (__attribute__((address_space(1))) uint32_t*)(dst + head);  // global, not flat
-        for (uint32_t i = lane; i < m / 2u; i += 64u) {
-            uint32_t v;
-            if (head)
-                v = (s32[i] >> 16) | (s32[i + 1u] << 16);
-            else
-                v = s32[i];
-            d32[i] = v;
+        if (n <= head) {
+            if (head && n && lane == 0) ((__attribute__((address_space(1))) uint16_t*)dst)[0] = ((const __attribute__((address_space(1))) uint16_t*)src)[0];
+            continue;
         }
-        if ((m & 1u) && lane == 0) dst[n - 1u] = src[n - 1u];
+        const uint32_t m = n - head;  // words from src + head to the 4-byte aligned dst + head
+        // Everything here is global memory, said so: dst comes out of two v_readlane halves, which makes it "generic" to
+        // the compiler, and a FLAT store (the single words at either end were) left outstanding forces every later
+        // wait to be a wait for all loads.  16 bytes per lane and step: four loads in flight instead of one.
+        using G32 = __attribute__((address_space(1))) uint32_t;
+        using G16 = __attribute__((address_space(1))) uint16_t;
+        typedef uint32_t quad_a4 __attribute__((ext_vector_type(4), aligned(4)));
+        using GQuad = __attribute__((address_space(1))) quad_a4;
+        const G32* s32 = (const G32*)src;
+        G32* d32 = (G32*)(dst + head);
+        if (head && n && lane == 0) ((G16*)dst)[0] = ((const G16*)src)[0];
+        const uint32_t nd = m / 2u;
+        for (uint32_t q = lane; q < nd / 4u; q += 64u) {
+            const uint32_t b = 4u * q;
+            const uint32_t a0 = s32[b], a1 = s32[b + 1u], a2 = s32[b + 2u], a3 = s32[b + 3u];
+            quad_a4 o;
+            if (head) {
+                const uint32_t a4 = s32[b + 4u];
+                o = quad_a4{(a0 >> 16) | (a1 << 16), (a1 >> 16) | (a2 << 16), (a2 >> 16) | (a3 << 16), (a3 >> 16) | (a4 << 16)};
+            } else {
+                o = quad_a4{a0, a1, a2, a3};
+            }
+            *(GQuad*)(d32 + b) = o;
+        }
+        for (uint32_t i = (nd & ~3u) + lane; i < nd; i += 64u) d32[i] = head ? (s32[i] >> 16) | (s32[i + 1u] << 16) : s32[i];
+        if ((m & 1u) && lane == 0) ((G16*)dst)[n - 1u] = ((const G16*)src)[n - 1u];
     }
 }
 
