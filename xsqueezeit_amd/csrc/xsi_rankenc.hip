@@ -502,8 +502,16 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                     (void*)(lst + (size_t)k * 16u * MULTI_LIST_CAP), 0, (int)(cnt[k] * 4u), 0x00020000);
                 rk[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (i0 + lane * 4u) * 4u, 0, 16);
             };
+            // in THIS order, list 0 first (a scheduling barrier behind each): the loop works through the lists in order and
+            // requests a list's next piece behind its current one, so a piece is always the oldest load in flight when it
+            // is needed - but the compiler had issued these first eight in reverse, which made list 0's piece the YOUNGEST
+            // at the loop's entry, and the wait at the top of the loop (one wait for both ways into it) a wait for all
+            // eight loads in every round: the last of them had been requested a moment before
 #pragma unroll
-            for (int k = 0; k < SMAX; ++k) load_piece(k, 0u);
+            for (int k = 0; k < SMAX; ++k) {
+                load_piece(k, 0u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             for (uint32_t i0 = 0; i0 < longest; i0 += 256u) {
 #pragma unroll
                 for (int k = 0; k < SMAX; ++k) {
