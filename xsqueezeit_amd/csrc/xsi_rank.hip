@@ -363,6 +363,7 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
             if ((uint32_t)q <= q_last) reinterpret_cast<row_u32x4*>(row)[(uint32_t)q * T + tid] = R[q];  // uniform condition
     };
     load_row(0);
+    __builtin_amdgcn_sched_barrier(0);  // (all pieces requested before the first is parked)
     store_row();
     uint32_t line = A.wah_lines[wah_first], Z = A.wah_z[wah_first];
     __syncthreads();
