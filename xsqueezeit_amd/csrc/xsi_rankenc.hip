@@ -359,6 +359,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
     uint32_t* wtot = slice + SL_WORDS;  // [0,16) wave totals of the slice, [32,48) list lengths of my waves
     uint32_t* ring_all = wtot + 64;     // [16 waves][128] ranks on their way to the lists
     const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    if (tab_lds != 0u) __builtin_trap();  // the kernel has no other LDS variable: the table starts at LDS address 0 (the gathers rely on it)
     const uint32_t slice_lds = tab_lds + tab_bytes;
     const uint32_t N = A.N;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -668,35 +669,46 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
         const ConstU32* lines = as_const(A.wah_lines) + wah_first;
         // Ranks on their way to my wave's list pass through a 128-entry ring in LDS, so that they leave as whole
         // 256-byte stores (a store of one to three lanes per chunk is one fabric write per lane).
-        uint32_t n_app = 0, n_out = 0;  // ranks appended / already stored, for the line in the making (wave-uniform)
+        // The 128 entries are a LINEAR buffer: the ranks not yet stored sit at its front (fewer than 64), a chunk's new
+        // ones go behind them at `wpos` - a scalar LDS byte address, so a lane's slot is v_mbcnt x 2 + ONE v_lshl_add
+        // (round 4; the ring it replaces took six vector instructions per chunk: the running count moved into a vector
+        // register, a wrap mask, a copy of the rank) - and a flush stores the first 64 and moves the rest to the front.
+        uint32_t n_out = 0;  // ranks already stored, for the line in the making (wave-uniform)
         uint32_t* my_list = nullptr;
         uint32_t* ring = ring_all + w * 128u;
+        const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(ring));
+        uint32_t wpos = ring_lds;
         auto open_list = [&](uint32_t sq) {
-            n_app = 0;
+            wpos = ring_lds;
             n_out = 0;
             my_list = glists + (size_t)((sq & 1u) * n_lists + member * W + w) * MULTI_LIST_CAP;
         };
         auto flush64 = [&]() {
-            my_list[n_out + lane] = ring[(n_out + lane) & 127u];
+            my_list[n_out + lane] = ring[lane];
             n_out += 64u;
+            const uint32_t rest = (wpos - ring_lds - 256u) >> 2;  // entries behind the 64 that leave
+            const uint32_t v = ring[64u + lane];
+            if (lane < rest) ring[lane] = v;
+            wpos -= 256u;
         };
+        using LdsRing = __attribute__((address_space(3))) uint32_t;
         auto append = [&](uint64_t xm, uint32_t rr) {
             if (xm) {
                 if (__builtin_amdgcn_inverse_ballot_w64(xm)) {
-                    asm volatile("" : "+v"(rr));  // the slot is formed here, not hoisted for all 64 chunks at once
-                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(xm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)xm, n_app));
-                    ring[slot & 127u] = rr;
+                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(xm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)xm, 0u));
+                    *reinterpret_cast<LdsRing*>((uintptr_t)(wpos + (slot << 2))) = rr;
                 }
-                n_app += (uint32_t)__popcll(xm);
-                if (n_app - n_out >= 64u) flush64();
+                wpos += 4u * (uint32_t)__popcll(xm);
+                if (wpos >= ring_lds + 256u) flush64();
             }
         };
         // the rest of the list, padded to a whole 64-entry store with entries that mean nothing (~0); its length goes
         // to LDS for the flag record; the wave waits for its stores
         auto publish = [&]() {
-            if (n_app != n_out) {
-                const uint32_t left = n_app - n_out;
-                my_list[n_out + lane] = lane < left ? ring[(n_out + lane) & 127u] : ~0u;
+            const uint32_t left = (wpos - ring_lds) >> 2;
+            if (left) {
+                my_list[n_out + lane] = lane < left ? ring[lane] : ~0u;
                 n_out += 64u;
             }
             if (lane == 0) wtot[32u + w] = n_out;
@@ -766,7 +778,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                 sbuf_load_chunks<G>(rsn, c0 + (uint32_t)g0, xn);
                 static_for<0, G>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
-                    pr[e] = *reinterpret_cast<const LdsU2*>((uintptr_t)(((r[g0 + e] >> 2) & 0x1FFF8u) + tab_lds));
+                    pr[e] = *reinterpret_cast<const LdsU2*>((uintptr_t)((r[g0 + e] >> 2) & 0x1FFF8u));  // the table starts at LDS address 0
                 });
                 if (dense_next) {
                     static_for<0, G>([&](auto ec) {
