@@ -1712,9 +1712,21 @@ __global__ void __launch_bounds__(1024) k_wah_units_wide(const EncBlock* __restr
         typedef uint32_t wah_u32x4 __attribute__((ext_vector_type(4)));
         using LdsU4 = __attribute__((address_space(3))) wah_u32x4;
         LdsU4* l4 = reinterpret_cast<LdsU4*>(lrow_w);
-        for (uint32_t i = tid; i < rw / 4u; i += 1024u) {
-            const uint4 v = src[i];
-            l4[i] = wah_u32x4{v.x, v.y, v.z, v.w};
+        // every piece of the row requested before the first is parked (as a loop this was load, wait, LDS write per
+        // round: up to five HBM round trips in a row per line); rows of at most 5 x 1024 16-byte units (655 360 bits)
+        constexpr int PIECES = (int)(WAH_WIDE_UNITS * 32u * WAH_BITS / 128u / 1024u) + 1;  // 8
+        uint4 pc[PIECES];
+        const uint32_t n4 = rw / 4u;
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            const uint32_t i = (uint32_t)q * 1024u + tid;
+            pc[q] = src[i < n4 ? i : 0u];  // unconditional (clamped): stays in flight
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            const uint32_t i = (uint32_t)q * 1024u + tid;
+            if (i < n4) l4[i] = wah_u32x4{pc[q].x, pc[q].y, pc[q].z, pc[q].w};
         }
         for (uint32_t i = rw + tid; i < row_words_lds; i += 1024u) lrow_w[i] = 0;
     }
