@@ -553,7 +553,7 @@ struct xsi_accessor {
     void* reg_dst = nullptr;        // the array registered with xsi_accessor_register_array
     size_t reg_bytes = 0;
     int32_t* reg_dev = nullptr;     // the device's address of that array (the compose kernel may store into it)
-    std::vector<void*> owned_arrays;  // xsi_accessor_alloc_array: freed at close at the latest
+    std::vector<std::pair<void*, size_t>> owned_arrays;  // xsi_accessor_alloc_array (pointer, bytes): freed at close at the latest
     uint64_t n_full = 0;            // values of a composed row: 2 * num_samples (hap_samples of a v4 file without the field)
     int32_t* direct_dst = nullptr;  // set for the duration of one call: where a single composed line should land
     bool direct_done = false;       // this call's line went there (not into h_rows)
@@ -1163,19 +1163,19 @@ int xsi_accessor_alloc_array(xsi_accessor* a, uint64_t n_values, int32_t** h_gt)
                          (unsigned long long)n_values, (unsigned long long)a->n_full);
     void* p = nullptr;
     HIP_TRY(hipHostMalloc(&p, (size_t)n_values * sizeof(int32_t), hipHostMallocDefault));
-    a->owned_arrays.push_back(p);
+    a->owned_arrays.push_back({p, (size_t)n_values * sizeof(int32_t)});
     *h_gt = static_cast<int32_t*>(p);
     return XSI_OK;
 }
 
 int xsi_accessor_free_array(xsi_accessor* a, int32_t* h_gt) {
     if (!a || !h_gt) return set_error(XSI_ERR_ARG, "free_array: null argument");
-    auto it = std::find(a->owned_arrays.begin(), a->owned_arrays.end(), static_cast<void*>(h_gt));
+    auto it = std::find_if(a->owned_arrays.begin(), a->owned_arrays.end(), [&](const std::pair<void*, size_t>& e) { return e.first == h_gt; });
     if (it == a->owned_arrays.end()) return set_error(XSI_ERR_ARG, "free_array: not an array of xsi_accessor_alloc_array");
     if (a->ctx) HIP_TRY(hipStreamSynchronize(a->ctx->stream));
     const uint8_t* b = reinterpret_cast<const uint8_t*>(h_gt);
     const uint8_t* r = reinterpret_cast<const uint8_t*>(a->reg_dst);
-    if (a->reg_dst && r >= b) accessor_drop_registration(a);  // (the registered array, or one inside this allocation: gone with it)
+    if (a->reg_dst && r >= b && r < b + it->second) accessor_drop_registration(a);  // the registered array lies in this allocation: gone with it
     a->owned_arrays.erase(it);
     HIP_TRY(hipHostFree(h_gt));
     return XSI_OK;
@@ -1649,7 +1649,7 @@ void xsi_accessor_close(xsi_accessor* a) {
     if (!a) return;
     if (a->ctx) (void)hipStreamSynchronize(a->ctx->stream);
     accessor_drop_registration(a);
-    for (void* p : a->owned_arrays) (void)hipHostFree(p);  // (arrays of xsi_accessor_alloc_array the caller did not free)
+    for (auto& e : a->owned_arrays) (void)hipHostFree(e.first);  // (arrays of xsi_accessor_alloc_array the caller did not free)
     for (auto& e : a->cache) (void)hipFree(e.mem);
     if (a->d_file) (void)hipFree(a->d_file);
     if (a->d_mini) (void)hipFree(a->d_mini);
