@@ -67,6 +67,8 @@ int bcf_unpack(bcf1_t* b, int which);
 int bcf_write(htsFile* fp, bcf_hdr_t* h, bcf1_t* v);
 #define bcf_write1(fp, h, v) bcf_write((fp), (h), (v))
 
+int bcf_index_build3(const char* fn, const char* fnidx, int min_shift, int n_threads);
+
 int bcf_get_format_values(const bcf_hdr_t* hdr, bcf1_t* line, const char* tag, void** dst, int* ndst, int type);
 #define bcf_get_format_int32(hdr, line, tag, dst, ndst) bcf_get_format_values(hdr, line, tag, (void**)(dst), ndst, BCF_HT_INT)
 #define bcf_get_genotypes(hdr, line, dst, ndst) bcf_get_format_values(hdr, line, "GT", (void**)(dst), ndst, BCF_HT_INT)

@@ -4,8 +4,10 @@
 // default library carries the stub at the bottom (xsi_htslib_shim_available() == 0, xsi_compress_bcf /
 // xsi_decompress_bcf return XSI_ERR_UNSUPPORTED).  What CAN be checked here is checked: tests/test_host.py compiles
 // this file with -fsyntax-only -DXSI_HAVE_HTSLIB against declaration-only prototypes of the htslib functions it uses
-// (tests/cxx/htslib_decls/), so a typo or a wrong argument list does not wait for the first machine with htslib.
-// It has never RUN: BASELINE configs[0] (a real BCF through -c / -x) stays untested.
+// (tests/cxx/htslib_decls/), and tests/test_shim_mock.py builds it against a small working stand-in for those ~35 calls
+// (tests/cxx/mini_hts/: GT-only VCF text, test infrastructure) and RUNS both fill loops and the c_xcf_* table on the
+// GPU: -c of the reference's fixtures == the oracle's files, -x -Ov == the input text, -s / -r / -t / -Ox.
+// It has never run against htslib itself: BASELINE configs[0] (a real BCF2 file through -c / -x) stays untested.
 //
 // With htslib it exports, under their reference names, the symbols an existing HTSLIB caller links against
 //
@@ -71,6 +73,14 @@ bool xsi_path_of(const char* bcf_path, bcf_hdr_t* hdr, std::string& out) {
 bool file_exists(const std::string& p) {
     struct stat st;
     return ::stat(p.c_str(), &st) == 0;
+}
+// create_index_file (xcf.cpp:39-60): a CSI index (min_shift 14) next to the variant BCF; -r / -R need it
+int build_index(const std::string& bcf_path) {
+    const int r = bcf_index_build3(bcf_path.c_str(), nullptr, 14, 1);
+    if (r == 0) return XSI_OK;
+    fprintf(stderr, r == -2 ? "index: failed to open %s\n" : r == -3 ? "index: %s is in a format that cannot be usefully indexed\n"
+                                                                    : "index: failed to create index for %s\n", bcf_path.c_str());
+    return XSI_ERR_IO;
 }
 
 struct Entry {
@@ -289,6 +299,7 @@ static int write_variant_bcf(const char* in_bcf, const std::string& var_path, co
 int xsi_compress_bcf(const char* in_bcf, const char* out_xsi, double maf, uint32_t block_len, uint32_t zstd_level) {
     if (!in_bcf || !out_xsi || !block_len) return XSI_ERR_ARG;
     int rc = write_variant_bcf(in_bcf, std::string(out_xsi) + VAR_EXT, out_xsi, block_len);
+    if (rc == XSI_OK) rc = build_index(std::string(out_xsi) + VAR_EXT);  // xsqueezeit.cpp:127
     if (rc) return rc;
     bcf_srs_t* sr = open_reader(in_bcf, nullptr, 0, nullptr);
     if (!sr) return XSI_ERR_IO;
@@ -415,6 +426,14 @@ int xsi_decompress_bcf(const char* in_xsi, const char* out_path, const xsi_decom
         if (!genotypes) rc = XSI_ERR_ARG;
     }
     const std::string var_in = std::string(in_xsi) + VAR_EXT;
+    if (rc == XSI_OK && !file_exists(var_in)) {
+        fprintf(stderr, "File %s is missing and required to decompress the .xsi\n", var_in.c_str());
+        rc = XSI_ERR_IO;
+    }
+    if (rc == XSI_OK && !file_exists(var_in + ".csi")) {  // xsqueezeit.cpp:174-178
+        fprintf(stderr, "Index for %s is missing, reindexing now...\n", var_in.c_str());
+        rc = build_index(var_in);
+    }
     if (rc == XSI_OK && !(sr = open_reader(var_in.c_str(), opt.regions, opt.regions_is_file, opt.targets))) rc = XSI_ERR_IO;
     std::string bcf_out(out_path);
     if (to_xsi) bcf_out += VAR_EXT;
@@ -501,8 +520,10 @@ int xsi_decompress_bcf(const char* in_xsi, const char* out_path, const xsi_decom
             break;
         }
         if (select) {  // recompute AC / AN as bcftools view -s does (:225-236, :297-303)
+            // (results not checked, as in the reference: a file whose header defines no AC / AN keeps none)
             int32_t an = (int32_t)n;
-            if (bcf_update_info_int32(hdr, rec, "AC", ac.data(), (int)n_alt) < 0 || bcf_update_info_int32(hdr, rec, "AN", &an, 1) < 0) rc = XSI_ERR_FORMAT;
+            bcf_update_info_int32(hdr, rec, "AC", ac.data(), (int)n_alt);
+            bcf_update_info_int32(hdr, rec, "AN", &an, 1);
         }
         if (to_xsi) {
             // update_and_write_xsi (:241-273): the record keeps BM, now pointing into the NEW file
