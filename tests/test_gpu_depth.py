@@ -69,6 +69,7 @@ def test_full_depth_block_against_oracle(n_haps, n_lines, thr, kernels, monkeypa
     (64976, 3, 700, 64, dict(XSI_RANK_WG_MIN_BLOCKS="1")),   # one-workgroup-per-block decode chain at depth (>= 192 blocks by default), 12 line ranges
     (64976, 3, 700, 64, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_DEC_PHASES="1")),   # the same in one range
     (40000, 4, 777, 40, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_DEC_PHASES="7")),   # ranges that do not divide the blocks' lines
+    (50002, 3, 500, 50, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_DEC_PHASES="3")),   # 56 chunks per wave: the instantiation whose gathers are pinned in front of the updates
     (5008, 6, 900, 5, dict(XSI_DEC_PHASES_SMALL="1", XSI_DEC_PHASES="5", XSI_RANKENC_MIN_N="2")),   # the batch-staged decode chain in ranges
     (24576, 3, 900, 24, dict()),                          # rank-tracking encode below 64 chunks per wave
     (12300, 2, 1200, 12, dict(XSI_RANKENC_MIN_N="2")),

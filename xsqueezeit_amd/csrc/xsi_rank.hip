@@ -556,6 +556,12 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
                 constexpr int e = decltype(ecn)::value;
                 pr[e] = *reinterpret_cast<const LdsPair*>((uintptr_t)(((r[g0 + e] >> 2) & 0x3FF8u) + tbase));
             });
+            // <56>: all eight gathers issued before the first update.  That instantiation came out with ONE in flight -
+            // ds_read, s_waitcnt lgkmcnt(0), update, ds_read, ... (tools/isa_scan.py) -: 25.7 -> 23.2 ms at 50 000
+            // haplotypes x 2 M sites, 25.5 -> 24.1 at 57 000.  Measured for every E: <48>, serialised as well, lost
+            // 0.5 ms with the barrier (45 000 haplotypes: 19.8 -> 20.4) and <64>, which has three in flight without
+            // it, 0.7 (27.2 -> 28.0): with fewer chunks per wave the interleaved form hides more than it costs.
+            if constexpr (E == 56) __builtin_amdgcn_sched_barrier(0);
             static_for<0, G>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
                 const uint32_t rr = r[g0 + e];
