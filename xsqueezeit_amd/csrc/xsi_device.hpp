@@ -255,6 +255,7 @@ using LdsCU32 = const __attribute__((address_space(3))) uint32_t;
 using LdsU32W = __attribute__((address_space(3))) uint32_t;
 constexpr int WAH_UNIT_ROUNDS = 3;  // 3 x 64 units x 32 groups = 6144 groups >= ceil(65 536 / 15)
 constexpr uint32_t WAH_UNIT_ROW_WORDS = 64u * 15u * (uint32_t)WAH_UNIT_ROUNDS;
+#include "xsi_wah_classify.inc"
 struct WahUnit {
     uint32_t H, F, O;  // heads, fill groups, all-ones groups of my unit (bit k = group k of the unit)
 };
@@ -264,21 +265,14 @@ __device__ __forceinline__ void wah_unit_classify(LdsCU32* row, uint32_t u, uint
 #pragma unroll
     for (int i = 0; i < 15; ++i) w[i] = row[u * 15u + (uint32_t)i];
     const uint32_t prev = row[u ? u * 15u - 1u : 0u] >> 17;  // the group before the unit (u > 0)
-    uint32_t nz = 0, no = 0;  // bit k: group k is not all zeros / not all ones
-    static_for<0, 32>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        constexpr int wi = (15 * k) >> 5, sh = (15 * k) & 31;
-        uint32_t val;
-        if constexpr (sh <= 17)
-            val = __builtin_amdgcn_ubfe(w[wi], (uint32_t)sh, 15u);
-        else
-            val = __builtin_amdgcn_alignbit(w[wi + 1], w[wi], (uint32_t)sh) & 0x7FFFu;
-        nz = ((val ? 1u : 0u) << k) | nz;
-        no = (((val ^ 0x7FFFu) ? 1u : 0u) << k) | no;
-    });
+    // bit k: group k is not all zeros / is all ones.  Five vector instructions a group, hand-scheduled
+    // (xsi_wah_classify.inc, generated by tools/gen_wah_classify.py; the compiler's form of "extract, compare twice, set
+    // bit k" came to about 7.5 + two s_nop: k_wah_units is bound by vector issue and a third of it was this)
+    uint32_t nz, on;
+    wah_unit_flags(w, nz, on);
     const uint32_t nv = G > gb ? G - gb : 0u;
     const uint32_t Vm = nv >= 32u ? ~0u : ((1u << nv) - 1u);
-    const uint32_t Z = ~nz & Vm, O = ~no & Vm;
+    const uint32_t Z = ~nz & Vm, O = on & Vm;
     const uint32_t pz = (u != 0u && prev == 0u) ? 1u : 0u, po = (u != 0u && prev == 0x7FFFu) ? 1u : 0u;
     const uint32_t Zs = Z & ((Z << 1) | pz), Os = O & ((O << 1) | po);
     m.H = Vm & ~(Zs | Os);
