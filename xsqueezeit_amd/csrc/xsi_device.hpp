@@ -360,8 +360,6 @@ __device__ __forceinline__ void wah_units_emit_line(LdsCU32* row, LdsU32W* fh, u
             const uint32_t t = t0 + lane;
             const int ua = (int)(ul << 2);
             const uint32_t Hs = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)m[r].H);
-            const uint32_t Fs = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)m[r].F);
-            const uint32_t Os = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)m[r].O);
             const uint32_t ex = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)excl);
             const uint32_t nhs = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)nh);
             const uint32_t kk = t - ex;  // lanes beyond the round: anything, nothing is stored
@@ -371,8 +369,11 @@ __device__ __forceinline__ void wah_units_emit_line(LdsCU32* row, LdsU32W* fh, u
             const uint32_t nxt = rest ? g + 1u + (uint32_t)__builtin_ctz(rest) : nhs;
             const uint32_t o = g * WAH_BITS;
             const uint32_t lit = __builtin_amdgcn_alignbit(row[(o >> 5) + 1u], row[o >> 5], o & 31u) & 0x7FFFu;
-            const uint32_t fill = 0x8000u | (((Os >> k) & 1u) << 14) | (nxt - g);
-            if (t < Wr) gdst[round_off + t] = (uint16_t)(((Fs >> k) & 1u) ? fill : lit);
+            // a head is a fill exactly when its own group is all zeros or all ones: read off the literal the lane
+            // fetches anyway (the unit's F and O masks came over two more ds_bpermute before)
+            const bool all1 = lit == 0x7FFFu;
+            const uint32_t fill = (all1 ? 0xC000u : 0x8000u) | (nxt - g);
+            if (t < Wr) gdst[round_off + t] = (uint16_t)((lit == 0u || all1) ? fill : lit);
         }
         round_off += Wr;
     }
