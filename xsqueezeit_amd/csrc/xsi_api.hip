@@ -929,8 +929,11 @@ int decode_counts_only(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P) {
 // of range p + 1 (side stream) runs underneath the chain of range p, which parks its ranks in `d_state` between the
 // launches - and behind the last one, when hi[b] is not the block's last WAH line, so that a later call continues
 // from there (the accessor's prefix decode).  The boundaries must have been computed on the context's stream.
+// `split_boundaries`: only the starts of every block's first range have been computed (launch_wah_boundaries_part 1);
+// the rest of the boundary scan goes to the side stream behind the first range's expansion, underneath the first
+// chain launch (whole-block decodes only: lo == hi == nullptr).
 static int run_wah_phases(xsi_hip_ctx* ctx, const uint8_t* f, DecodePlan& P, uint32_t* out, uint32_t stride_w,
-                          const uint32_t* lo, const uint32_t* hi, uint32_t K, uint32_t* d_state) {
+                          const uint32_t* lo, const uint32_t* hi, uint32_t K, uint32_t* d_state, bool split_boundaries = false) {
     hipStream_t s = ctx->stream;
     DecLines& L = P.L;
     const uint32_t nb = P.n_blocks, lpg = wah_expand_lines_per_group(L);
@@ -969,6 +972,7 @@ static int run_wah_phases(xsi_hip_ctx* ctx, const uint8_t* f, DecodePlan& P, uin
         const uint32_t groups = P.phase_tab[(size_t)p * (3u * nb + 1u) + 3u * nb];
         HIP_TRY(launch_wah_expand_phase(ctx->side2, f, P.d_blocks, L, P.d_totals, tab, tab + nb, tab + 2u * nb, nb, groups));
         HIP_TRY(hipEventRecord(ctx->ev_phase[p], ctx->side2));
+        if (p == 0u && split_boundaries) HIP_TRY(launch_wah_boundaries_part(ctx->side2, f, P.d_blocks, nb, L, K, 2));
     }
     stage_mark(ctx, XSI_ST_DEC_EXPAND);  // what shows of the expansion: the wait for its first range
     // (measurement: XSI_DEC_PHASES_SERIAL=1 lets every range expand before the first chain launch, which leaves
@@ -1059,7 +1063,6 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
     L.yp_rows = P.n_wah ? P.n_wah : 1u;
     L.yp_compact = (!any_haploid && rank_decode_takes_compact(L.N, L.yp_stride, P.n_blocks)) ? 1u : 0u;
     stage_mark(ctx, XSI_ST_DEC_BOUND);
-    HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
     // Phased: the chain needs line j of every block at its step j, so the WAH lines of every block are cut into K
     // ranges; the expansion of range p+1 (side stream) runs underneath the chain of range p, which parks its
     // ranks in HBM between the launches (4 N bytes per block: 64 MB at 245 blocks of 64 976 haplotypes).  A whole second expansion
@@ -1072,11 +1075,22 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
         return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
     }();
     if (n_phases > 1u && !any_haploid && P.n_wah >= 256u * P.n_blocks && rank_decode_phased_ok(L.N, L.yp_stride, P.n_blocks)) {
+        // The boundary scan is phased too: only the first range's line starts are found in front of the chain, the rest
+        // of the scan runs underneath the first chain launch: configs[2] 65.6 -> 64.7 ms per step (boundaries 1.16 ->
+        // 0.51 ms visible, the first range's expansion 0.68 -> 0.48).  Short rows only: a long-row chain fills the CUs
+        // (section 5.6 of DESIGN.md), the second part just takes its turn there (configs[3] shard 493.2 against 494.0 ms).
+        // (XSI_DEC_BOUNDARIES_WHOLE=1: all of it in front, as before - A/B runs)
+        const bool split = getenv("XSI_DEC_BOUNDARIES_WHOLE") == nullptr && L.y_stride64 * 8u <= 16384u;
+        if (split)
+            HIP_TRY(launch_wah_boundaries_part(s, f, P.d_blocks, P.n_blocks, L, n_phases, 1));
+        else
+            HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
         uint32_t* d_state;
         WS(d_state, "dec.rank_state", 4ull * rank_decode_state_words(L.N, P.n_blocks));
-        int prc = run_wah_phases(ctx, f, P, out, stride_w, nullptr, nullptr, n_phases, d_state);
+        int prc = run_wah_phases(ctx, f, P, out, stride_w, nullptr, nullptr, n_phases, d_state, split);
         if (prc) return prc;
     } else {
+        HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
         stage_mark(ctx, XSI_ST_DEC_EXPAND);
         HIP_TRY(launch_wah_expand(s, f, P.d_blocks, L, P.n_wah, P.d_totals));
         stage_mark(ctx, XSI_ST_CHAIN_DEC);

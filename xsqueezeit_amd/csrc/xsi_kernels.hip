@@ -2685,16 +2685,24 @@ __global__ void __launch_bounds__(1024) k_wah_tile_scan(const DecBlock* __restri
     }
 }
 
+// ranges == 0: every tile.  Else (phased decode, no fully haploid lines): part 1 = the tiles that hold the starts of the
+// block's first n_wah / ranges lines - those in front of that many lines' groups -, part 2 = the others.
 __global__ void __launch_bounds__(BND_T) k_wah_boundaries(const uint8_t* __restrict__ file,
-                                                          const DecBlock* __restrict__ blocks, DecLines L) {
+                                                          const DecBlock* __restrict__ blocks, DecLines L, uint32_t ranges,
+                                                          int part) {
     __shared__ uint64_t s_scan[20];
     const DecBlock& D = blocks[blockIdx.y];
     const uint32_t c0 = blockIdx.x * BND_TILE;
     if (D.error || D.n_wah == 0 || c0 >= D.wah_words) return;
+    const uint32_t Gd = (L.N + WAH_BITS - 1u) / WAH_BITS;
+    const uint64_t tile_base = L.tile_base[(size_t)blockIdx.y * L.max_tiles + blockIdx.x];
+    if (ranges) {
+        const bool first = tile_base < (uint64_t)(D.n_wah / ranges) * Gd;
+        if (first != (part == 1)) return;
+    }
     const uint16_t* wm = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah);
     const uint32_t nwords = D.wah_words;
     constexpr uint32_t K = BND_K * BND_Q;
-    const uint32_t Gd = (L.N + WAH_BITS - 1u) / WAH_BITS;
     const bool mixed = D.off_line_haploid != VAL_UNDEFINED;
     const uint32_t w0 = c0 + threadIdx.x * K;
     uint32_t g[K];
@@ -2712,7 +2720,7 @@ __global__ void __launch_bounds__(BND_T) k_wah_boundaries(const uint8_t* __restr
         }
     }
     uint64_t tot;
-    uint64_t ex = L.tile_base[(size_t)blockIdx.y * L.max_tiles + blockIdx.x] + block_scan_excl64(sum, s_scan, &tot);
+    uint64_t ex = tile_base + block_scan_excl64(sum, s_scan, &tot);
     // uniform lines: line index and offset inside the line by ONE division per thread, then
     // carried along word by word (a word never spans two lines, so the offset wraps exactly)
     uint64_t jline = 0;
@@ -2759,7 +2767,18 @@ hipError_t launch_wah_boundaries(hipStream_t s, const uint8_t* file, const DecBl
     if (!n_blocks || !L.max_tiles) return hipSuccess;
     k_wah_tile_sums<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L);
     k_wah_tile_scan<<<dim3(n_blocks), dim3(1024), 0, s>>>(blocks, L);
-    k_wah_boundaries<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L);
+    k_wah_boundaries<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L, 0u, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_wah_boundaries_part(hipStream_t s, const uint8_t* file, const DecBlock* blocks, uint32_t n_blocks,
+                                      const DecLines& L, uint32_t ranges, int part) {
+    if (!n_blocks || !L.max_tiles || !ranges) return hipSuccess;
+    if (part == 1) {
+        k_wah_tile_sums<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L);
+        k_wah_tile_scan<<<dim3(n_blocks), dim3(1024), 0, s>>>(blocks, L);
+    }
+    k_wah_boundaries<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L, ranges, part);
     return hipGetLastError();
 }
 
