@@ -937,6 +937,21 @@ static int run_wah_phases(xsi_hip_ctx* ctx, const uint8_t* f, DecodePlan& P, uin
     hipStream_t s = ctx->stream;
     DecLines& L = P.L;
     const uint32_t nb = P.n_blocks, lpg = wah_expand_lines_per_group(L);
+    // Range p of a block with n lines = lines [n cuts[p] / den, n cuts[p + 1] / den).  K equal ranges - or, with the
+    // split boundary scan, a ramp in front of them: 1/4, 1/2 and one whole range's worth of lines, so that what shows in
+    // front of the first chain launch (the scan's first part and the first expansion) covers n / 4K lines, not n / K
+    // (configs[2]: 64.7 -> 64.4 ms per step).
+    std::vector<uint32_t> cuts;
+    uint32_t den = K;
+    if (split_boundaries && K >= 2u) {
+        den = 4u * K;
+        cuts = {0u, 1u, 3u};
+        for (uint32_t c = 7u; c < den; c += 4u) cuts.push_back(c);
+        cuts.push_back(den);
+    } else {
+        for (uint32_t p = 0; p <= K; ++p) cuts.push_back(p);
+    }
+    K = (uint32_t)cuts.size() - 1u;
     // per phase and block: first WAH line (batch-wide rank), lines, and the running number of 4-line groups
     P.phase_tab.assign((size_t)K * (3u * nb + 1u), 0u);
     for (uint32_t p = 0; p < K; ++p) {
@@ -948,7 +963,7 @@ static int run_wah_phases(xsi_hip_ctx* ctx, const uint8_t* f, DecodePlan& P, uin
             const uint32_t nw = D.error ? 0u : D.n_wah;
             const uint32_t b_lo = lo ? (lo[b] < nw ? lo[b] : nw) : 0u, b_hi = hi ? (hi[b] < nw ? hi[b] : nw) : nw;
             const uint32_t n = b_hi > b_lo ? b_hi - b_lo : 0u;
-            const uint32_t plo = (uint32_t)((uint64_t)n * p / K), phi = (uint32_t)((uint64_t)n * (p + 1u) / K);
+            const uint32_t plo = (uint32_t)((uint64_t)n * cuts[p] / den), phi = (uint32_t)((uint64_t)n * cuts[p + 1u] / den);
             start[b] = D.wah_first + b_lo + plo;
             cnt[b] = phi - plo;
             gpre[b] = g;
@@ -972,7 +987,8 @@ static int run_wah_phases(xsi_hip_ctx* ctx, const uint8_t* f, DecodePlan& P, uin
         const uint32_t groups = P.phase_tab[(size_t)p * (3u * nb + 1u) + 3u * nb];
         HIP_TRY(launch_wah_expand_phase(ctx->side2, f, P.d_blocks, L, P.d_totals, tab, tab + nb, tab + 2u * nb, nb, groups));
         HIP_TRY(hipEventRecord(ctx->ev_phase[p], ctx->side2));
-        if (p == 0u && split_boundaries) HIP_TRY(launch_wah_boundaries_part(ctx->side2, f, P.d_blocks, nb, L, K, 2));
+        // (the scan's first part covered the ramp: see decode_planes)
+        if (split_boundaries && p == (K > 3u ? 2u : 0u)) HIP_TRY(launch_wah_boundaries_part(ctx->side2, f, P.d_blocks, nb, L, den, cuts[p + 1u], 2));
     }
     stage_mark(ctx, XSI_ST_DEC_EXPAND);  // what shows of the expansion: the wait for its first range
     // (measurement: XSI_DEC_PHASES_SERIAL=1 lets every range expand before the first chain launch, which leaves
@@ -1082,7 +1098,7 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
         // (XSI_DEC_BOUNDARIES_WHOLE=1: all of it in front, as before - A/B runs)
         const bool split = getenv("XSI_DEC_BOUNDARIES_WHOLE") == nullptr && L.y_stride64 * 8u <= 16384u;
         if (split)
-            HIP_TRY(launch_wah_boundaries_part(s, f, P.d_blocks, P.n_blocks, L, n_phases, 1));
+            HIP_TRY(launch_wah_boundaries_part(s, f, P.d_blocks, P.n_blocks, L, 4u * n_phases, 7u, 1));  // run_wah_phases' first three ranges
         else
             HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
         uint32_t* d_state;

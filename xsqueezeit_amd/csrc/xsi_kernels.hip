@@ -2686,10 +2686,10 @@ __global__ void __launch_bounds__(1024) k_wah_tile_scan(const DecBlock* __restri
 }
 
 // ranges == 0: every tile.  Else (phased decode, no fully haploid lines): part 1 = the tiles that hold the starts of the
-// block's first n_wah / ranges lines - those in front of that many lines' groups -, part 2 = the others.
+// block's first n_wah num / ranges lines - those in front of that many lines' groups -, part 2 = the others.
 __global__ void __launch_bounds__(BND_T) k_wah_boundaries(const uint8_t* __restrict__ file,
                                                           const DecBlock* __restrict__ blocks, DecLines L, uint32_t ranges,
-                                                          int part) {
+                                                          uint32_t num, int part) {
     __shared__ uint64_t s_scan[20];
     const DecBlock& D = blocks[blockIdx.y];
     const uint32_t c0 = blockIdx.x * BND_TILE;
@@ -2697,7 +2697,7 @@ __global__ void __launch_bounds__(BND_T) k_wah_boundaries(const uint8_t* __restr
     const uint32_t Gd = (L.N + WAH_BITS - 1u) / WAH_BITS;
     const uint64_t tile_base = L.tile_base[(size_t)blockIdx.y * L.max_tiles + blockIdx.x];
     if (ranges) {
-        const bool first = tile_base < (uint64_t)(D.n_wah / ranges) * Gd;
+        const bool first = tile_base < (uint64_t)(uint32_t)((uint64_t)D.n_wah * num / ranges) * Gd;
         if (first != (part == 1)) return;
     }
     const uint16_t* wm = reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah);
@@ -2767,18 +2767,18 @@ hipError_t launch_wah_boundaries(hipStream_t s, const uint8_t* file, const DecBl
     if (!n_blocks || !L.max_tiles) return hipSuccess;
     k_wah_tile_sums<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L);
     k_wah_tile_scan<<<dim3(n_blocks), dim3(1024), 0, s>>>(blocks, L);
-    k_wah_boundaries<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L, 0u, 0);
+    k_wah_boundaries<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L, 0u, 0u, 0);
     return hipGetLastError();
 }
 
 hipError_t launch_wah_boundaries_part(hipStream_t s, const uint8_t* file, const DecBlock* blocks, uint32_t n_blocks,
-                                      const DecLines& L, uint32_t ranges, int part) {
+                                      const DecLines& L, uint32_t ranges, uint32_t num, int part) {
     if (!n_blocks || !L.max_tiles || !ranges) return hipSuccess;
     if (part == 1) {
         k_wah_tile_sums<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L);
         k_wah_tile_scan<<<dim3(n_blocks), dim3(1024), 0, s>>>(blocks, L);
     }
-    k_wah_boundaries<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L, ranges, part);
+    k_wah_boundaries<<<dim3(L.max_tiles, n_blocks), dim3(BND_T), 0, s>>>(file, blocks, L, ranges, num, part);
     return hipGetLastError();
 }
 

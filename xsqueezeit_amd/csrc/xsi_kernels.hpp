@@ -148,11 +148,11 @@ hipError_t launch_scan_dec_blocks2(hipStream_t s, DecBlock* blocks, uint32_t n_b
 hipError_t launch_dec_line_lists(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L);
 hipError_t launch_wah_boundaries(hipStream_t s, const uint8_t* file, const DecBlock* blocks, uint32_t n_blocks,
                                  const DecLines& L);
-// The same in two parts for the phased decode with `ranges` line ranges per block: part 1 = tile sums, their scan and
-// the starts of every block's FIRST range of lines (the tiles in front of groups n_wah / ranges x G), part 2 = the
-// other tiles (any stream, behind part 1).  Blocks without fully haploid lines only.
+// The same in two parts for the phased decode: part 1 = tile sums, their scan and the starts of every block's first
+// n_wah x num / ranges lines (the tiles in front of that many lines' groups), part 2 = the other tiles (any stream,
+// behind part 1).  Blocks without fully haploid lines only.
 hipError_t launch_wah_boundaries_part(hipStream_t s, const uint8_t* file, const DecBlock* blocks, uint32_t n_blocks,
-                                      const DecLines& L, uint32_t ranges, int part);
+                                      const DecLines& L, uint32_t ranges, uint32_t num, int part);
 hipError_t launch_sparse_walk(hipStream_t s, const uint8_t* file, const DecBlock* blocks, uint32_t n_blocks,
                               const DecLines& L);
 hipError_t launch_wah_expand(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
