@@ -413,3 +413,30 @@ def test_config4_shape_against_oracle(tmp_path):
     assert L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, int(nal[77]), int(bm[77])) == n_haps
     assert np.array_equal(buf, rows[77])
     L.xsi_accessor_close(a)  # frees brow (an array of xsi_accessor_alloc_array the caller did not free)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_phased_decode_on_random_shapes(seed, monkeypatch):
+    """The phased decode (line ranges with a ramp in front, the boundary scan in two parts, ranks parked between the
+    chain launches) on random geometries: blocks of unequal length (the last one short, down to a handful of lines),
+    range counts that do not divide anything, rows from 16 384 to 65 536 haplotypes: rows == input, file == oracle."""
+    import gpu_util as G
+    rng = np.random.default_rng(1000 + seed)
+    n_haps = int(rng.integers(8192, 32768)) * 2
+    block_len = int(rng.integers(700, 1500))
+    n_blocks = int(rng.integers(2, 5))
+    n_lines = (n_blocks - 1) * block_len + int(rng.integers(3, block_len))
+    phases = int(rng.integers(2, 33))
+    thr = int(rng.integers(0, 40))
+    monkeypatch.setenv("XSI_RANK_WG_MIN_BLOCKS", "1")
+    monkeypatch.setenv("XSI_DEC_PHASES", str(phases))
+    bits, packed, stride = _device_synth(n_haps, n_lines, 100 + seed)
+    p = G.params(n_haps // 2, block_len, thr)
+    ref = G.oracle_file_from_bits(bits, p)
+    region, offsets, res = G.encode_packed(packed, n_haps, p)
+    assert res.n_wah_lines >= 256 * n_blocks  # what decode_planes asks for before it cuts the lines into ranges
+    got = G.assemble_file(region, offsets, p, n_lines, n_lines, ["S%d" % i for i in range(n_haps // 2)])
+    assert got == ref, (n_haps, block_len, n_lines, phases)
+    out, counts = G.decode_packed(got, n_haps, stride)
+    assert np.array_equal(out, packed), (n_haps, block_len, n_lines, phases)
+    assert np.array_equal(counts, bits.sum(1).astype(np.int32))
