@@ -384,3 +384,11 @@ def test_append_packs_simple_rows_to_bits():
                 g2 = gt.copy()
                 g2[pos] = bad
                 assert L.xsi_debug_pack_bit_row(g2.ctypes.data, n, dp, out.ctypes.data) == 0, (n, dp, pos, bad)
+
+
+def test_generated_wah_classification_is_in_sync():
+    """csrc/xsi_wah_classify.inc (one hand-scheduled asm statement) is what tools/gen_wah_classify.py writes."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_wah_classify.py"), "--check"])
+    assert r.returncode == 0
