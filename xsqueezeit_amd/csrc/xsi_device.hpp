@@ -259,12 +259,14 @@ constexpr uint32_t WAH_UNIT_ROW_WORDS = 64u * 15u * (uint32_t)WAH_UNIT_ROUNDS;
 struct WahUnit {
     uint32_t H, F, O;  // heads, fill groups, all-ones groups of my unit (bit k = group k of the unit)
 };
-__device__ __forceinline__ void wah_unit_classify(LdsCU32* row, uint32_t u, uint32_t G, WahUnit& m) {
+// `ua`: the unit whose words are READ (callers whose lanes may hold a unit behind the line's last one pass the last
+// one here: such a lane's masks come out zero whatever it reads, but it must not read behind the row's LDS)
+__device__ __forceinline__ void wah_unit_classify(LdsCU32* row, uint32_t u, uint32_t G, WahUnit& m, uint32_t ua) {
     const uint32_t gb = u * 32u;
     uint32_t w[15];
 #pragma unroll
-    for (int i = 0; i < 15; ++i) w[i] = row[u * 15u + (uint32_t)i];
-    const uint32_t prev = row[u ? u * 15u - 1u : 0u] >> 17;  // the group before the unit (u > 0)
+    for (int i = 0; i < 15; ++i) w[i] = row[ua * 15u + (uint32_t)i];
+    const uint32_t prev = row[ua ? ua * 15u - 1u : 0u] >> 17;  // the group before the unit (u > 0)
     // bit k: group k is not all zeros / is all ones.  Five vector instructions a group, hand-scheduled
     // (xsi_wah_classify.inc, generated by tools/gen_wah_classify.py; the compiler's form of "extract, compare twice, set
     // bit k" came to about 7.5 + two s_nop: k_wah_units is bound by vector issue and a third of it was this)
@@ -282,13 +284,14 @@ __device__ __forceinline__ void wah_unit_classify(LdsCU32* row, uint32_t u, uint
 // Masks of every unit of the line (one call per wave); returns the number of WAH16 words of the line.
 __device__ __forceinline__ uint32_t wah_units_classify_line(LdsCU32* row, uint32_t G, WahUnit (&m)[WAH_UNIT_ROUNDS]) {
     const uint32_t lane = lane_id();
-    const uint32_t rounds = (((G + 31u) >> 5) + 63u) >> 6;
+    const uint32_t units = (G + 31u) >> 5, rounds = (units + 63u) >> 6;
     uint32_t cnt = 0;
 #pragma unroll
     for (int r = 0; r < WAH_UNIT_ROUNDS; ++r) {
         m[r] = WahUnit{0u, 0u, 0u};
         if ((uint32_t)r < rounds) {  // wave-uniform
-            wah_unit_classify(row, (uint32_t)r * 64u + lane, G, m[r]);
+            const uint32_t u = (uint32_t)r * 64u + lane;
+            wah_unit_classify(row, u, G, m[r], u < units ? u : units - 1u);
             cnt += (uint32_t)__popc(m[r].H);
         }
     }

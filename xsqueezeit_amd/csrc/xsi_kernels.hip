@@ -1546,7 +1546,7 @@ __global__ void __launch_bounds__(256) k_wah_units_small(EncLines L, const uint3
     const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
     WahUnit m{0u, 0u, 0u};
     LdsCU32* row = reinterpret_cast<LdsCU32*>(rows + li * upl * 15u);  // my line's row
-    if (mine) wah_unit_classify(row, u, G, m);
+    if (mine) wah_unit_classify(row, u, G, m, u);
     const uint32_t cnt = (uint32_t)__popc(m.H);
     const uint32_t inc = wave_scan_incl_dpp(cnt);
     // heads before my line = inclusive count of the last lane of the line before
@@ -1597,7 +1597,14 @@ static uint32_t wah_units_small_upl(const EncLines& L) {
 // xsi_device.hpp on it.  The sizing pass counts heads; the writing pass (after the layout is known) classifies
 // again and stores the words straight into the file image: no scratch copy of the words (10 GB at 64 976 x 2 M).
 constexpr int WAH_STAGE_Q = 16;  // 16 x 64 lanes x 8 bytes = 8 KiB
-constexpr uint32_t WAH_UNIT_WAVE_WORDS = WAH_UNIT_ROW_WORDS + 64u * (uint32_t)WAH_UNIT_ROUNDS + 16u;  // row, fh, 64-byte strip
+constexpr uint32_t WAH_UNIT_SCRATCH_WORDS = 64u * (uint32_t)WAH_UNIT_ROUNDS + 16u;  // fh, 64-byte strip (behind a wave's row)
+// LDS words of a wave's row: every unit's 15 words (+ the word behind a literal), at least the row itself
+static uint32_t wah_units_row_words(uint32_t y_stride64) {
+    const uint32_t units = ((y_stride64 * 64u + WAH_BITS - 1u) / WAH_BITS + 31u) / 32u;
+    const uint32_t need = units * 15u + 1u > 2u * y_stride64 ? units * 15u + 1u : 2u * y_stride64;
+    const uint32_t w = (need + 3u) & ~3u;
+    return w < WAH_UNIT_ROW_WORDS ? w : WAH_UNIT_ROW_WORDS;
+}
 // MODE 0: sizing pass; 1: writing pass (classifies again, words straight into the file image); 2: sizing pass that also
 // leaves the line's words IN THE LINE'S OWN ROW (the row is in LDS by then, and a line whose words would not fit its
 // row - less than one line in 16 literal groups short of incompressible - is left alone): k_wah_write then moves the
@@ -1605,7 +1612,10 @@ constexpr uint32_t WAH_UNIT_WAVE_WORDS = WAH_UNIT_ROW_WORDS + 64u * (uint32_t)WA
 template <int MODE>
 __global__ void __launch_bounds__(256) k_wah_units(const EncBlock* __restrict__ blocks, EncLines L,
                                                    const uint32_t* __restrict__ d_total_wah, uint32_t max_wah,
-                                                   uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result) {
+                                                   uint8_t* __restrict__ out, const uint64_t* __restrict__ d_result,
+                                                   uint32_t row_words) {
+    // row_words: LDS words of a wave's row (wah_units_row_words: what the rows of this launch need, not the 2880 of the
+    // longest row the kernel takes - 36 instead of 49 KB per workgroup at 64 976 haplotypes: four waves per SIMD, not three)
     constexpr bool WRITE_PASS = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char wah_smem[];
     if (WRITE_PASS && d_result[3]) return;  // capacity error: nothing may be written
@@ -1622,11 +1632,11 @@ __global__ void __launch_bounds__(256) k_wah_units(const EncBlock* __restrict__ 
     typedef uint32_t wah_u32x2 __attribute__((ext_vector_type(2)));
     using LdsU2 = __attribute__((address_space(3))) wah_u32x2;
     LdsU32W* lrow_w = reinterpret_cast<LdsU32W*>((__attribute__((address_space(3))) unsigned char*)wah_smem) +
-                      (size_t)wv * WAH_UNIT_WAVE_WORDS;
+                      (size_t)wv * (row_words + WAH_UNIT_SCRATCH_WORDS);
     LdsU2* lrow2 = reinterpret_cast<LdsU2*>(lrow_w);
     LdsCU32* lrow = reinterpret_cast<LdsCU32*>(lrow_w);
-    LdsU32W* fh = lrow_w + WAH_UNIT_ROW_WORDS;
-    for (uint32_t i = 2u * np + lane; i < WAH_UNIT_ROW_WORDS; i += 64u) lrow_w[i] = 0;  // beyond the row: zeros
+    LdsU32W* fh = lrow_w + row_words;
+    for (uint32_t i = 2u * np + lane; i < row_words; i += 64u) lrow_w[i] = 0;  // beyond the row: zeros
     uint64_t m_dst = 0;
     uint32_t m_nbits = 0;
     if (lane < WAH_LINES_PER_WAVE && j0 + lane < total) {
@@ -1742,7 +1752,7 @@ __global__ void __launch_bounds__(1024) k_wah_units_wide(const EncBlock* __restr
     for (int r = 0; r < WAH_WIDE_ROUNDS; ++r) {
         const uint32_t u = (uint32_t)r * 1024u + tid;
         m[r] = WahUnit{0u, 0u, 0u};
-        if (u < units) wah_unit_classify(lrow, u, G, m[r]);
+        if (u < units) wah_unit_classify(lrow, u, G, m[r], u);
         const uint64_t B = __ballot(m[r].H != 0u);
         if (lane == 0) {
             hb[2u * ((uint32_t)r * 16u + w)] = (uint32_t)B;
@@ -1863,15 +1873,16 @@ hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_
         return L.wah_inplace ? launch_wah_units_wide<2>(s, nullptr, L, d_total_wah, max_wah, nullptr, nullptr)
                              : launch_wah_units_wide<0>(s, nullptr, L, d_total_wah, max_wah, nullptr, nullptr);
     if (wah_units_ok(L.y_stride64)) {
-        const uint32_t lds = 4u * 4u * WAH_UNIT_WAVE_WORDS;
+        const uint32_t row_words = wah_units_row_words(L.y_stride64);
+        const uint32_t lds = 4u * 4u * (row_words + WAH_UNIT_SCRATCH_WORDS);
         const void* fn = L.wah_inplace ? reinterpret_cast<const void*>(&k_wah_units<2>) : reinterpret_cast<const void*>(&k_wah_units<0>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         const dim3 grid((max_wah + per_wg - 1u) / per_wg);
         if (L.wah_inplace)
-            k_wah_units<2><<<grid, dim3(256), lds, s>>>(nullptr, L, d_total_wah, max_wah, nullptr, nullptr);
+            k_wah_units<2><<<grid, dim3(256), lds, s>>>(nullptr, L, d_total_wah, max_wah, nullptr, nullptr, row_words);
         else
-            k_wah_units<0><<<grid, dim3(256), lds, s>>>(nullptr, L, d_total_wah, max_wah, nullptr, nullptr);
+            k_wah_units<0><<<grid, dim3(256), lds, s>>>(nullptr, L, d_total_wah, max_wah, nullptr, nullptr, row_words);
         return hipGetLastError();
     }
     if (const uint32_t upl = wah_units_small_upl(L)) {
@@ -1961,12 +1972,13 @@ hipError_t launch_wah_write(hipStream_t s, const EncBlock* blocks, const EncLine
     if (!L.wah_scratch && !L.wah_inplace && wah_units_wide_ok(L.y_stride64))
         return launch_wah_units_wide<1>(s, blocks, L, nullptr, max_wah, out, d_result);
     if (!L.wah_scratch && !L.wah_inplace && wah_units_ok(L.y_stride64)) {  // classify again, words straight into place
-        const uint32_t lds = 4u * 4u * WAH_UNIT_WAVE_WORDS;
+        const uint32_t row_words = wah_units_row_words(L.y_stride64);
+        const uint32_t lds = 4u * 4u * (row_words + WAH_UNIT_SCRATCH_WORDS);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units<1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         k_wah_units<1><<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), lds, s>>>(blocks, L, nullptr, max_wah, out,
-                                                                                     d_result);
+                                                                                     d_result, row_words);
         return hipGetLastError();
     }
     k_wah_write<<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), 0, s>>>(blocks, L, max_wah, out, d_result);
