@@ -312,7 +312,7 @@ __device__ __forceinline__ uint32_t select_bit32(uint32_t x, uint32_t k) {
     if (k >= (x & 1u)) pos += 1u;
     return pos;
 }
-// Emit the words of the line to dst (2-byte aligned).  `fh` = LDS scratch of 64 * WAH_UNIT_ROUNDS + 16 words.
+// Emit the words of the line to dst (2-byte aligned).  `fh` = LDS scratch of 64 * WAH_UNIT_ROUNDS + 32 words.
 // WORD-major: lane i of a step forms word i of the round.  The heads are spread very unevenly over the units (2.4 a
 // unit on average at configs[2], ~30 in the busiest of a round), so a loop in which every unit emits its own heads runs
 // as long as the busiest unit at a few percent lane use.  A word's unit: the units whose first word falls into the
@@ -352,31 +352,42 @@ __device__ __forceinline__ void wah_units_emit_line(LdsCU32* row, LdsU32W* fh, u
         const uint32_t excl = inc - cnt;
         const uint32_t Wr = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);  // words of this round
         uint32_t carry = 0;  // unit lane + 1 of the last word of the step before
-        for (uint32_t t0 = 0; t0 < Wr; t0 += 64u) {
+        // Two steps of 64 words per iteration (one strip of 128 markers): the second step's chain of dependent LDS
+        // operations - markers, prefix maximum, three ds_bpermute, the head's select, the literal's two words - runs in
+        // the gaps of the first one's; only the prefix maxima are chained (the first step's last lane seeds the second).
+        for (uint32_t t0 = 0; t0 < Wr; t0 += 128u) {
             mk[lane] = 0;
-            if (cnt && excl - t0 < 64u) mk[excl - t0] = (uint8_t)(lane + 1u);  // (excl < t0 wraps to a large number)
-            asm volatile("" ::: "memory");  // other lanes' stores: no forwarding of my own zero to the load below
-            uint32_t u = wave_scan_max_incl_dpp((uint32_t)mk[lane]);  // one wave: its LDS operations stay in order
-            u = u > carry ? u : carry;
-            carry = (uint32_t)__builtin_amdgcn_readlane((int)u, 63);
-            const uint32_t ul = u - 1u;  // u >= 1: word 0 of a round is the first word of a unit
-            const uint32_t t = t0 + lane;
-            const int ua = (int)(ul << 2);
-            const uint32_t Hs = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)m[r].H);
-            const uint32_t ex = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)excl);
-            const uint32_t nhs = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)nh);
-            const uint32_t kk = t - ex;  // lanes beyond the round: anything, nothing is stored
-            const uint32_t k = select_bit32(Hs, kk < 32u ? kk : 31u) & 31u;
-            const uint32_t g = ((uint32_t)r * 64u + ul) * 32u + k;
-            const uint32_t rest = (Hs >> k) >> 1;
-            const uint32_t nxt = rest ? g + 1u + (uint32_t)__builtin_ctz(rest) : nhs;
-            const uint32_t o = g * WAH_BITS;
-            const uint32_t lit = __builtin_amdgcn_alignbit(row[(o >> 5) + 1u], row[o >> 5], o & 31u) & 0x7FFFu;
-            // a head is a fill exactly when its own group is all zeros or all ones: read off the literal the lane
-            // fetches anyway (the unit's F and O masks came over two more ds_bpermute before)
-            const bool all1 = lit == 0x7FFFu;
-            const uint32_t fill = (all1 ? 0xC000u : 0x8000u) | (nxt - g);
-            if (t < Wr) gdst[round_off + t] = (uint16_t)((lit == 0u || all1) ? fill : lit);
+            mk[64u + lane] = 0;
+            if (cnt && excl - t0 < 128u) mk[excl - t0] = (uint8_t)(lane + 1u);  // (excl < t0 wraps to a large number)
+            asm volatile("" ::: "memory");  // other lanes' stores: no forwarding of my own zero to the loads below
+            uint32_t u2[2];
+            u2[0] = wave_scan_max_incl_dpp((uint32_t)mk[lane]);  // one wave: its LDS operations stay in order
+            u2[1] = wave_scan_max_incl_dpp((uint32_t)mk[64u + lane]);
+            u2[0] = u2[0] > carry ? u2[0] : carry;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)u2[0], 63);
+            u2[1] = u2[1] > carry ? u2[1] : carry;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)u2[1], 63);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t ul = u2[h] - 1u;  // u >= 1: word 0 of a round is the first word of a unit
+                const uint32_t t = t0 + 64u * (uint32_t)h + lane;
+                const int ua = (int)(ul << 2);
+                const uint32_t Hs = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)m[r].H);
+                const uint32_t ex = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)excl);
+                const uint32_t nhs = (uint32_t)__builtin_amdgcn_ds_bpermute(ua, (int)nh);
+                const uint32_t kk = t - ex;  // lanes beyond the round: anything, nothing is stored
+                const uint32_t k = select_bit32(Hs, kk < 32u ? kk : 31u) & 31u;
+                const uint32_t g = ((uint32_t)r * 64u + ul) * 32u + k;
+                const uint32_t rest = (Hs >> k) >> 1;
+                const uint32_t nxt = rest ? g + 1u + (uint32_t)__builtin_ctz(rest) : nhs;
+                const uint32_t o = g * WAH_BITS;  // (a lane beyond the round holds some head of the round's last unit)
+                const uint32_t lit = __builtin_amdgcn_alignbit(row[(o >> 5) + 1u], row[o >> 5], o & 31u) & 0x7FFFu;
+                // a head is a fill exactly when its own group is all zeros or all ones: read off the literal the lane
+                // fetches anyway (the unit's F and O masks came over two more ds_bpermute before)
+                const bool all1 = lit == 0x7FFFu;
+                const uint32_t fill = (all1 ? 0xC000u : 0x8000u) | (nxt - g);
+                if (t < Wr) gdst[round_off + t] = (uint16_t)((lit == 0u || all1) ? fill : lit);
+            }
         }
         round_off += Wr;
     }

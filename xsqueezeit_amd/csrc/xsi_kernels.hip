@@ -1597,7 +1597,7 @@ static uint32_t wah_units_small_upl(const EncLines& L) {
 // xsi_device.hpp on it.  The sizing pass counts heads; the writing pass (after the layout is known) classifies
 // again and stores the words straight into the file image: no scratch copy of the words (10 GB at 64 976 x 2 M).
 constexpr int WAH_STAGE_Q = 16;  // 16 x 64 lanes x 8 bytes = 8 KiB
-constexpr uint32_t WAH_UNIT_SCRATCH_WORDS = 64u * (uint32_t)WAH_UNIT_ROUNDS + 16u;  // fh, 64-byte strip (behind a wave's row)
+constexpr uint32_t WAH_UNIT_SCRATCH_WORDS = 64u * (uint32_t)WAH_UNIT_ROUNDS + 32u;  // fh, 128-byte strip (behind a wave's row)
 // LDS words of a wave's row: every unit's 15 words (+ the word behind a literal), at least the row itself
 static uint32_t wah_units_row_words(uint32_t y_stride64) {
     const uint32_t units = ((y_stride64 * 64u + WAH_BITS - 1u) / WAH_BITS + 31u) / 32u;
