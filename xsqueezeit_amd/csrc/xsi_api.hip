@@ -329,6 +329,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
         WS(L.chain_sync, "enc.chain_sync", 4ull * CHAIN_SYNC_TOTAL_WORDS);
         WS(L.chain_lists, "enc.chain_lists", 4ull * CHAIN_LIST_WORDS);
         WS(L.chain_slices, "enc.chain_slices", CHAIN_SLICE_BYTES);
+        WS(L.chain_bmps, "enc.chain_bmps", CHAIN_BMP_BYTES);
     }
     // WAH16 words per line, worst case ceil(N/15) (+1 for the saturation split): encode once, then copy
     L.wah_scratch_stride = ((N + 14u) / 15u + 3u) & ~1u;  // even: rows stay 4-byte aligned for k_wah_write
@@ -412,7 +413,10 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     HIP_TRY(hipStreamSynchronize(s));
     chain_abort = (uint32_t)chain_prof[0];
     if (chain_rank_enc_multi_supported(L) && getenv("XSI_MULTI_PROF")) {
-        static const char* nm[7] = {"main+publish", "barrier+wait lists", "apply lists", "barrier", "slice scan+store+flag", "wait slices", "table copy"};
+        static const char* nm_lists[7] = {"main+publish", "barrier+wait lists", "apply lists", "barrier", "slice scan+store+flag", "wait slices", "table copy"};
+        static const char* nm_bmp[7] = {"M1 gathers", "clear + M2 deposits", "E1 bitmap store+flag", "wait bitmaps", "E3 slice OR+scan+store+flag", "wait slices", "E4 table copy"};
+        static const char* nm_hyb[7] = {"M1 gathers", "list pass + publish", "wait lists", "clear+apply+scan+table", "clear+deposits+bitmap store", "waits (bitmap form)", "slice + table copy"};
+        const char* const* nm = getenv("XSI_MULTI_LISTS") ? nm_lists : getenv("XSI_MULTI_BMP") ? nm_bmp : nm_hyb;
         uint64_t tot = 0;
         for (int i = 1; i < 8; ++i) tot += chain_prof[i];
         for (int i = 1; i < 8; ++i)

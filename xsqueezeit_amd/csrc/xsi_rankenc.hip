@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "xsi_device.hpp"
 
@@ -807,13 +808,668 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Round 5: the exchange chosen PER LINE by the line's minor allele count (known from the classification).
+//
+// What a line of k_chain_rank_enc_multi costs (phase clocks, round 4 / 5): the gathers + rank updates 3.2 us whatever
+// the line; a hand-off through L2 - store acknowledgements, flag, poll, loads - about 3 us; list append + apply grow with
+// the ones of the row.  Most WAH lines are sparse (allele counts are octave-uniform: at 500 000 haplotypes two of three
+// WAH lines have fewer than 49 152 minor alleles), so:
+//   minor <= thr   ONE hand-off: rank lists as in k_chain_rank_enc_multi, but EVERY member applies ALL lists to a
+//                  bitmap of the whole row in its own LDS and scans that row itself: no slices, no second hand-off, no
+//                  table copy;
+//   minor >  thr   BITMAPS instead of lists: a member deposits the ones of its haplotypes into a private bitmap of the
+//                  whole row in its LDS (ds_or_b32, as the one-workgroup kernel does), stores it (N / 8 bytes) through
+//                  the XCD's L2, and the owner of a slice ORs the S members' pieces of it (8 bytes per thread and
+//                  member, no filter, no per-entry work), scans it and publishes finished table entries that every
+//                  member copies: two hand-offs whose cost does not depend on the ones of the row.
+// The bitmap of a row (N / 8 bytes) cannot stand next to the rank-select table (S x 16 KiB of the 160 KiB) while that is
+// being gathered from: it takes the place of the table's first half once every wave is through its gathers (barrier,
+// clear, barrier), so the deposits of a bitmap line are a pass of their own behind the gathers; the appends of a list
+// line need no such room and stay fused with the gathers.
+// A member can run at most one line ahead of another (to finish line j + 1 it needs every member's lists or bitmap of
+// that line, which a member publishes behind its gathers of line j): lists and their flags are double-buffered by the
+// parity of the line's sequence number.  Bitmaps and slices need no second buffer: a member passes the slice poll of a
+// line only when every member has flagged its slice, i.e. has finished reading the bitmaps, and passes the bitmap poll
+// of a later line only when every member has flagged its bitmap, i.e. has finished copying the slices.
+// ------------------------------------------------------------------------------------------
+struct RankEncHybArgs {
+    const uint32_t* wah_lines;
+    const uint32_t* src;
+    uint32_t src_stride_w;
+    const uint32_t* cnt;    // ones of every binary line (the classification's counts)
+    uint32_t* dst;          // permuted rows y by rank
+    uint32_t dst_stride_w;  // words per row
+    uint32_t N;
+    uint32_t n_blocks;
+    uint32_t S;             // workgroups per block
+    uint32_t gpx;           // groups per XCD slot: the grid is 8 * gpx * S workgroups
+    uint32_t thr;           // lines with at most this many minor alleles travel as lists
+    uint32_t* sync;         // [0] abort, [2] profile records written
+    uint32_t* list_flags;   // [group][parity][member][32 words]: per wave {length, seq}
+    uint32_t* lists;        // [group][parity][S * 16 waves][MULTI_LIST_CAP] ranks, whole 64-entry stores (padding: ~0)
+    uint64_t* flags;        // [group][16]: [0, 8) bitmap flags (seq), [8, 16) slice flags (seq << 32 | ones of the slice)
+    uint32_t* bmps;         // [group][member][S * 2048] words: the members' private bitmaps of the row
+    v4u* slices;            // [group][member][1024]: two table entries each
+    uint32_t test_desert;   // testing only: member 1 of every group leaves at once
+    uint32_t prof;          // XSI_MULTI_PROF = 1 + workgroup + (wave << 16): that wave records (tag << 56 | 100 MHz clock)
+    uint32_t* xcc_ids;      // [group][8]: 1 + XCC_ID of each member (handshake at the start of the launch)
+    uint64_t timeout_ticks;
+    uint64_t* prof_buf;
+    uint32_t prof_cap;
+};
+
+template <bool PROF>
+__global__ void __launch_bounds__(1024) k_chain_rank_enc_hyb(const EncBlock* __restrict__ eblocks, RankEncHybArgs A) {
+    constexpr uint32_t T = 1024, W = 16;
+    constexpr int E = 64, G = 8, SMAX = 8;
+    constexpr uint32_t SL_WORDS = 2048u;  // row words of a slice: two per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t S = A.S;
+    const uint32_t tab_bytes = S * SL_WORDS * 8u;
+    uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + tab_bytes);  // [0,64) totals for the scans, [64,80) list lengths of my waves
+    uint32_t* ring_all = wtot + 128;                                 // [16 waves][128] ranks on their way to the lists
+    const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    if (tab_lds != 0u) __builtin_trap();  // table and bitmap start at LDS address 0 (gathers and deposits rely on it)
+    const uint32_t N = A.N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    const uint32_t group = xcd * A.gpx + q / S, member = q % S, n_groups = 8u * A.gpx;
+    const uint32_t n_lists = S * W;
+    if (A.test_desert && member == 1u) return;
+    const uint32_t bmp_units = S * (SL_WORDS / 4u);  // 16-byte units of a bitmap
+
+    const uint32_t row_bytes = ((N + 63u) / 64u) * 8u;  // bytes of an input row that hold haplotypes
+    auto in_rsrc = [&](uint32_t line) -> v4u {
+        const uint64_t base = reinterpret_cast<uint64_t>(A.src + (size_t)line * A.src_stride_w);
+        v4u d;
+        d[0] = (uint32_t)base;
+        d[1] = (uint32_t)(base >> 32) & 0xFFFFu;
+        d[2] = row_bytes;
+        d[3] = 0x00020000u;
+        return d;
+    };
+    auto group_rsrc = [&](const void* base, uint32_t bytes) -> __amdgpu_buffer_rsrc_t {
+        const uint64_t v = reinterpret_cast<uint64_t>(base);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rs_lflags = group_rsrc(A.list_flags + (size_t)group * 2u * S * 32u, 2u * S * 128u);
+    const __amdgpu_buffer_rsrc_t rs_bmps = group_rsrc(A.bmps + (size_t)group * S * S * SL_WORDS, S * S * SL_WORDS * 4u);
+    const __amdgpu_buffer_rsrc_t rs_slices = group_rsrc(A.slices + (size_t)group * S * 1024u, S * 16384u);
+    uint32_t* const glists = A.lists + (size_t)group * 2u * n_lists * MULTI_LIST_CAP;
+    uint64_t* const gbflags = A.flags + (size_t)group * 16u;
+    uint64_t* const gsflags = gbflags + 8u;
+    uint64_t t_start = 0;
+    auto give_up = [&](uint32_t& spins) -> bool {  // every 32 polls: has the launch been aborted / has this wait run out?
+        if ((++spins & 31u) != 0u) return false;
+        if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(A.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return true;
+        const uint64_t now = wall_clock64();
+        if (!t_start) t_start = now;
+        if (now - t_start > A.timeout_ticks) {
+            __hip_atomic_store(A.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+        return false;
+    };
+    // phase records of one wave (every other wave stores into one dummy slot behind the buffer: no branch)
+    const bool profiling = PROF && blockIdx.x == (A.prof & 0xFFFFu) - 1u && w == (A.prof >> 16);
+    uint32_t pidx = profiling ? 0u : A.prof_cap;
+    const uint32_t pstep = profiling ? 1u : 0u;
+    auto prof = [&](uint32_t i) {
+        if constexpr (PROF) {
+            const uint64_t now = wall_clock64();
+            uint64_t* dst = A.prof_buf + (pidx < A.prof_cap ? pidx : A.prof_cap);
+            if (lane == 0) *dst = ((uint64_t)i << 56) | (now & 0xFFFFFFFFFFFFFFull);
+            pidx += pstep;
+        }
+    };
+    using LdsV4 = __attribute__((address_space(3))) v4u;
+    // every wave is done with the table: the bitmap takes its place
+    auto clear_bitmap = [&]() {
+        lds_barrier();
+        uint32_t tid_here = tid;
+        asm volatile("" : "+v"(tid_here));
+#pragma unroll
+        for (int k = 0; k < SMAX / 2; ++k) {
+            const uint32_t unit = (uint32_t)k * T + tid_here;
+            if (unit < bmp_units) *reinterpret_cast<LdsV4*>((uintptr_t)(unit * 16u)) = v4u{0u, 0u, 0u, 0u};
+        }
+        lds_barrier();
+    };
+    auto deposit = [&](uint64_t xm, uint32_t rr) {
+        if (xm) {
+            if (__builtin_amdgcn_inverse_ballot_w64(xm)) {
+                LdsU32* p = reinterpret_cast<LdsU32*>((uintptr_t)((rr >> 3) & 0x1FFFCu));
+                __hip_atomic_fetch_or(p, 1u << (rr & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
+
+    // ---- ONE hand-off: the row `rank` whose ones (zeros, if `dense`) the waves have published as lists under `seq`
+    auto exchange_lists = [&](uint32_t rank, uint32_t seq, bool dense, uint32_t& Zout) -> bool {
+        const uint32_t par = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seq & 1u));
+        uint32_t cnt_l = 0;
+        {
+            const uint32_t my_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)wtot[64u + w]);
+            if (lane == 0u) {
+                u32x2 fl;
+                fl[0] = my_len;
+                fl[1] = seq;
+                __builtin_amdgcn_raw_buffer_store_b64(fl, rs_lflags, w * 8u, (par * S + member) * 128u, 0);
+            }
+            const uint32_t ml = lane < S ? lane : 0u;
+            uint32_t spins = 0;
+            t_start = 0;
+            for (;;) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_lflags, ml * 128u + w * 8u, par * S * 128u, 16);
+                if (__builtin_amdgcn_ballot_w64(v[1] != seq) == 0ull) {
+                    cnt_l = lane < S ? v[0] : 0u;
+                    break;
+                }
+                if (give_up(spins)) return false;
+                __builtin_amdgcn_s_sleep(0);
+            }
+        }
+        prof(2);  // wait for the lists
+        // the first pieces travel while the bitmap is cleared
+        const uint32_t* lst = glists + (size_t)(par * n_lists + w) * MULTI_LIST_CAP;  // + k * 16 lists: member k's
+        uint32_t cnt[SMAX], longest = 0;
+#pragma unroll
+        for (int k = 0; k < SMAX; ++k) {
+            cnt[k] = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, k);
+            longest = cnt[k] > longest ? cnt[k] : longest;
+        }
+        v4u rk[SMAX];
+        auto load_piece = [&](int k, uint32_t i0) {
+            // lists are whole 64-entry stores; beyond a list the range check returns 0 (no memory request), masked below
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(lst + (size_t)k * 16u * MULTI_LIST_CAP), 0, (int)(cnt[k] * 4u), 0x00020000);
+            rk[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (i0 + lane * 4u) * 4u, 0, 16);
+        };
+#pragma unroll
+        for (int k = 0; k < SMAX; ++k) {
+            load_piece(k, 0u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        clear_bitmap();
+        // ---- every list, every rank
+        for (uint32_t i0 = 0; i0 < longest; i0 += 256u) {
+#pragma unroll
+            for (int k = 0; k < SMAX; ++k) {
+                if (i0 + lane * 4u < cnt[k]) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t e = rk[k][u];
+                        if (e != ~0u) {  // (padding of a list's last 64-entry store)
+                            LdsU32* p = reinterpret_cast<LdsU32*>((uintptr_t)((e >> 3) & 0x1FFFCu));
+                            __hip_atomic_fetch_or(p, 1u << (e & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+                load_piece(k, i0 + 256u);
+            }
+        }
+        lds_barrier();  // the row is complete
+        // ---- the whole row -> table: thread t holds the 16-byte units t, t + 1024, ... (four words each)
+        uint32_t tid_here = tid;
+        asm volatile("" : "+v"(tid_here));
+        v4u wv[SMAX / 2];
+        uint32_t cu[SMAX / 2], inc[SMAX / 2];
+#pragma unroll
+        for (int i = 0; i < SMAX / 2; ++i) {
+            const uint32_t unit = (uint32_t)i * T + tid_here;
+            v4u v = v4u{0u, 0u, 0u, 0u};
+            if (unit < bmp_units) v = *reinterpret_cast<const LdsV4*>((uintptr_t)(unit * 16u));
+            if (dense) {  // the lists named the row's zeros: complement, positions at or beyond N stay zero
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t p0 = (unit * 4u + (uint32_t)u) * 32u;
+                    const uint32_t m = p0 + 32u <= N ? ~0u : (p0 >= N ? 0u : (1u << (N - p0)) - 1u);
+                    v[u] = ~v[u] & m;
+                }
+            }
+            wv[i] = v;
+            cu[i] = (uint32_t)__popc(v[0]) + (uint32_t)__popc(v[1]) + (uint32_t)__popc(v[2]) + (uint32_t)__popc(v[3]);
+            inc[i] = wave_scan_incl_dpp(cu[i]);
+            if (lane == 63u) wtot[(uint32_t)i * W + w] = inc[i];
+        }
+        lds_barrier();  // every word of the row is in registers: the table may take its place; the wave totals are in LDS
+        const uint32_t sc = wave_scan_incl_dpp(wtot[lane]);
+        const uint32_t ones = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+#pragma unroll
+        for (int i = 0; i < SMAX / 2; ++i) {
+            const uint32_t unit = (uint32_t)i * T + tid_here;
+            const uint32_t seg = (uint32_t)i * W + w;
+            const uint32_t base = seg ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)seg - 1) : 0u;
+            const uint32_t p0 = base + inc[i] - cu[i];
+            const uint32_t p1 = p0 + (uint32_t)__popc(wv[i][0]);
+            const uint32_t p2 = p1 + (uint32_t)__popc(wv[i][1]);
+            const uint32_t p3 = p2 + (uint32_t)__popc(wv[i][2]);
+            if (unit < bmp_units) {
+                *reinterpret_cast<LdsV4*>((uintptr_t)(unit * 32u)) = v4u{wv[i][0], p0, wv[i][1], p1};
+                *reinterpret_cast<LdsV4*>((uintptr_t)(unit * 32u + 16u)) = v4u{wv[i][2], p2, wv[i][3], p3};
+                // my slice of the row for the WAH pass (rows are whole 16-byte units)
+                if ((unit >> 9) == member && unit * 4u < A.dst_stride_w)
+                    *reinterpret_cast<v4u*>(A.dst + (size_t)rank * A.dst_stride_w + unit * 4u) = wv[i];
+            }
+        }
+        Zout = N - ones;
+        lds_barrier();
+        prof(3);  // clear + apply + scan + table
+        return true;
+    };
+
+    // ---- TWO hand-offs: the row `rank` whose ones the waves have just deposited into the bitmap
+    auto exchange_bmp = [&](uint32_t rank, uint32_t seq, uint32_t& Zout) -> bool {
+        uint32_t tid_here = tid;
+        asm volatile("" : "+v"(tid_here));  // addresses are formed here, not kept (spilled) across the lines
+        lds_barrier();  // every deposit has landed
+        {
+            v4u b[SMAX / 2];
+#pragma unroll
+            for (int k = 0; k < SMAX / 2; ++k) {
+                const uint32_t unit = (uint32_t)k * T + tid_here;
+                b[k] = *reinterpret_cast<const LdsV4*>((uintptr_t)((unit < bmp_units ? unit : 0u) * 16u));
+            }
+#pragma unroll
+            for (int k = 0; k < SMAX / 2; ++k) {
+                const uint32_t unit = (uint32_t)k * T + tid_here;
+                if (unit < bmp_units) __builtin_amdgcn_raw_buffer_store_b128(b[k], rs_bmps, unit * 16u, member * S * 8192u, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my part of the bitmap has left
+        __syncthreads();
+        if (tid == 0)
+            *reinterpret_cast<volatile __attribute__((address_space(1))) uint64_t*>(
+                (__attribute__((address_space(1))) uint64_t*)(gbflags + member)) = (uint64_t)seq;
+        prof(4);  // clear + deposits + bitmap stored, flagged
+        {
+            const uint64_t* fp = gbflags + (lane < S ? lane : 0u);
+            uint32_t spins = 0;
+            t_start = 0;
+            for (;;) {
+                const uint64_t v = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_ballot_w64((uint32_t)v != seq) == 0ull) break;
+                if (give_up(spins)) return false;
+                __builtin_amdgcn_s_sleep(0);
+            }
+        }
+        prof(5);  // wait for the bitmaps
+        uint32_t ones_slice;
+        {
+            u32x2 pc[SMAX];
+#pragma unroll
+            for (int k = 0; k < SMAX; ++k) {
+                pc[k] = u32x2{0u, 0u};
+                if ((uint32_t)k < S) pc[k] = __builtin_amdgcn_raw_buffer_load_b64(rs_bmps, member * 8192u + tid_here * 8u, (uint32_t)k * S * 8192u, 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // all S loads in flight before the first is consumed
+            uint2 v = make_uint2(0u, 0u);
+#pragma unroll
+            for (int k = 0; k < SMAX; ++k) {
+                v.x |= pc[k][0];
+                v.y |= pc[k][1];
+            }
+            const uint32_t c = (uint32_t)__popc(v.x) + (uint32_t)__popc(v.y);
+            const uint32_t inc = wave_scan_incl_dpp(c);
+            if (lane == 63u) wtot[w] = inc;
+            lds_barrier();
+            const uint32_t sc = row16_scan_incl(lane < W ? wtot[lane] : 0u);
+            ones_slice = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
+            const uint32_t base = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
+            const uint32_t pre0 = base + inc - c;
+            v4u ent;
+            ent[0] = v.x;
+            ent[1] = pre0;
+            ent[2] = v.y;
+            ent[3] = pre0 + (uint32_t)__popc(v.x);
+            __builtin_amdgcn_raw_buffer_store_b128(ent, rs_slices, tid_here * 16u, member * 16384u, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my entries have left
+            __syncthreads();
+            if (tid == 0)
+                *reinterpret_cast<volatile __attribute__((address_space(1))) uint64_t*>(
+                    (__attribute__((address_space(1))) uint64_t*)(gsflags + member)) = ((uint64_t)seq << 32) | ones_slice;
+            // my part of the row for the WAH pass: behind the flag, nobody in the chain waits for this store
+            const uint32_t roww = member * SL_WORDS + 2u * tid_here;  // rows are whole 16-byte units
+            if (roww < A.dst_stride_w) *reinterpret_cast<uint2*>(A.dst + (size_t)rank * A.dst_stride_w + roww) = v;
+        }
+        prof(6);  // slice ORed, scanned, stored, flagged
+        uint32_t tot_l;
+        {
+            const uint64_t* fp = gsflags + (lane < S ? lane : 0u);
+            uint32_t spins = 0;
+            t_start = 0;
+            for (;;) {
+                const uint64_t v = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_ballot_w64((uint32_t)(v >> 32) != seq) == 0ull) {
+                    tot_l = lane < S ? (uint32_t)v : 0u;
+                    break;
+                }
+                if (give_up(spins)) return false;
+                __builtin_amdgcn_s_sleep(0);
+            }
+        }
+        prof(5);  // wait for the slices
+        const uint32_t incl = wave_scan_incl_dpp(tot_l);
+        {
+            v4u t[SMAX];
+#pragma unroll
+            for (int k = 0; k < SMAX; ++k) {
+                t[k] = v4u{0u, 0u, 0u, 0u};
+                if ((uint32_t)k < S) t[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_slices, tid_here * 16u, (uint32_t)k * 16384u, 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < SMAX; ++k)
+                if ((uint32_t)k < S) {
+                    const uint32_t b = k ? (uint32_t)__builtin_amdgcn_readlane((int)incl, k - 1) : 0u;
+                    v4u e = t[k];
+                    e[1] += b;
+                    e[3] += b;
+                    *reinterpret_cast<LdsV4*>((uintptr_t)((uint32_t)k * 16384u + tid_here * 16u)) = e;
+                }
+        }
+        Zout = N - (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        lds_barrier();
+        prof(6);  // table copied
+        return true;
+    };
+
+    for (uint32_t i = tid; i < 128u; i += T) wtot[i] = 0;
+    __syncthreads();
+    // One-time handshake: the members of a group must share an XCD (see k_chain_rank_enc_multi).
+    {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc = (xcc & 15u) + 1u;
+        uint32_t* ids = A.xcc_ids + group * 8u;
+        if (tid == 0) __hip_atomic_store(ids + member, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spins = 0;
+        t_start = 0;
+        for (;;) {
+            const uint32_t v = __hip_atomic_load(ids + (lane < S ? lane : member), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_ballot_w64(v == 0u && lane != member) == 0ull) {
+                if (__builtin_amdgcn_ballot_w64(v != xcc && lane != member) != 0ull) {  // spread over several XCDs: not this kernel's case
+                    __hip_atomic_store(A.sync, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+                break;
+            }
+            if (give_up(spins)) return;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    prof(7);
+    uint32_t seq = 0;
+    const uint32_t c0 = member * 1024u + w * (uint32_t)E;  // my first chunk of the row
+    const uint32_t full_chunks = N >> 6, rem_bits = N & 63u;
+    for (uint32_t blk = group; blk < A.n_blocks; blk += n_groups) {
+        const EncBlock& B = eblocks[blk];
+        if (B.has_haploid) continue;  // the position-major kernels take the blocks with fully haploid lines
+        const uint32_t wah_first = B.wah_first, n_wah = B.n_wah;
+        if (n_wah == 0) continue;
+        const ConstU32* lines = as_const(A.wah_lines) + wah_first;
+        uint32_t lane_here = lane;
+        asm volatile("" : "+v"(lane_here));  // the identity ranks are formed in this block's code, not kept across the blocks
+        uint32_t r[E];
+        static_for<0, E>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            const uint32_t h = (c0 + (uint32_t)e) * 64u + lane_here;
+            r[e] = h < N ? h : 0u;
+        });
+        // ---- lists: ranks on their way to my wave's list pass through a linear 128-entry buffer in LDS, so that they
+        // leave as whole 256-byte stores (k_chain_rank_enc_multi)
+        uint32_t n_out = 0;
+        uint32_t* my_list = nullptr;
+        uint32_t* ring = ring_all + w * 128u;
+        const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(ring));
+        uint32_t wpos = ring_lds;
+        auto open_list = [&](uint32_t sq) {
+            wpos = ring_lds;
+            n_out = 0;
+            my_list = glists + (size_t)((sq & 1u) * n_lists + member * W + w) * MULTI_LIST_CAP;
+        };
+        auto flush64 = [&]() {
+            my_list[n_out + lane] = ring[lane];
+            n_out += 64u;
+            const uint32_t rest = (wpos - ring_lds - 256u) >> 2;  // entries behind the 64 that leave
+            const uint32_t v = ring[64u + lane];
+            if (lane < rest) ring[lane] = v;
+            wpos -= 256u;
+        };
+        using LdsRing = __attribute__((address_space(3))) uint32_t;
+        auto append = [&](uint64_t xm, uint32_t rr) {
+            if (xm) {
+                if (__builtin_amdgcn_inverse_ballot_w64(xm)) {
+                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(xm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)xm, 0u));
+                    *reinterpret_cast<LdsRing*>((uintptr_t)(wpos + (slot << 2))) = rr;
+                }
+                wpos += 4u * (uint32_t)__popcll(xm);
+                if (wpos >= ring_lds + 256u) flush64();
+            }
+        };
+        // the rest of the list, padded to a whole 64-entry store with entries that mean nothing (~0); its length goes to
+        // LDS for the flag; the wave waits for its stores
+        auto publish = [&]() {
+            const uint32_t left = (wpos - ring_lds) >> 2;
+            if (left) {
+                my_list[n_out + lane] = lane < left ? ring[lane] : ~0u;
+                n_out += 64u;
+            }
+            if (lane == 0) wtot[64u + w] = n_out;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        auto complement = [&](uint64_t x, uint32_t chunk) -> uint64_t {
+            uint32_t fc = full_chunks;
+            asm volatile("" : "+s"(fc));  // the mask is formed where it is used (hoisted for all 64 chunks it spills 128 SGPRs)
+            const uint64_t vm = chunk < fc ? ~0ull : (chunk == fc && rem_bits ? (1ull << rem_bits) - 1ull : 0ull);
+            return ~x & vm;
+        };
+        // how the row of a line travels: 0 = bitmap, 1 = list of its ones, 2 = list of its zeros
+        auto kind_of = [&](uint32_t line) -> uint32_t {
+            const uint32_t c = as_const(A.cnt)[line];
+            const bool dense = c * 2u > N;
+            return (dense ? N - c : c) <= A.thr ? (dense ? 2u : 1u) : 0u;
+        };
+        auto deposit_pass = [&](v4u rsn) {
+            static_for<0, E / G>([&](auto gc) {
+                constexpr int g0 = decltype(gc)::value * G;
+                uint64_t xn[G];
+                sbuf_load_chunks<G>(rsn, c0 + (uint32_t)g0, xn);
+                static_for<0, G>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    deposit(xn[e], r[g0 + e]);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        // line 0: ranks are the identity, its row is the input row itself (bits at or beyond N are zero)
+        uint32_t Z = 0;
+        uint32_t kind = kind_of(lines[0]);
+        ++seq;
+        if (kind) {
+            const v4u rs0 = in_rsrc(lines[0]);
+            open_list(seq);
+            static_for<0, E / G>([&](auto gc) {
+                constexpr int g0 = decltype(gc)::value * G;
+                uint64_t x0[G];
+                sbuf_load_chunks<G>(rs0, c0 + (uint32_t)g0, x0);
+                if (kind == 2u) {
+                    static_for<0, G>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        x0[e] = complement(x0[e], c0 + (uint32_t)(g0 + e));
+                    });
+                }
+                static_for<0, G>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    append(x0[e], r[g0 + e]);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            publish();
+            if (!exchange_lists(wah_first, seq, kind == 2u, Z)) return;
+        } else {
+            clear_bitmap();
+            deposit_pass(in_rsrc(lines[0]));
+            if (!exchange_bmp(wah_first, seq, Z)) return;
+        }
+        auto prefetch_row = [&](uint32_t line) -> uint2 {  // my workgroup's 8 KiB of the input row, into L2
+            const uint2* rowp = reinterpret_cast<const uint2*>(A.src + (size_t)line * A.src_stride_w) + member * 1024u;
+            return (member * 1024u + tid) * 8u < row_bytes ? rowp[tid] : make_uint2(0u, 0u);
+        };
+        for (uint32_t j = 0; j < n_wah; ++j) {
+            const bool more = j + 1u < n_wah;
+            const uint2 pf = prefetch_row(lines[j + 2u < n_wah ? j + 2u : j]);
+            const v4u rsc = in_rsrc(lines[j]);
+            kind = more ? kind_of(lines[j + 1u]) : 0u;
+            if (kind) {
+                // ---- gathers + rank updates, the next line's flagged haplotypes appended to my list on the way
+                const v4u rsn = in_rsrc(lines[j + 1u]);
+                open_list(seq + 1u);
+                static_for<0, E / G>([&](auto gc) {
+                    constexpr int g0 = decltype(gc)::value * G;
+                    uint64_t xc[G], xn[G];
+                    u32x2 pr[G];
+                    sbuf_load_chunks<G>(rsc, c0 + (uint32_t)g0, xc);
+                    sbuf_load_chunks<G>(rsn, c0 + (uint32_t)g0, xn);
+                    static_for<0, G>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        pr[e] = *reinterpret_cast<const LdsU2*>((uintptr_t)((r[g0 + e] >> 2) & 0x1FFF8u));  // the table starts at LDS address 0
+                    });
+                    if (kind == 2u) {
+                        static_for<0, G>([&](auto ec) {
+                            constexpr int e = decltype(ec)::value;
+                            xn[e] = complement(xn[e], c0 + (uint32_t)(g0 + e));
+                        });
+                    }
+                    static_for<0, G>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        const uint32_t rr = r[g0 + e];
+                        const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
+                        const uint32_t rn = __builtin_amdgcn_inverse_ballot_w64(xc[e]) ? Z + ob : rr - ob;
+                        r[g0 + e] = rn;
+                        append(xn[e], rn);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                asm volatile("" ::"v"(pf.x), "v"(pf.y));
+                publish();
+                prof(0);  // gathers + appends + publish
+                ++seq;
+                if (!exchange_lists(wah_first + j + 1u, seq, kind == 2u, Z)) return;
+            } else {
+                // ---- gathers + rank updates alone
+                static_for<0, E / G>([&](auto gc) {
+                    constexpr int g0 = decltype(gc)::value * G;
+                    uint64_t xc[G];
+                    u32x2 pr[G];
+                    sbuf_load_chunks<G>(rsc, c0 + (uint32_t)g0, xc);
+                    static_for<0, G>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        pr[e] = *reinterpret_cast<const LdsU2*>((uintptr_t)((r[g0 + e] >> 2) & 0x1FFF8u));
+                    });
+                    static_for<0, G>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        const uint32_t rr = r[g0 + e];
+                        const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
+                        r[g0 + e] = __builtin_amdgcn_inverse_ballot_w64(xc[e]) ? Z + ob : rr - ob;
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                asm volatile("" ::"v"(pf.x), "v"(pf.y));
+                prof(1);  // gathers alone
+                if (more) {
+                    clear_bitmap();
+                    deposit_pass(in_rsrc(lines[j + 1u]));
+                    ++seq;
+                    if (!exchange_bmp(wah_first + j + 1u, seq, Z)) return;
+                }
+            }
+        }
+        // (the next block's first row: a list pass touches neither table nor bitmap, clear_bitmap starts with a barrier)
+    }
+    if constexpr (PROF) {
+        if (profiling && lane == 0) A.sync[2] = pidx;
+    }
+}
+
 bool chain_rank_enc_multi_supported(const EncLines& L) {
     const bool off = getenv("XSI_NO_RANKENC_MULTI") != nullptr;  // read per call (tests force the other kernel)
-    return !off && !L.no_multi && L.chain_sync && L.chain_lists && L.chain_slices && L.N > 65536u && L.N <= 524288u &&
+    return !off && !L.no_multi && L.chain_sync && L.chain_lists && L.chain_slices && L.chain_bmps && L.N > 65536u && L.N <= 524288u &&
            (L.y_stride64 % 2u) == 0u;
 }
 
+static hipError_t launch_rank_encode_hyb_grid(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L, int cus) {
+    RankEncHybArgs A{};
+    A.wah_lines = L.wah_lines;
+    A.src = L.planes;
+    A.src_stride_w = L.plane_stride_w;
+    A.cnt = L.cnt;
+    A.dst = reinterpret_cast<uint32_t*>(L.yrows);
+    A.dst_stride_w = L.y_stride64 * 2u;
+    A.N = L.N;
+    A.n_blocks = n_blocks;
+    A.S = (L.N + 65535u) / 65536u;
+    A.gpx = (uint32_t)cus / 8u / A.S;
+    if (A.gpx < 1u) return hipErrorInvalidValue;
+    while (A.gpx > 1u && 8u * (A.gpx - 1u) >= n_blocks) --A.gpx;  // no more groups than blocks need
+    if (8u * A.gpx * A.S > CHAIN_MAX_WGS) return hipErrorInvalidValue;
+    static_assert(CHAIN_SLICEFLAG_WORDS >= (CHAIN_MAX_WGS / 2u) * 32u, "16 flags of 8 bytes per group");
+    const char* thr = getenv("XSI_MULTI_LIST_THR");
+    A.thr = thr ? (uint32_t)atoi(thr) : 49152u;
+    A.sync = L.chain_sync;
+    A.list_flags = L.chain_sync + CHAIN_SYNC_WORDS;
+    A.flags = reinterpret_cast<uint64_t*>(L.chain_sync + CHAIN_SYNC_WORDS + CHAIN_LISTFLAG_WORDS);
+    A.lists = L.chain_lists;
+    A.bmps = L.chain_bmps;
+    A.slices = reinterpret_cast<v4u*>(L.chain_slices);
+    A.test_desert = getenv("XSI_MULTI_TEST_DESERT") ? 1u : 0u;
+    A.prof = getenv("XSI_MULTI_PROF") ? (uint32_t)atoi(getenv("XSI_MULTI_PROF")) : 0u;
+    A.xcc_ids = L.chain_sync + CHAIN_SYNC_WORDS + CHAIN_LISTFLAG_WORDS + CHAIN_SLICEFLAG_WORDS;
+    const char* tmo = getenv("XSI_MULTI_TIMEOUT_MS");
+    A.timeout_ticks = 100000ull * (uint64_t)(tmo && atoi(tmo) > 0 ? atoi(tmo) : 2000);
+    hipError_t e = hipMemsetAsync(L.chain_sync, 0, 4ull * CHAIN_SYNC_TOTAL_WORDS, s);
+    if (e != hipSuccess) return e;
+    static uint64_t* prof_buf = nullptr;  // (profiling runs only; never freed)
+    constexpr uint32_t PROF_CAP = 1u << 20;
+    if (A.prof && !prof_buf && hipMalloc(&prof_buf, 8ull * PROF_CAP + 8) != hipSuccess) return hipErrorOutOfMemory;
+    A.prof_buf = prof_buf;
+    A.prof_cap = PROF_CAP;
+    const uint32_t lds = A.S * 16384u + 512u + 16u * 128u * 4u;
+    auto kern = A.prof ? &k_chain_rank_enc_hyb<true> : &k_chain_rank_enc_hyb<false>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    kern<<<dim3(8u * A.gpx * A.S), dim3(1024), lds, s>>>(blocks, A);
+    e = hipGetLastError();
+    if (A.prof && e == hipSuccess) {  // phase report of the chosen wave: per tag the time that ended with it
+        e = hipStreamSynchronize(s);
+        uint32_t n = 0;
+        if (e == hipSuccess) e = hipMemcpy(&n, L.chain_sync + 2, 4, hipMemcpyDeviceToHost);
+        if (n > PROF_CAP) n = PROF_CAP;
+        std::vector<uint64_t> rec(n);
+        if (e == hipSuccess && n) e = hipMemcpy(rec.data(), prof_buf, 8ull * n, hipMemcpyDeviceToHost);
+        static const char* nm[8] = {"gathers+appends+publish", "gathers alone", "wait lists", "clear+apply+scan+table",
+                                    "clear+deposits+bitmap store", "waits (bitmap form)", "slice / table copy", "start"};
+        uint64_t sum[8] = {0}, cntv[8] = {0};
+        for (uint32_t i = 1; i < n; ++i) {
+            const uint32_t tag = (uint32_t)(rec[i] >> 56) & 7u;
+            sum[tag] += (rec[i] - rec[i - 1]) & 0xFFFFFFFFFFFFFFull;
+            cntv[tag]++;
+        }
+        for (int t = 0; t < 7; ++t)
+            fprintf(stderr, "[xsi hyb prof] %-28s %9.3f ms  (%llu records, %.2f us each)\n", nm[t], sum[t] * 1e-5,
+                    (unsigned long long)cntv[t], cntv[t] ? sum[t] * 1e-2 / cntv[t] : 0.0);
+    }
+    return e;
+}
+
 static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L, int cus) {
+    if (!getenv("XSI_MULTI_LISTS")) return launch_rank_encode_hyb_grid(s, blocks, n_blocks, L, cus);
     RankEncMultiArgs A{};
     A.wah_lines = L.wah_lines;
     A.src = L.planes;
