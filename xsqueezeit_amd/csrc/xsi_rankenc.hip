@@ -996,6 +996,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_hyb(const EncBlock* __r
             __builtin_amdgcn_sched_barrier(0);
         }
         clear_bitmap();
+        prof(8);  // bitmap cleared
         // ---- every list, every rank
         for (uint32_t i0 = 0; i0 < longest; i0 += 256u) {
 #pragma unroll
@@ -1014,6 +1015,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_hyb(const EncBlock* __r
             }
         }
         lds_barrier();  // the row is complete
+        prof(9);  // lists applied
         // ---- the whole row -> table: thread t holds the 16-byte units t, t + 1024, ... (four words each)
         uint32_t tid_here = tid;
         asm volatile("" : "+v"(tid_here));
@@ -1038,6 +1040,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_hyb(const EncBlock* __r
             if (lane == 63u) wtot[(uint32_t)i * W + w] = inc[i];
         }
         lds_barrier();  // every word of the row is in registers: the table may take its place; the wave totals are in LDS
+        prof(10);  // row read + wave scans
         const uint32_t sc = wave_scan_incl_dpp(wtot[lane]);
         const uint32_t ones = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
 #pragma unroll
@@ -1068,6 +1071,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_hyb(const EncBlock* __r
         uint32_t tid_here = tid;
         asm volatile("" : "+v"(tid_here));  // addresses are formed here, not kept (spilled) across the lines
         lds_barrier();  // every deposit has landed
+        prof(11);  // clear + deposits
         {
             v4u b[SMAX / 2];
 #pragma unroll
@@ -1327,61 +1331,45 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_hyb(const EncBlock* __r
             const uint2 pf = prefetch_row(lines[j + 2u < n_wah ? j + 2u : j]);
             const v4u rsc = in_rsrc(lines[j]);
             kind = more ? kind_of(lines[j + 1u]) : 0u;
-            if (kind) {
-                // ---- gathers + rank updates, the next line's flagged haplotypes appended to my list on the way
-                const v4u rsn = in_rsrc(lines[j + 1u]);
-                open_list(seq + 1u);
-                static_for<0, E / G>([&](auto gc) {
-                    constexpr int g0 = decltype(gc)::value * G;
-                    uint64_t xc[G], xn[G];
-                    u32x2 pr[G];
-                    sbuf_load_chunks<G>(rsc, c0 + (uint32_t)g0, xc);
-                    sbuf_load_chunks<G>(rsn, c0 + (uint32_t)g0, xn);
-                    static_for<0, G>([&](auto ec) {
-                        constexpr int e = decltype(ec)::value;
-                        pr[e] = *reinterpret_cast<const LdsU2*>((uintptr_t)((r[g0 + e] >> 2) & 0x1FFF8u));  // the table starts at LDS address 0
-                    });
-                    if (kind == 2u) {
-                        static_for<0, G>([&](auto ec) {
-                            constexpr int e = decltype(ec)::value;
-                            xn[e] = complement(xn[e], c0 + (uint32_t)(g0 + e));
-                        });
-                    }
-                    static_for<0, G>([&](auto ec) {
-                        constexpr int e = decltype(ec)::value;
-                        const uint32_t rr = r[g0 + e];
-                        const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
-                        const uint32_t rn = __builtin_amdgcn_inverse_ballot_w64(xc[e]) ? Z + ob : rr - ob;
-                        r[g0 + e] = rn;
-                        append(xn[e], rn);
-                    });
-                    __builtin_amdgcn_sched_barrier(0);
+            // ---- gathers + rank updates; when the next line travels as lists its flagged haplotypes are appended to my
+            // list on the way (ONE loop for both kinds of line: an empty range reads as zeros, no appends - two copies of
+            // the loop under a branch had their common head hoisted above it and 83 registers spilled)
+            v4u rsn = in_rsrc(lines[more ? j + 1u : j]);
+            if (!kind) rsn[2] = 0;
+            open_list(seq + 1u);
+            static_for<0, E / G>([&](auto gc) {
+                constexpr int g0 = decltype(gc)::value * G;
+                uint64_t xc[G], xn[G];
+                u32x2 pr[G];
+                sbuf_load_chunks<G>(rsc, c0 + (uint32_t)g0, xc);
+                sbuf_load_chunks<G>(rsn, c0 + (uint32_t)g0, xn);
+                static_for<0, G>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    pr[e] = *reinterpret_cast<const LdsU2*>((uintptr_t)((r[g0 + e] >> 2) & 0x1FFF8u));  // the table starts at LDS address 0
                 });
-                asm volatile("" ::"v"(pf.x), "v"(pf.y));
+                if (kind == 2u) {
+                    static_for<0, G>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        xn[e] = complement(xn[e], c0 + (uint32_t)(g0 + e));
+                    });
+                }
+                static_for<0, G>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value;
+                    const uint32_t rr = r[g0 + e];
+                    const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
+                    const uint32_t rn = __builtin_amdgcn_inverse_ballot_w64(xc[e]) ? Z + ob : rr - ob;
+                    r[g0 + e] = rn;
+                    append(xn[e], rn);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            asm volatile("" ::"v"(pf.x), "v"(pf.y));
+            if (kind) {
                 publish();
                 prof(0);  // gathers + appends + publish
                 ++seq;
                 if (!exchange_lists(wah_first + j + 1u, seq, kind == 2u, Z)) return;
             } else {
-                // ---- gathers + rank updates alone
-                static_for<0, E / G>([&](auto gc) {
-                    constexpr int g0 = decltype(gc)::value * G;
-                    uint64_t xc[G];
-                    u32x2 pr[G];
-                    sbuf_load_chunks<G>(rsc, c0 + (uint32_t)g0, xc);
-                    static_for<0, G>([&](auto ec) {
-                        constexpr int e = decltype(ec)::value;
-                        pr[e] = *reinterpret_cast<const LdsU2*>((uintptr_t)((r[g0 + e] >> 2) & 0x1FFF8u));
-                    });
-                    static_for<0, G>([&](auto ec) {
-                        constexpr int e = decltype(ec)::value;
-                        const uint32_t rr = r[g0 + e];
-                        const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
-                        r[g0 + e] = __builtin_amdgcn_inverse_ballot_w64(xc[e]) ? Z + ob : rr - ob;
-                    });
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                asm volatile("" ::"v"(pf.x), "v"(pf.y));
                 prof(1);  // gathers alone
                 if (more) {
                     clear_bitmap();
@@ -1453,15 +1441,16 @@ static hipError_t launch_rank_encode_hyb_grid(hipStream_t s, const EncBlock* blo
         if (n > PROF_CAP) n = PROF_CAP;
         std::vector<uint64_t> rec(n);
         if (e == hipSuccess && n) e = hipMemcpy(rec.data(), prof_buf, 8ull * n, hipMemcpyDeviceToHost);
-        static const char* nm[8] = {"gathers+appends+publish", "gathers alone", "wait lists", "clear+apply+scan+table",
-                                    "clear+deposits+bitmap store", "waits (bitmap form)", "slice / table copy", "start"};
-        uint64_t sum[8] = {0}, cntv[8] = {0};
+        static const char* nm[12] = {"gathers+appends+publish", "gathers alone", "wait lists", "table entries written",
+                                     "bitmap stored + flagged", "waits (bitmap form)", "slice / table copy", "start",
+                                     "barrier + clear", "lists applied", "row read + wave scans", "clear + deposits"};
+        uint64_t sum[12] = {0}, cntv[12] = {0};
         for (uint32_t i = 1; i < n; ++i) {
-            const uint32_t tag = (uint32_t)(rec[i] >> 56) & 7u;
+            const uint32_t tag = (uint32_t)(rec[i] >> 56) % 12u;
             sum[tag] += (rec[i] - rec[i - 1]) & 0xFFFFFFFFFFFFFFull;
             cntv[tag]++;
         }
-        for (int t = 0; t < 7; ++t)
+        for (int t = 0; t < 12; ++t)
             fprintf(stderr, "[xsi hyb prof] %-28s %9.3f ms  (%llu records, %.2f us each)\n", nm[t], sum[t] * 1e-5,
                     (unsigned long long)cntv[t], cntv[t] ? sum[t] * 1e-2 / cntv[t] : 0.0);
     }
