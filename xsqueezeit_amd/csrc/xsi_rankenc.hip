@@ -1280,15 +1280,27 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_hyb(const EncBlock* __r
             const bool dense = c * 2u > N;
             return (dense ? N - c : c) <= A.thr ? (dense ? 2u : 1u) : 0u;
         };
+        // The deposit pass has nothing to hide a scalar load behind, so the key bits of group g + 1 travel while group g is
+        // deposited.  Scalar loads return out of order - a wait for one is a wait for all - so the wait for group g stands
+        // in FRONT of the request for g + 1; both are written out, because the compiler places a load next to its first use
+        // and cannot be told that a wait has already happened.
         auto deposit_pass = [&](v4u rsn) {
+            auto request = [&](uint32_t chunk) -> v16u {
+                v16u v;
+                asm volatile("s_buffer_load_dwordx16 %0, %1, %2" : "=&s"(v) : "s"(rsn), "s"(chunk * 8u));
+                return v;
+            };
+            v16u cur = request(c0);
             static_for<0, E / G>([&](auto gc) {
                 constexpr int g0 = decltype(gc)::value * G;
-                uint64_t xn[G];
-                sbuf_load_chunks<G>(rsn, c0 + (uint32_t)g0, xn);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cur));
+                v16u nxt = cur;
+                if constexpr (g0 + G < E) nxt = request(c0 + (uint32_t)(g0 + G));
                 static_for<0, G>([&](auto ec) {
                     constexpr int e = decltype(ec)::value;
-                    deposit(xn[e], r[g0 + e]);
+                    deposit(((uint64_t)cur[2 * e + 1] << 32) | cur[2 * e], r[g0 + e]);
                 });
+                cur = nxt;
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
