@@ -71,6 +71,8 @@ def test_full_depth_block_against_oracle(n_haps, n_lines, thr, kernels, monkeypa
     (40000, 4, 777, 40, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_DEC_PHASES="7")),   # ranges that do not divide the blocks' lines
     (50002, 3, 500, 50, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_DEC_PHASES="3")),   # 56 chunks per wave: the instantiation whose gathers are pinned in front of the updates
     (5008, 6, 900, 5, dict(XSI_DEC_PHASES_SMALL="1", XSI_DEC_PHASES="5", XSI_RANKENC_MIN_N="2")),   # the batch-staged decode chain in ranges
+    (64976, 1, 8192, 64, dict(XSI_RANK_WG_MIN_BLOCKS="1")),   # the kernel instantiation bench.py's default line decodes with (<64>, ramp + equal ranges, two-part boundary scan), one whole block deep
+    (64976, 1, 8192, 64, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_DEC_PHASES="1")),   # and in one range
     (24576, 3, 900, 24, dict()),                          # rank-tracking encode below 64 chunks per wave
     (12300, 2, 1200, 12, dict(XSI_RANKENC_MIN_N="2")),
 ])
@@ -93,6 +95,38 @@ def test_chain_kernel_variants_at_depth(n_haps, n_blocks, block_len, thr, force,
     assert got == ref
     out, _ = G.decode_packed(got, n_haps, stride)
     assert np.array_equal(out, packed)
+
+
+@pytest.mark.parametrize("n_haps,block_len,n_blocks", [
+    (140000, 150, 2),   # 3 workgroups per block (an odd count: the last 16-byte units of a bitmap have no second half)
+    (330000, 120, 2),   # 6
+    (500000, 100, 2),   # 8
+])
+@pytest.mark.parametrize("list_thr", ["0", "1000000", None])
+def test_long_row_encode_exchange_forms(n_haps, block_len, n_blocks, list_thr, monkeypatch):
+    """k_chain_rank_enc_multi chooses per line between rank lists with one hand-off (sparse lines; a row with more ones
+    than zeros as the list of its zeros) and bitmaps with two (dense lines).  Forced to either form for every line, and
+    with the default threshold, the bytes are the oracle's (wah.hpp:506-578, internal_gt_record.hpp:32-49)."""
+    import gpu_util as G
+    L = binding.lib()
+    if list_thr is not None:
+        monkeypatch.setenv("XSI_MULTI_LIST_THR", list_thr)
+    assert L.xsi_hip_chain_kernel(n_haps, n_blocks, 0).decode() == "k_chain_rank_enc_multi"
+    n_lines = block_len * n_blocks
+    bits, packed, stride = _device_synth(n_haps, n_lines, 11)
+    # a dense row (more ones than zeros, few zeros) and an all-but-empty WAH line among them
+    bits[5] = 1
+    bits[5, ::997] = 0
+    bits[7] = 0
+    bits[7, 3::n_haps // 700] = 1
+    packed = synth.pack_rows(bits, stride)
+    p = G.params(n_haps // 2, block_len, n_haps // 1000)
+    ref = G.oracle_file_from_bits(bits, p)
+    before = L.xsi_hip_ctx_chain_fallbacks(G.ctx().handle)
+    region, offsets, res = G.encode_packed(packed, n_haps, p)
+    assert L.xsi_hip_ctx_chain_fallbacks(G.ctx().handle) == before
+    got = G.assemble_file(region, offsets, p, n_lines, n_lines, ["S%d" % i for i in range(n_haps // 2)])
+    assert got == ref
 
 
 def test_multi_workgroup_chain_falls_back_instead_of_hanging(monkeypatch):

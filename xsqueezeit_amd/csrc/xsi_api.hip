@@ -407,21 +407,9 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     stage_mark(ctx, -1);
     uint64_t res[5];
     uint32_t chain_abort = 0;
-    uint64_t chain_prof[8] = {0};  // [0] abort word (+ pad), [1..7] phase ticks of workgroup 0 (XSI_MULTI_PROF)
     HIP_TRY(hipMemcpyAsync(res, d_result, sizeof(res), hipMemcpyDeviceToHost, s));
-    if (chain_rank_enc_multi_supported(L)) HIP_TRY(hipMemcpyAsync(chain_prof, L.chain_sync, sizeof(chain_prof), hipMemcpyDeviceToHost, s));
+    if (chain_rank_enc_multi_supported(L)) HIP_TRY(hipMemcpyAsync(&chain_abort, L.chain_sync, sizeof(chain_abort), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    chain_abort = (uint32_t)chain_prof[0];
-    if (chain_rank_enc_multi_supported(L) && getenv("XSI_MULTI_PROF")) {
-        static const char* nm_lists[7] = {"main+publish", "barrier+wait lists", "apply lists", "barrier", "slice scan+store+flag", "wait slices", "table copy"};
-        static const char* nm_bmp[7] = {"M1 gathers", "clear + M2 deposits", "E1 bitmap store+flag", "wait bitmaps", "E3 slice OR+scan+store+flag", "wait slices", "E4 table copy"};
-        static const char* nm_hyb[7] = {"M1 gathers", "list pass + publish", "wait lists", "clear+apply+scan+table", "clear+deposits+bitmap store", "waits (bitmap form)", "slice + table copy"};
-        const char* const* nm = getenv("XSI_MULTI_LISTS") ? nm_lists : getenv("XSI_MULTI_BMP") ? nm_bmp : nm_hyb;
-        uint64_t tot = 0;
-        for (int i = 1; i < 8; ++i) tot += chain_prof[i];
-        for (int i = 1; i < 8; ++i)
-            fprintf(stderr, "[xsi multi prof] %-24s %9.3f ms  %5.1f %%\n", nm[i - 1], chain_prof[i] * 1e-5, tot ? 100.0 * chain_prof[i] / tot : 0.0);
-    }
     stage_collect(ctx);
     if (chain_abort) {
         // The workgroups of a block did not all become resident (another process or stream holds CUs) and a wait

@@ -280,561 +280,60 @@ hipError_t launch_rank_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_
 
 
 // ------------------------------------------------------------------------------------------
-// 65 536 < N <= 524 288 haplotypes: the same chain with S = ceil(N / 65536) workgroups per block.
+// 65 536 < N <= 524 288 haplotypes: the same chain with S = ceil(N / 65536) workgroups per block: k_chain_rank_enc_multi.
 //
-// The position-major kernel for these sizes (k_chain_stream) moves the prefix array through HBM: 8 N bytes
-// of scattered traffic per line and block, one CU per block (696 ms for 153 blocks of 500 000 haplotypes,
-// at the HBM limit of that access pattern).  Element-major, a workgroup keeps 65 536 ranks in registers
-// and holds the rank-select table of ALL N positions in its LDS (8 bytes per 32 positions: 128 KiB at
-// 524 288); what the S workgroups ("members") of a block exchange per line is only where the ONES of the
-// next line go, and member m OWNS the row positions [65536 m, 65536 m + 65536):
-//   M   main phase as in k_chain_rank_enc, but a lane whose next-line bit is set APPENDS its new rank to its
-//       wave's list (through a 128-entry ring in LDS, so that the list leaves as whole 256-byte stores).  A row
-//       with more ones than zeros travels as the list of its ZEROS (half of all list entries come from such
-//       rows: 72 k -> 50 k entries per line on average at 500 000 haplotypes);
-//   S1  the workgroup signals its lists (one flag record per member: sequence number + the 16 list lengths,
-//       16-byte stores by one wave behind a workgroup barrier; every wave polls the records it needs);
-//   A   every workgroup reads all lists but deposits only the ranks in ITS slice (LDS atomic OR into an
-//       8 KiB slice buffer): one eighth of the atomics of "everybody builds the whole row";
-//   B   popcounts + scan of the slice alone (two words per thread, as in k_chain_rank_enc): the slice leaves
-//       as finished {bits, ones before (inside the slice)} table entries (16 KiB) plus its ones in a flag;
-//   S2  every wave polls the S slice flags (8-byte sc1 loads);
-//   C   every workgroup copies the S slices into its table, adding each slice's base (ones of the slices
-//       before it): 16 bytes per thread and slice, no clear, no scan over the whole row.
-// Hand-offs go through the L2 of ONE XCD: the members of a group are dispatched 8 workgroups apart, i.e. to the
-// same XCD (HW_REG_XCC_ID == blockIdx.x & 7 for every workgroup of a launch, tools/microbench4.hip), and a
-// handshake at the start of the launch verifies it (members on different XCDs abort the launch: the host runs the
-// batch with k_chain_stream).  So the bytes are stored PLAIN (write-through L1, the line stays in the XCD's L2) and
-// loaded with sc1 loads (past L1, served by that L2): 128 KiB written by one workgroup and read by 7 others takes
-// 1.36 us this way against 4.06 us with sc1 stores, which drop the line from L2 (profiles/r03_microbench4.txt).
-// Every storing wave waits for its stores (vmcnt(0)) in front of the workgroup barrier behind which the flag is
-// stored; a polling wave loads the bytes only after its own poll has matched.  Sequence numbers grow by one per
-// exchange and never repeat inside a launch; lists, slices and flags are double-buffered by the sequence number's
-// parity (a member can be at most one exchange ahead of another: it needs that member's lists / slice of the
-// exchange before).
-// Every workgroup of the grid must be resident for the exchanges to complete: the grid is at most one workgroup
-// per CU and groups walk the blocks persistently.  A wait that does not complete within `timeout_ticks` of the
-// 100 MHz clock raises the abort flag; every poll loop looks at it, the waves leave (a barrier only waits for the
-// waves that are left) and the host runs the batch again with k_chain_stream (xsi_api.hip, encode_run).
-// Measured and dropped on the way (configs[3] shard, chain ms): every workgroup applying every list, scanning the
-// whole row, one counter meeting per line (round 2's form) 430; owner-computes with sc1 stores 462; plain stores
-// through the XCD's L2 421; per-WAVE flags without the two workgroup barriers 576; global atomic ORs into a row
-// bitmap in L2 instead of lists: 27 G atomics/s chip-wide whatever the scope (tools/microbench4.hip), a factor 40
-// short; lists bucketed by owner at the writer: about one instruction per entry, no fewer than the filter costs the
-// readers (6 per 64 entries x 8 readers).
-// ------------------------------------------------------------------------------------------
-constexpr uint32_t MULTI_LIST_CAP = 4096u;  // ranks per wave and line: every one of its 64 x 64 haplotypes
-
-struct RankEncMultiArgs {
-    const uint32_t* wah_lines;
-    const uint32_t* src;
-    uint32_t src_stride_w;
-    const uint32_t* cnt;    // ones of every binary line (the classification's counts)
-    uint32_t* dst;          // permuted rows y by rank
-    uint32_t dst_stride_w;  // words per row
-    uint32_t N;
-    uint32_t n_blocks;
-    uint32_t S;             // workgroups per block
-    uint32_t gpx;           // groups per XCD slot: the grid is 8 * gpx * S workgroups
-    uint32_t* sync;         // [0] abort
-    uint32_t* list_flags;   // [group][parity][member][32 words]: 6 records {seq, lengths of lists 3q, 3q+1, 3q+2}
-    uint64_t* slice_flags;  // [group][parity][8]: seq << 32 | ones of the slice
-    uint32_t* lists;        // [group][parity][S * 16 waves][MULTI_LIST_CAP] ranks, whole 64-entry stores (padding: ~0)
-    v4u* slices;            // [group][parity][member][1024]: two table entries each
-    uint32_t test_desert;   // testing only: member 1 of every group leaves at once
-    uint32_t prof;          // XSI_MULTI_PROF: phase times of workgroup 0 into sync[2..]
-    uint32_t* xcc_ids;      // [group][8]: 1 + XCC_ID of each member (handshake at the start of the launch)
-    uint64_t timeout_ticks;
-    uint32_t wave_flags;    // every wave flags its own list (8 bytes: seq << 32 | length) as soon as its stores have drained,
-                            // and starts on the lists it applies without waiting for the rest of its workgroup
-};
-
-template <bool WAVE_FLAGS, bool PROF>
-__global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* __restrict__ eblocks, RankEncMultiArgs A) {
-    constexpr uint32_t T = 1024, W = 16;
-    constexpr int E = 64, G = 8, SMAX = 8;
-    constexpr uint32_t SL_WORDS = 2048u;  // row words of a slice: two per thread
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tab_bytes = A.S * SL_WORDS * 8u;
-    uint32_t* slice = reinterpret_cast<uint32_t*>(smem + tab_bytes);
-    uint32_t* wtot = slice + SL_WORDS;  // [0,16) wave totals of the slice, [32,48) list lengths of my waves
-    uint32_t* ring_all = wtot + 64;     // [16 waves][128] ranks on their way to the lists
-    const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    if (tab_lds != 0u) __builtin_trap();  // the kernel has no other LDS variable: the table starts at LDS address 0 (the gathers rely on it)
-    const uint32_t slice_lds = tab_lds + tab_bytes;
-    const uint32_t N = A.N;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
-    const uint32_t group = xcd * A.gpx + q / A.S, member = q % A.S, n_groups = 8u * A.gpx;
-    const uint32_t n_lists = A.S * W;
-    if (A.test_desert && member == 1u) return;
-
-    const uint32_t row_bytes = ((N + 63u) / 64u) * 8u;  // bytes of an input row that hold haplotypes
-    auto in_rsrc = [&](uint32_t line) -> v4u {
-        const uint64_t base = reinterpret_cast<uint64_t>(A.src + (size_t)line * A.src_stride_w);
-        v4u d;
-        d[0] = (uint32_t)base;
-        d[1] = (uint32_t)(base >> 32) & 0xFFFFu;
-        d[2] = row_bytes;
-        d[3] = 0x00020000u;
-        return d;
-    };
-    // Everything the members share lives in per-group regions reached through four buffer descriptors that are
-    // formed once, from scalar halves: (parity, member, list) select by SCALAR offsets.  (A descriptor built inside
-    // the line loop from a 64-bit product ends up in vector registers and every access in a waterfall loop.)
-    auto group_rsrc = [&](const void* base, uint32_t bytes) -> __amdgpu_buffer_rsrc_t {
-        const uint64_t v = reinterpret_cast<uint64_t>(base);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
-    };
-    const __amdgpu_buffer_rsrc_t rs_lflags = group_rsrc(A.list_flags + (size_t)group * 2u * A.S * 32u, 2u * A.S * 128u);
-    const __amdgpu_buffer_rsrc_t rs_slices = group_rsrc(A.slices + (size_t)group * 2u * A.S * 1024u, 2u * A.S * 16384u);
-    uint32_t* const glists = A.lists + (size_t)group * 2u * n_lists * MULTI_LIST_CAP;
-    uint64_t* const gsflags = A.slice_flags + (size_t)group * 16u;
-    uint64_t t_start = 0;
-    auto give_up = [&](uint32_t& spins) -> bool {  // every 32 polls: has the launch been aborted / has this wait run out?
-        if ((++spins & 31u) != 0u) return false;
-        if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(A.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return true;
-        const uint64_t now = wall_clock64();
-        if (!t_start) t_start = now;
-        if (now - t_start > A.timeout_ticks) {
-            __hip_atomic_store(A.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return true;
-        }
-        return false;
-    };
-
-    // phases S1 .. C for the row `rank` whose ones the members have just published under sequence number `seq`;
-    // false = the launch is aborting
-    // XSI_MULTI_PROF: wave 0 of workgroup 0 adds the 100 MHz ticks of every phase to sync[2 + 2 i] (64-bit)
-    uint64_t t_prof = 0;
-    auto prof = [&](uint32_t i) {
-        if constexpr (!PROF) return;  // (the phase clocks are compiled out of the production instantiations)
-        if (A.prof && blockIdx.x == 0 && w == 0u) {
-            const uint64_t now = wall_clock64();
-            if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<uint64_t*>(A.sync + 2u) + i, now - t_prof, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t_prof = now;
-        }
-    };
-    // `dense`: the lists of this row name its ZEROS (a row with more ones than zeros publishes the shorter list;
-    // the owners complement their slices)
-    auto exchange = [&](uint32_t rank, uint32_t seq, bool dense, uint32_t& Zout) -> bool {
-        const uint32_t par = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seq & 1u));
-        prof(0);  // main phase + publish
-        uint32_t cnt_l = 0;
-        if constexpr (WAVE_FLAGS) {
-            // Per-wave hand-off (round 4): this wave's list is complete in L2 (publish waited for its stores), so it is
-            // flagged at once - 8 bytes, sequence number and length - and the lists this wave applies, list w of every
-            // member, are written by the waves with the same place in their workgroups' issue order: the waves that
-            // finish their main phase early (the arbiter serves the oldest wave first) apply their lists while the late
-            // ones are still gathering, instead of waiting for them at a workgroup barrier in front of a flag record.
-            // 357.5 -> 345.7 ms over the configs[3] shard (same build); the wait moves behind the lists (the barrier in
-            // front of the slice scan), the flag record's round trip is gone.  Dealing the 16 S lists out in the order
-            // they are published, so that every wave holds early and late lists and applies them batch by batch as they
-            // arrive, measured 441 ms: every batch pays the lists' round trip to L2 again (apply 60 -> 130 ms).
-            const uint32_t my_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)wtot[32u + w]);
-            if (lane == 0u) {
-                u32x2 fl;
-                fl[0] = my_len;
-                fl[1] = seq;
-                __builtin_amdgcn_raw_buffer_store_b64(fl, rs_lflags, w * 8u, (par * A.S + member) * 128u, 0);
-            }
-            const uint32_t ml = lane < A.S ? lane : 0u;
-            uint32_t spins = 0;
-            t_start = 0;
-            for (;;) {
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_lflags, ml * 128u + w * 8u, par * A.S * 128u, 16);
-                if (__builtin_amdgcn_ballot_w64(v[1] != seq) == 0ull) {
-                    cnt_l = lane < A.S ? v[0] : 0u;
-                    break;
-                }
-                if (give_up(spins)) return false;
-                __builtin_amdgcn_s_sleep(0);
-            }
-        } else {
-        lds_barrier();  // every wave's list stores have been waited for (publish), its length is in wtot[32 + wave]
-        if (w == 0u && lane < 6u) {
-            v4u rec;
-            rec[0] = seq;
-            rec[1] = wtot[32u + 3u * lane];
-            rec[2] = 3u * lane + 1u < W ? wtot[33u + 3u * lane] : 0u;
-            rec[3] = 3u * lane + 2u < W ? wtot[34u + 3u * lane] : 0u;
-            __builtin_amdgcn_raw_buffer_store_b128(rec, rs_lflags, lane * 16u, (par * A.S + member) * 128u, 0);
-        }
-        // ---- S1: the flag records of the lists my wave applies: list w of EVERY member (wave w of each member covers the
-        // same stretch of its member's haplotypes, so the 16 waves get lists of about equal length; S consecutive
-        // lists = eight waves of one member measured 8 ms slower over the configs[3] shard: the waves of a workgroup
-        // finish their main phase in issue order and the late ones' lists were also the long-waited ones)
-        {
-            const uint32_t ml = lane < A.S ? lane : 0u, wl = w, rq = wl / 3u, rc = wl - 3u * rq;  // list w of member `lane`
-            uint32_t spins = 0;
-            t_start = 0;
-            for (;;) {
-                const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs_lflags, ml * 128u + rq * 16u, par * A.S * 128u, 16);
-                if (__builtin_amdgcn_ballot_w64(v[0] != seq) == 0ull) {
-                    cnt_l = lane < A.S ? (rc == 0u ? v[1] : rc == 1u ? v[2] : v[3]) : 0u;
-                    break;
-                }
-                if (give_up(spins)) return false;
-                __builtin_amdgcn_s_sleep(0);  // (s_sleep 1 between polls: 4 ms slower over the configs[3] shard)
-            }
-        }
-        }
-        prof(1);  // barrier + wait for the lists
-        // ---- A: all lists, my slice's ranks only
-        {
-            uint32_t member_v = member, slice_lds_v = slice_lds;
-            asm volatile("" : "+v"(member_v), "+v"(slice_lds_v));  // operands of the hand-written entry step below
-            const uint32_t* lst = glists + (size_t)(par * n_lists + w) * MULTI_LIST_CAP;  // + k * 16 lists: member k's
-            uint32_t cnt[SMAX], longest = 0;
-#pragma unroll
-            for (int k = 0; k < SMAX; ++k) {
-                cnt[k] = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, k);
-                longest = cnt[k] > longest ? cnt[k] : longest;
-            }
-            // All S lists of a step in flight together (the loop is bound by the round trips to L2, not by bytes), and a
-            // list's next piece is requested as soon as its current one has been worked on: the pieces of step i + 1
-            // travel while the rest of step i is applied.
-            v4u rk[SMAX];
-            auto load_piece = [&](int k, uint32_t i0) {
-                // lists are whole 64-entry stores; beyond a list the range check returns 0 (no memory request), masked below
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    (void*)(lst + (size_t)k * 16u * MULTI_LIST_CAP), 0, (int)(cnt[k] * 4u), 0x00020000);
-                rk[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (i0 + lane * 4u) * 4u, 0, 16);
-            };
-            // in THIS order, list 0 first (a scheduling barrier behind each): the loop works through the lists in order and
-            // requests a list's next piece behind its current one, so a piece is always the oldest load in flight when it
-            // is needed - but the compiler had issued these first eight in reverse, which made list 0's piece the YOUNGEST
-            // at the loop's entry, and the wait at the top of the loop (one wait for both ways into it) a wait for all
-            // eight loads in every round: the last of them had been requested a moment before
-#pragma unroll
-            for (int k = 0; k < SMAX; ++k) {
-                load_piece(k, 0u);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            for (uint32_t i0 = 0; i0 < longest; i0 += 256u) {
-#pragma unroll
-                for (int k = 0; k < SMAX; ++k) {
-                    if (i0 + lane * 4u < cnt[k]) {
-                        // Per entry: the lanes whose rank lies in my slice (rank >> 16 == member; padding entries, ~0,
-                        // belong to nobody) set its bit.  v_cmpx narrows exec to them, so the LDS atomic only costs
-                        // those lanes, and there is no branch: 6 instructions per 64 entries, written out because
-                        // the compiler's form (compare, save exec, branch, restore) takes 10.
-                        uint64_t live;
-                        uint32_t t0, t1;
-                        asm volatile("s_mov_b64 %0, exec" : "=s"(live));
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            asm volatile(
-                                "v_cmpx_eq_u32_sdwa vcc, %[v], %[m] src0_sel:WORD_1 src1_sel:DWORD\n\t"
-                                "v_bfe_u32 %[a], %[v], 5, 11\n\t"
-                                "v_lshlrev_b32 %[b], %[v], 1\n\t"
-                                "v_lshl_add_u32 %[a], %[a], 2, %[base]\n\t"
-                                "ds_or_b32 %[a], %[b]\n\t"
-                                "s_mov_b64 exec, %[live]"
-                                : [a] "=&v"(t0), [b] "=&v"(t1)
-                                : [v] "v"(rk[k][u]), [m] "v"(member_v), [base] "v"(slice_lds_v), [live] "s"(live)
-                                : "memory", "vcc");
-                        }
-                    }
-                    load_piece(k, i0 + 256u);  // (behind the work on the current piece: its registers are free now)
-                }
-            }
-        }
-        prof(2);  // lists applied
-        lds_barrier();  // my slice is complete; every wave is done with the table of the line before
-        prof(3);  // barrier behind the lists
-        // ---- B: my slice -> table entries
-        uint32_t ones_slice;
-        uint2 row_words;
-        uint32_t tid_here = tid;
-        asm volatile("" : "+v"(tid_here));  // addresses are formed here, not kept (spilled) across the lines
-        {
-            uint2 v = *reinterpret_cast<const uint2*>(slice + 2u * tid_here);
-            *reinterpret_cast<uint2*>(slice + 2u * tid_here) = make_uint2(0u, 0u);
-            if (dense) {  // the deposits were the row's zeros: complement, positions at or beyond N stay zero
-                const uint32_t p0 = (member * SL_WORDS + 2u * tid_here) * 32u;
-                const uint32_t m0 = p0 + 32u <= N ? ~0u : (p0 >= N ? 0u : (1u << (N - p0)) - 1u);
-                const uint32_t m1 = p0 + 64u <= N ? ~0u : (p0 + 32u >= N ? 0u : (1u << (N - p0 - 32u)) - 1u);
-                v.x = ~v.x & m0;
-                v.y = ~v.y & m1;
-            }
-            const uint32_t c = (uint32_t)__popc(v.x) + (uint32_t)__popc(v.y);
-            const uint32_t inc = wave_scan_incl_dpp(c);
-            if (lane == 63u) wtot[w] = inc;
-            lds_barrier();
-            const uint32_t sc = row16_scan_incl(lane < W ? wtot[lane] : 0u);
-            ones_slice = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
-            const uint32_t base = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
-            const uint32_t pre0 = base + inc - c;
-            v4u ent;
-            ent[0] = v.x;
-            ent[1] = pre0;
-            ent[2] = v.y;
-            ent[3] = pre0 + (uint32_t)__popc(v.x);
-            // (whole table entries travel: 12-byte {64 bits, prefix} records - a quarter fewer bytes through L2 - measured
-            // slower, table copy 43.4 -> 49.7 ms over the configs[3] shard: 12-byte accesses run below the 16-byte rate)
-            __builtin_amdgcn_raw_buffer_store_b128(ent, rs_slices, tid_here * 16u, (par * A.S + member) * 16384u, 0);
-            row_words = v;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my entries have left
-        __syncthreads();
-        // (a global store, said so: through a plain pointer it was a FLAT store, and with a flat operation outstanding the
-        // compiler has to wait for ALL loads wherever it waits for one)
-        if (tid == 0)
-            *reinterpret_cast<volatile __attribute__((address_space(1))) uint64_t*>(
-                (__attribute__((address_space(1))) uint64_t*)(gsflags + par * 8u + member)) = ((uint64_t)seq << 32) | ones_slice;
-        {   // my part of the row for the WAH pass: behind the flag, nobody in the chain waits for this store
-            const uint32_t roww = member * SL_WORDS + 2u * tid_here;  // rows are whole 16-byte units
-            if (roww < A.dst_stride_w) *reinterpret_cast<uint2*>(A.dst + (size_t)rank * A.dst_stride_w + roww) = row_words;
-        }
-        prof(4);  // slice scanned, stored, flagged
-        // ---- S2: every member's slice
-        uint32_t tot_l;
-        {
-            const uint64_t* fp = gsflags + par * 8u + (lane < A.S ? lane : 0u);
-            uint32_t spins = 0;
-            t_start = 0;
-            for (;;) {
-                const uint64_t v = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__builtin_amdgcn_ballot_w64((uint32_t)(v >> 32) != seq) == 0ull) {
-                    tot_l = lane < A.S ? (uint32_t)v : 0u;
-                    break;
-                }
-                if (give_up(spins)) return false;
-                __builtin_amdgcn_s_sleep(0);
-            }
-        }
-        prof(5);  // wait for the slices
-        const uint32_t incl = wave_scan_incl_dpp(tot_l);
-        // ---- C: the S slices -> my table, each with its base
-        {
-            v4u t[SMAX];
-#pragma unroll
-            for (int k = 0; k < SMAX; ++k)  // slices past S: beyond the descriptor's range or the other parity's, not stored
-                t[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_slices, tid_here * 16u, (par * A.S + (uint32_t)k) * 16384u, 16);
-            // all S loads in flight before the first is consumed: left to itself the scheduler (128 VGPRs, 64 of them
-            // ranks) ran them one after the other through ONE register quad - load, s_waitcnt vmcnt(0), ds_write, load, ...:
-            // eight round trips to L2 per line instead of one
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < SMAX; ++k)
-                if ((uint32_t)k < A.S) {
-                    const uint32_t b = k ? (uint32_t)__builtin_amdgcn_readlane((int)incl, k - 1) : 0u;
-                    v4u e = t[k];
-                    e[1] += b;
-                    e[3] += b;
-                    *reinterpret_cast<__attribute__((address_space(3))) v4u*>((uintptr_t)(tab_lds + (uint32_t)k * 16384u + tid_here * 16u)) = e;
-                }
-        }
-        Zout = N - (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        lds_barrier();
-        prof(6);  // table copied
-        return true;
-    };
-
-    for (uint32_t i = tid; i < SL_WORDS; i += T) slice[i] = 0;
-    // One-time handshake: the members of a group must share an XCD (see the header comment).  Every workgroup
-    // publishes 1 + its XCC_ID with an agent-scope store and waits for the others' with agent-scope loads.
-    {
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        xcc = (xcc & 15u) + 1u;
-        uint32_t* ids = A.xcc_ids + group * 8u;
-        if (tid == 0) __hip_atomic_store(ids + member, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t spins = 0;
-        t_start = 0;
-        for (;;) {
-            const uint32_t v = __hip_atomic_load(ids + (lane < A.S ? lane : member), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__builtin_amdgcn_ballot_w64(v == 0u && lane != member) == 0ull) {
-                if (__builtin_amdgcn_ballot_w64(v != xcc && lane != member) != 0ull) {  // spread over several XCDs: not this kernel's case
-                    __hip_atomic_store(A.sync, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return;
-                }
-                break;
-            }
-            if (give_up(spins)) return;
-            __builtin_amdgcn_s_sleep(4);
-        }
-    }
-    if (A.prof) t_prof = wall_clock64();
-    uint32_t seq = 0;
-    const uint32_t c0 = member * 1024u + w * (uint32_t)E;  // my first chunk of the row
-    for (uint32_t blk = group; blk < A.n_blocks; blk += n_groups) {
-        const EncBlock& B = eblocks[blk];
-        if (B.has_haploid) continue;  // the position-major kernels take the blocks with fully haploid lines
-        const uint32_t wah_first = B.wah_first, n_wah = B.n_wah;
-        if (n_wah == 0) continue;
-        const ConstU32* lines = as_const(A.wah_lines) + wah_first;
-        // Ranks on their way to my wave's list pass through a 128-entry ring in LDS, so that they leave as whole
-        // 256-byte stores (a store of one to three lanes per chunk is one fabric write per lane).
-        // The 128 entries are a LINEAR buffer: the ranks not yet stored sit at its front (fewer than 64), a chunk's new
-        // ones go behind them at `wpos` - a scalar LDS byte address, so a lane's slot is v_mbcnt x 2 + ONE v_lshl_add
-        // (round 4; the ring it replaces took six vector instructions per chunk: the running count moved into a vector
-        // register, a wrap mask, a copy of the rank) - and a flush stores the first 64 and moves the rest to the front.
-        uint32_t n_out = 0;  // ranks already stored, for the line in the making (wave-uniform)
-        uint32_t* my_list = nullptr;
-        uint32_t* ring = ring_all + w * 128u;
-        const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane(
-            (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(ring));
-        uint32_t wpos = ring_lds;
-        auto open_list = [&](uint32_t sq) {
-            wpos = ring_lds;
-            n_out = 0;
-            my_list = glists + (size_t)((sq & 1u) * n_lists + member * W + w) * MULTI_LIST_CAP;
-        };
-        auto flush64 = [&]() {
-            my_list[n_out + lane] = ring[lane];
-            n_out += 64u;
-            const uint32_t rest = (wpos - ring_lds - 256u) >> 2;  // entries behind the 64 that leave
-            const uint32_t v = ring[64u + lane];
-            if (lane < rest) ring[lane] = v;
-            wpos -= 256u;
-        };
-        using LdsRing = __attribute__((address_space(3))) uint32_t;
-        auto append = [&](uint64_t xm, uint32_t rr) {
-            if (xm) {
-                if (__builtin_amdgcn_inverse_ballot_w64(xm)) {
-                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(xm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)xm, 0u));
-                    *reinterpret_cast<LdsRing*>((uintptr_t)(wpos + (slot << 2))) = rr;
-                }
-                wpos += 4u * (uint32_t)__popcll(xm);
-                if (wpos >= ring_lds + 256u) flush64();
-            }
-        };
-        // the rest of the list, padded to a whole 64-entry store with entries that mean nothing (~0); its length goes
-        // to LDS for the flag record; the wave waits for its stores
-        auto publish = [&]() {
-            const uint32_t left = (wpos - ring_lds) >> 2;
-            if (left) {
-                my_list[n_out + lane] = lane < left ? ring[lane] : ~0u;
-                n_out += 64u;
-            }
-            if (lane == 0) wtot[32u + w] = n_out;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        // a row with more ones than zeros travels as the list of its zeros: on such a line the flags are the
-        // complement of the input bits, restricted to the haplotypes that exist
-        const uint32_t full_chunks = N >> 6, rem_bits = N & 63u;
-        auto is_dense = [&](uint32_t line) -> bool { return as_const(A.cnt)[line] * 2u > N; };
-        auto complement = [&](uint64_t x, uint32_t chunk) -> uint64_t {
-            uint32_t fc = full_chunks;
-            asm volatile("" : "+s"(fc));  // the mask is formed where it is used (hoisted for all 64 chunks it spills 128 SGPRs)
-            const uint64_t vm = chunk < fc ? ~0ull : (chunk == fc && rem_bits ? (1ull << rem_bits) - 1ull : 0ull);
-            return ~x & vm;
-        };
-        uint32_t lane_here = lane;
-        asm volatile("" : "+v"(lane_here));  // the identity ranks are formed in this block's code, not kept across the blocks
-        // line 0: ranks are the identity, its row is the input row itself
-        ++seq;
-        open_list(seq);
-        bool dense_next = is_dense(lines[0]);
-        {
-            const v4u rs0 = in_rsrc(lines[0]);
-            static_for<0, E / G>([&](auto gc) {
-                constexpr int g0 = decltype(gc)::value * G;
-                uint64_t x0[G];
-                sbuf_load_chunks<G>(rs0, c0 + (uint32_t)g0, x0);
-                if (dense_next) {
-                    static_for<0, G>([&](auto ec) {
-                        constexpr int e = decltype(ec)::value;
-                        x0[e] = complement(x0[e], c0 + (uint32_t)(g0 + e));
-                    });
-                }
-                static_for<0, G>([&](auto ec) {
-                    constexpr int e = decltype(ec)::value;
-                    append(x0[e], (c0 + (uint32_t)(g0 + e)) * 64u + lane_here);  // bits at or beyond N are zero
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            publish();
-        }
-        uint32_t Z = 0;
-        if (!exchange(wah_first, seq, dense_next, Z)) return;
-        uint32_t r[E];
-        static_for<0, E>([&](auto ec) {
-            constexpr int e = decltype(ec)::value;
-            const uint32_t h = (c0 + (uint32_t)e) * 64u + lane_here;
-            r[e] = h < N ? h : 0u;
-        });
-        auto prefetch_row = [&](uint32_t line) -> uint2 {  // my workgroup's 8 KiB of the input row, into L2
-            const uint2* rowp = reinterpret_cast<const uint2*>(A.src + (size_t)line * A.src_stride_w) + member * 1024u;
-            return (member * 1024u + tid) * 8u < row_bytes ? rowp[tid] : make_uint2(0u, 0u);
-        };
-        for (uint32_t j = 0; j < n_wah; ++j) {
-            const bool more = j + 1u < n_wah;
-            const uint2 pf = prefetch_row(lines[j + 2u < n_wah ? j + 2u : j]);
-            const v4u rsc = in_rsrc(lines[j]);
-            v4u rsn = in_rsrc(lines[more ? j + 1u : j]);
-            if (!more) rsn[2] = 0;  // nothing follows the block's last line: an empty range reads as zeros, no appends
-            dense_next = more && is_dense(lines[j + 1u]);
-            open_list(seq + 1u);
-            static_for<0, E / G>([&](auto gc) {
-                constexpr int g0 = decltype(gc)::value * G;
-                uint64_t xc[G], xn[G];
-                u32x2 pr[G];
-                sbuf_load_chunks<G>(rsc, c0 + (uint32_t)g0, xc);
-                sbuf_load_chunks<G>(rsn, c0 + (uint32_t)g0, xn);
-                static_for<0, G>([&](auto ec) {
-                    constexpr int e = decltype(ec)::value;
-                    pr[e] = *reinterpret_cast<const LdsU2*>((uintptr_t)((r[g0 + e] >> 2) & 0x1FFF8u));  // the table starts at LDS address 0
-                });
-                if (dense_next) {
-                    static_for<0, G>([&](auto ec) {
-                        constexpr int e = decltype(ec)::value;
-                        xn[e] = complement(xn[e], c0 + (uint32_t)(g0 + e));
-                    });
-                }
-                static_for<0, G>([&](auto ec) {
-                    constexpr int e = decltype(ec)::value;
-                    const uint32_t rr = r[g0 + e];
-                    const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
-                    const uint32_t rn = __builtin_amdgcn_inverse_ballot_w64(xc[e]) ? Z + ob : rr - ob;
-                    r[g0 + e] = rn;
-                    append(xn[e], rn);
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            asm volatile("" ::"v"(pf.x), "v"(pf.y));
-            if (more) {
-                publish();
-                ++seq;
-                if (!exchange(wah_first + j + 1u, seq, dense_next, Z)) return;
-            }
-        }
-        __syncthreads();  // the next block's first table must not overtake this block's last gathers
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// Round 5: the exchange chosen PER LINE by the line's minor allele count (known from the classification).
-//
-// What a line of k_chain_rank_enc_multi costs (phase clocks, round 4 / 5): the gathers + rank updates 3.2 us whatever
-// the line; a hand-off through L2 - store acknowledgements, flag, poll, loads - about 3 us; list append + apply grow with
-// the ones of the row.  Most WAH lines are sparse (allele counts are octave-uniform: at 500 000 haplotypes two of three
-// WAH lines have fewer than 49 152 minor alleles), so:
-//   minor <= thr   ONE hand-off: rank lists as in k_chain_rank_enc_multi, but EVERY member applies ALL lists to a
-//                  bitmap of the whole row in its own LDS and scans that row itself: no slices, no second hand-off, no
-//                  table copy;
-//   minor >  thr   BITMAPS instead of lists: a member deposits the ones of its haplotypes into a private bitmap of the
-//                  whole row in its LDS (ds_or_b32, as the one-workgroup kernel does), stores it (N / 8 bytes) through
-//                  the XCD's L2, and the owner of a slice ORs the S members' pieces of it (8 bytes per thread and
-//                  member, no filter, no per-entry work), scans it and publishes finished table entries that every
-//                  member copies: two hand-offs whose cost does not depend on the ones of the row.
-// The bitmap of a row (N / 8 bytes) cannot stand next to the rank-select table (S x 16 KiB of the 160 KiB) while that is
-// being gathered from: it takes the place of the table's first half once every wave is through its gathers (barrier,
-// clear, barrier), so the deposits of a bitmap line are a pass of their own behind the gathers; the appends of a list
-// line need no such room and stay fused with the gathers.
+// The position-major kernel for these sizes (k_chain_stream) moves the prefix array through HBM: 8 N bytes of scattered
+// traffic per line and block, one CU per block (696 ms for 153 blocks of 500 000 haplotypes, at the HBM limit of that
+// access pattern).  Element-major, a workgroup ("member") keeps 65 536 ranks in registers and holds the rank-select table
+// of ALL N positions in its LDS (8 bytes per 32 positions: 128 KiB at 524 288); what the S members of a block exchange
+// per line is where the ONES of the next line go, and member m OWNS the row positions [65536 m, 65536 m + 65536).
+// How the ones travel is chosen PER LINE by the line's minor allele count (known from the classification).  What a line
+// costs (phase clocks, XSI_MULTI_PROF): the gathers + rank updates 3.2 - 4.2 us whatever the line; a hand-off through L2 -
+// store acknowledgements, flag, poll, loads - about 3 us; appending to and applying rank lists grows with the ones of
+// the row.  Most WAH lines are sparse (allele counts are octave-uniform: at 500 000 haplotypes two of three WAH lines have
+// fewer than 49 152 minor alleles), so:
+//   minor <= thr   ONE hand-off.  A lane whose next-line bit is set appends its new rank to its wave's list during the
+//                  gathers (through a 128-entry buffer in LDS, so that the list leaves as whole 256-byte stores; a row
+//                  with more ones than zeros travels as the list of its ZEROS); every wave flags its own list (8 bytes:
+//                  length + sequence number) as soon as its stores have drained and polls the flags of list w of every
+//                  member; EVERY member applies ALL lists to a bitmap of the whole row in its own LDS (LDS atomic OR) and
+//                  scans that row itself into its table: no slices, no second hand-off, no table copy;
+//   minor >  thr   TWO hand-offs whose cost does not depend on the ones: a member deposits the ones of its haplotypes
+//                  into a private bitmap of the whole row in its LDS (ds_or_b32, as the one-workgroup kernel does), stores
+//                  it (N / 8 bytes) through the XCD's L2, and the owner of a slice ORs the S members' pieces of it (8
+//                  bytes per thread and member, no filter, no per-entry work), scans it and publishes finished
+//                  {bits, ones before} table entries plus the slice's ones in a flag; every member copies the S slices
+//                  into its table, adding each slice's base.
+// The bitmap of a row (N / 8 bytes) cannot stand next to the table (S x 16 KiB of the 160 KiB) while that is being
+// gathered from: it takes the place of the table's first half once every wave is through its gathers (barrier, clear,
+// barrier), so the deposits of a bitmap line are a pass of their own behind the gathers; the appends of a list line need
+// no such room and stay fused with the gathers.
 // A member can run at most one line ahead of another (to finish line j + 1 it needs every member's lists or bitmap of
 // that line, which a member publishes behind its gathers of line j): lists and their flags are double-buffered by the
 // parity of the line's sequence number.  Bitmaps and slices need no second buffer: a member passes the slice poll of a
 // line only when every member has flagged its slice, i.e. has finished reading the bitmaps, and passes the bitmap poll
-// of a later line only when every member has flagged its bitmap, i.e. has finished copying the slices.
+// of a later line only when every member has flagged its bitmap, i.e. has finished copying the slices.  Sequence
+// numbers grow by one per line and never repeat inside a launch.
+// Hand-offs go through the L2 of ONE XCD: the members of a group are dispatched 8 workgroups apart, i.e. to the same XCD
+// (HW_REG_XCC_ID == blockIdx.x & 7 for every workgroup of a launch, tools/microbench4.hip), and a handshake at the start of
+// the launch verifies it (members on different XCDs abort the launch: the host runs the batch with k_chain_stream).  So
+// the bytes are stored PLAIN (write-through L1, the line stays in the XCD's L2) and loaded with sc1 loads (past L1, served
+// by that L2): 128 KiB written by one workgroup and read by 7 others takes 1.36 us this way against 4.06 us with sc1
+// stores, which drop the line from L2 (profiles/r03_microbench4.txt).  A storing wave waits for its stores (vmcnt(0)) in
+// front of the flag (or of the workgroup barrier behind which the flag is stored); a polling wave loads the bytes only
+// after its own poll has matched.
+// Every workgroup of the grid must be resident for the exchanges to complete: the grid is at most one workgroup per CU
+// and groups walk the blocks persistently.  A wait that does not complete within `timeout_ticks` of the 100 MHz clock
+// raises the abort flag; every poll loop looks at it, the waves leave (a barrier only waits for the waves that are left)
+// and the host runs the batch again with k_chain_stream (xsi_api.hip, encode_run).
+// History (configs[3] shard, encode chain ms; docs/EXPERIMENTS.md has the measurements): every member applying every
+// list + scanning the whole row + one counter meeting per line (round 2) 430; owner-computes lists -> slices -> table
+// copy for every line (rounds 3 - 4) 363 -> 297; bitmaps for every line 326; lists with one hand-off for every line 311;
+// the per-line choice 265.
 // ------------------------------------------------------------------------------------------
-struct RankEncHybArgs {
+constexpr uint32_t MULTI_LIST_CAP = 4096u;  // ranks per wave and line: every one of its 64 x 64 haplotypes
+
+struct RankEncMultiArgs {
     const uint32_t* wah_lines;
     const uint32_t* src;
     uint32_t src_stride_w;
@@ -861,7 +360,7 @@ struct RankEncHybArgs {
 };
 
 template <bool PROF>
-__global__ void __launch_bounds__(1024) k_chain_rank_enc_hyb(const EncBlock* __restrict__ eblocks, RankEncHybArgs A) {
+__global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* __restrict__ eblocks, RankEncMultiArgs A) {
     constexpr uint32_t T = 1024, W = 16;
     constexpr int E = 64, G = 8, SMAX = 8;
     constexpr uint32_t SL_WORDS = 2048u;  // row words of a slice: two per thread
@@ -1185,7 +684,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_hyb(const EncBlock* __r
 
     for (uint32_t i = tid; i < 128u; i += T) wtot[i] = 0;
     __syncthreads();
-    // One-time handshake: the members of a group must share an XCD (see k_chain_rank_enc_multi).
+    // One-time handshake: the members of a group must share an XCD (see the header comment).
     {
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1225,8 +724,10 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_hyb(const EncBlock* __r
             const uint32_t h = (c0 + (uint32_t)e) * 64u + lane_here;
             r[e] = h < N ? h : 0u;
         });
-        // ---- lists: ranks on their way to my wave's list pass through a linear 128-entry buffer in LDS, so that they
-        // leave as whole 256-byte stores (k_chain_rank_enc_multi)
+        // ---- lists: ranks on their way to my wave's list pass through a LINEAR 128-entry buffer in LDS, so that they
+        // leave as whole 256-byte stores (a store of one to three lanes per chunk is one fabric write per lane): the ranks
+        // not yet stored sit at its front (fewer than 64), a chunk's new ones go behind them at `wpos` - a scalar LDS byte
+        // address, so a lane's slot is v_mbcnt x 2 + ONE v_lshl_add - and a flush stores the first 64 and moves the rest down
         uint32_t n_out = 0;
         uint32_t* my_list = nullptr;
         uint32_t* ring = ring_all + w * 128u;
@@ -1404,8 +905,8 @@ bool chain_rank_enc_multi_supported(const EncLines& L) {
            (L.y_stride64 % 2u) == 0u;
 }
 
-static hipError_t launch_rank_encode_hyb_grid(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L, int cus) {
-    RankEncHybArgs A{};
+static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L, int cus) {
+    RankEncMultiArgs A{};
     A.wah_lines = L.wah_lines;
     A.src = L.planes;
     A.src_stride_w = L.plane_stride_w;
@@ -1441,7 +942,7 @@ static hipError_t launch_rank_encode_hyb_grid(hipStream_t s, const EncBlock* blo
     A.prof_buf = prof_buf;
     A.prof_cap = PROF_CAP;
     const uint32_t lds = A.S * 16384u + 512u + 16u * 128u * 4u;
-    auto kern = A.prof ? &k_chain_rank_enc_hyb<true> : &k_chain_rank_enc_hyb<false>;
+    auto kern = A.prof ? &k_chain_rank_enc_multi<true> : &k_chain_rank_enc_multi<false>;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     kern<<<dim3(8u * A.gpx * A.S), dim3(1024), lds, s>>>(blocks, A);
@@ -1463,49 +964,10 @@ static hipError_t launch_rank_encode_hyb_grid(hipStream_t s, const EncBlock* blo
             cntv[tag]++;
         }
         for (int t = 0; t < 12; ++t)
-            fprintf(stderr, "[xsi hyb prof] %-28s %9.3f ms  (%llu records, %.2f us each)\n", nm[t], sum[t] * 1e-5,
+            fprintf(stderr, "[xsi multi prof] %-28s %9.3f ms  (%llu records, %.2f us each)\n", nm[t], sum[t] * 1e-5,
                     (unsigned long long)cntv[t], cntv[t] ? sum[t] * 1e-2 / cntv[t] : 0.0);
     }
     return e;
-}
-
-static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L, int cus) {
-    if (!getenv("XSI_MULTI_LISTS")) return launch_rank_encode_hyb_grid(s, blocks, n_blocks, L, cus);
-    RankEncMultiArgs A{};
-    A.wah_lines = L.wah_lines;
-    A.src = L.planes;
-    A.src_stride_w = L.plane_stride_w;
-    A.cnt = L.cnt;
-    A.dst = reinterpret_cast<uint32_t*>(L.yrows);
-    A.dst_stride_w = L.y_stride64 * 2u;
-    A.N = L.N;
-    A.n_blocks = n_blocks;
-    A.S = (L.N + 65535u) / 65536u;
-    A.gpx = (uint32_t)cus / 8u / A.S;
-    if (A.gpx < 1u) return hipErrorInvalidValue;
-    while (A.gpx > 1u && 8u * (A.gpx - 1u) >= n_blocks) --A.gpx;  // no more groups than blocks need
-    if (8u * A.gpx * A.S > CHAIN_MAX_WGS) return hipErrorInvalidValue;
-    A.sync = L.chain_sync;
-    A.list_flags = L.chain_sync + CHAIN_SYNC_WORDS;
-    A.slice_flags = reinterpret_cast<uint64_t*>(L.chain_sync + CHAIN_SYNC_WORDS + CHAIN_LISTFLAG_WORDS);
-    A.lists = L.chain_lists;
-    A.slices = reinterpret_cast<v4u*>(L.chain_slices);
-    A.test_desert = getenv("XSI_MULTI_TEST_DESERT") ? 1u : 0u;
-    A.prof = getenv("XSI_MULTI_PROF") ? 1u : 0u;
-    A.wave_flags = getenv("XSI_MULTI_RECORD_FLAGS") ? 0u : 1u;  // (0: the workgroup-wide flag record of round 3, testing)
-    A.xcc_ids = L.chain_sync + CHAIN_SYNC_WORDS + CHAIN_LISTFLAG_WORDS + CHAIN_SLICEFLAG_WORDS;
-    // wall_clock64 ticks at 100 MHz; a healthy exchange takes microseconds
-    const char* tmo = getenv("XSI_MULTI_TIMEOUT_MS");
-    A.timeout_ticks = 100000ull * (uint64_t)(tmo && atoi(tmo) > 0 ? atoi(tmo) : 2000);
-    hipError_t e = hipMemsetAsync(L.chain_sync, 0, 4ull * CHAIN_SYNC_TOTAL_WORDS, s);
-    if (e != hipSuccess) return e;
-    const uint32_t lds = A.S * 16384u + 8192u + 256u + 16u * 128u * 4u;
-    auto kern = A.prof ? (A.wave_flags ? &k_chain_rank_enc_multi<true, true> : &k_chain_rank_enc_multi<false, true>)
-                       : (A.wave_flags ? &k_chain_rank_enc_multi<true, false> : &k_chain_rank_enc_multi<false, false>);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    kern<<<dim3(8u * A.gpx * A.S), dim3(1024), lds, s>>>(blocks, A);
-    return hipGetLastError();
 }
 
 hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L) {
