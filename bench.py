@@ -279,7 +279,9 @@ def run_config4(args, real_stdout, emit=True):
         li = int(line_of_block0[int(frac * (len(line_of_block0) - 1))])
         rec = {"line": li, "bm_offset": int(bm[li] & 0x7FFF)}
         for mode in ("prefix", "full"):
-            if mode == "full":
+            had_switch = os.environ.get("XSI_ENABLE_TUNING_ENV")
+            if mode == "full":  # (the library ignores its tuning variables unless the process opts in)
+                os.environ["XSI_ENABLE_TUNING_ENV"] = "1"
                 os.environ["XSI_ACCESSOR_FULL_DECODE"] = "1"
             binding.check(L.xsi_accessor_set_cache_bytes(a, 0))       # evict everything
             binding.check(L.xsi_accessor_set_cache_bytes(a, budget_before))
@@ -288,6 +290,8 @@ def run_config4(args, real_stdout, emit=True):
             r = get(a, int(nal[li]), int(bm[li]), ctypes.byref(pbuf), ctypes.byref(nout))
             rec[mode + "_ms"] = (time.perf_counter() - tq) * 1e3
             os.environ.pop("XSI_ACCESSOR_FULL_DECODE", None)
+            if had_switch is None:
+                os.environ.pop("XSI_ENABLE_TUNING_ENV", None)
             if r != N or not np.array_equal(buf, rows[li].cpu().numpy()):
                 raise SystemExit("cold query at line %d (%s) failed: %s" % (li, mode, L.xsi_hip_last_error()))
         cold_iso.append(rec)

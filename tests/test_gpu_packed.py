@@ -507,15 +507,12 @@ def test_counts_from_the_producer(n_haps, n_lines, block_len, thr, monkeypatch):
 
 
 @pytest.mark.parametrize("n_haps,n_lines,block_len", [(64976, 24, 12), (20000, 40, 20), (131074, 12, 6), (300000, 8, 4)])
-@pytest.mark.parametrize("two_pass", [False, True])
-def test_incompressible_lines_and_words_kept_in_the_row(n_haps, n_lines, block_len, two_pass, monkeypatch):
+def test_incompressible_lines_and_words_kept_in_the_row(n_haps, n_lines, block_len):
     """The WAH sizing pass leaves a line's words in the line's own permuted row when they fit (the writing pass then
     only moves them); a line of (almost) only literal groups takes more bytes than its row (16/15) and is encoded from
     the row again.  Half the lines here are coin flips (every group a literal), the others synthetic; bytes against
-    the oracle, with the in-place words and with XSI_WAH_TWO_PASS=1 (classify twice, as before)."""
+    the oracle."""
     import gpu_util as G
-    if two_pass:
-        monkeypatch.setenv("XSI_WAH_TWO_PASS", "1")
     rng = np.random.default_rng(n_haps)
     bits = synth.synth_bits(5, 0, n_lines, n_haps)
     for l in range(0, n_lines, 2):
@@ -535,17 +532,13 @@ def test_incompressible_lines_and_words_kept_in_the_row(n_haps, n_lines, block_l
 
 
 @pytest.mark.parametrize("n_haps", [131074, 140002, 262144])
-@pytest.mark.parametrize("paint", [False, True])
-def test_long_row_expansion_on_adversarial_rows(n_haps, paint, monkeypatch):
+def test_long_row_expansion_on_adversarial_rows(n_haps):
     """Rows above 16 KiB are expanded by toggles (k_wah_expand_wide_t: every WAH16 word flips the bits where the row
     changes, the row is the running XOR): runs that start and end on 15-bit group, 32-bit word and 64-bit chunk
     boundaries, fills next to literals, literal after literal (lines of several 4096-word rounds), all ones, a single
-    bit at either end - decoded rows against the source, and the same file through round 1's painting kernel
-    (XSI_WAH_EXPAND_PAINT=1).  MAC threshold 0 and one line per block keep every line a WAH line in identity order, so
+    bit at either end - decoded rows against the source.  MAC threshold 0 and one line per block keep every line a WAH line in identity order, so
     the WAH words are exactly the rows' runs."""
     import gpu_util as G
-    if paint:
-        monkeypatch.setenv("XSI_WAH_EXPAND_PAINT", "1")
     rng = np.random.default_rng(n_haps + 7)
     rows = []
     def row():

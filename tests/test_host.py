@@ -386,6 +386,23 @@ def test_append_packs_simple_rows_to_bits():
                 assert L.xsi_debug_pack_bit_row(g2.ctypes.data, n, dp, out.ctypes.data) == 0, (n, dp, pos, bad)
 
 
+@pytest.mark.parametrize("isa", [None, "0", "1"])
+def test_host_packer_under_sanitizers(isa):
+    """`make -C xsqueezeit_amd/csrc asan-host`: the writer's packer (csrc/xsi_pack.cpp) built with AddressSanitizer and
+    UndefinedBehaviorSanitizer against exact-size heap buffers, every row length from 1 to 1100 and the bench sizes, in
+    every instruction-set form this CPU has (the reference's own sanitizer build: /root/reference/Makefile:7-10)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "xsqueezeit_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", csrc, "asan-host"])
+    env = dict(os.environ, XSI_ENABLE_TUNING_ENV="1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0")
+    env.pop("XSI_PACK_ISA", None)
+    env.pop("LD_PRELOAD", None)
+    if isa is not None:
+        env["XSI_PACK_ISA"] = isa
+    r = subprocess.run([os.path.join(ROOT, "tests", "cxx", "_build", "pack_asan")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "pack_asan ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_generated_wah_classification_is_in_sync():
     """csrc/xsi_wah_classify.inc (one hand-scheduled asm statement) is what tools/gen_wah_classify.py writes."""
     import subprocess

@@ -14,7 +14,7 @@ gcc -std=c99 -O2 -I include tests/c/boundary_roundtrip.c -o /tmp/boundary_roundt
   /tmp/boundary_roundtrip /tmp/b1.xsi 2504 100000 8192
   /tmp/boundary_roundtrip /tmp/b2.xsi 32488 12000 8192
   echo "# XSI_WRITER_NO_PACK=1: every line the int32 way (what round 2 did)"
-  XSI_WRITER_NO_PACK=1 /tmp/boundary_roundtrip /tmp/b3.xsi 2504 600000 8192
+  XSI_ENABLE_TUNING_ENV=1 XSI_WRITER_NO_PACK=1 /tmp/boundary_roundtrip /tmp/b3.xsi 2504 600000 8192
   echo "# the pack loop alone (tools/pack_rate.c): xsi_debug_pack_bit_row over rows in DRAM, one thread"
   gcc -O2 -I include tools/pack_rate.c -o /tmp/pack_rate -L xsqueezeit_amd -lxsi_hip -Wl,-rpath,"$PWD/xsqueezeit_amd"
   /tmp/pack_rate 5008 300000 | tail -1

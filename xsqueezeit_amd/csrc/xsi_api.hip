@@ -211,7 +211,7 @@ namespace xsi {
 
 uint64_t ws_budget_now(const xsi_hip_ctx* c, const char* grown) {
     if (c->ws_budget) return c->ws_budget;
-    if (const char* e = getenv("XSI_WS_BUDGET_MB")) return (uint64_t)strtoull(e, nullptr, 10) << 20;
+    if (const char* e = tuning_env("XSI_WS_BUDGET_MB")) return (uint64_t)strtoull(e, nullptr, 10) << 20;
     // half of what is free now plus what this context already holds and will reuse - but never more than the buffer
     // that takes the per-line rows (`grown`: it is freed before it is allocated again) can actually get
     size_t free_b = 0, total_b = 0;
@@ -336,7 +336,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     L.wah_scratch = nullptr;  // without it the lines are sized first and encoded again straight into place
     if (use_wah_scratch && !wah_units_any(L.y_stride64)) WS(L.wah_scratch, "enc.wah_scratch", 2ull * L.wah_scratch_stride * y_rows);
     // the unit encoders read a row into LDS whole: the sizing pass can leave the words in the row's place (read per call: testing)
-    L.wah_inplace = (wah_units_any(L.y_stride64) && !getenv("XSI_WAH_TWO_PASS")) ? 1u : 0u;
+    L.wah_inplace = wah_units_any(L.y_stride64) ? 1u : 0u;
     WS(L.flagbits, "enc.flagbits", 4ull * (MAX_BIN_PER_BLOCK / 32) * FV_COUNT * (size_t)n_blocks);
     WS(L.flagwah, "enc.flagwah", 2ull * FLAG_WORDS_MAX * FV_COUNT * (size_t)n_blocks);
     uint32_t* d_totals;
@@ -363,7 +363,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
         const uint64_t per_line = (1ull + (p->mac_threshold < N / 2u ? p->mac_threshold : N / 2u)) * L.aet;
         sp_stride = (max_bin * per_line + 255u) & ~255ull;
         // (worst-case regions: 2.5 GB for the 153 blocks of a configs[3] shard, where the sparse lists take 19 ms if they wait for the chain)
-        if (sp_stride * n_blocks <= (4ull << 30) && !getenv("XSI_NO_SPARSE_OVERLAP")) WS(sp_scratch, "enc.sparse_scratch", sp_stride * n_blocks);
+        if (sp_stride * n_blocks <= (4ull << 30) && !tuning_env("XSI_NO_SPARSE_OVERLAP")) WS(sp_scratch, "enc.sparse_scratch", sp_stride * n_blocks);
     }
     // The chain over several workgroups per block fills every CU's registers with workgroups that wait for one
     // another: sparse work started first holds CUs back from it for as long as it runs (+18 ms of chain for 19 ms of
@@ -491,7 +491,7 @@ int xsi_hip_encode_packed_counted(xsi_hip_ctx* ctx, const xsi_encode_params* p, 
     if (d_row_counts) {
         // the producer of the rows counted them (the writer's packer does, one popcount per mask): the pass over the
         // matrix that GtBlock::scan_genotypes stands for (gt_block.hpp:207-269) has been made already
-        if (getenv("XSI_CHECK_ROW_COUNTS")) {
+        if (tuning_env("XSI_CHECK_ROW_COUNTS")) {
             HIP_TRY(launch_count_rows(s, reinterpret_cast<const uint32_t*>(d_bits), row_stride_bytes / 4u, N, (uint32_t)n_lines, cnt_all));
             uint32_t* d_bad;
             WS(d_bad, "enc.cnt_check", 4);
@@ -985,7 +985,7 @@ static int run_wah_phases(xsi_hip_ctx* ctx, const uint8_t* f, DecodePlan& P, uin
     stage_mark(ctx, XSI_ST_DEC_EXPAND);  // what shows of the expansion: the wait for its first range
     // (measurement: XSI_DEC_PHASES_SERIAL=1 lets every range expand before the first chain launch, which leaves
     // the chain's launches by themselves: their time minus the unphased chain's is the cost of cutting it up)
-    HIP_TRY(hipStreamWaitEvent(s, ctx->ev_phase[getenv("XSI_DEC_PHASES_SERIAL") ? K - 1u : 0u], 0));
+    HIP_TRY(hipStreamWaitEvent(s, ctx->ev_phase[tuning_env("XSI_DEC_PHASES_SERIAL") ? K - 1u : 0u], 0));
     stage_mark(ctx, XSI_ST_CHAIN_DEC);
     for (uint32_t p = 0; p < K; ++p) {
         const uint32_t* tab = d_tab + (size_t)p * (3u * nb + 1u);
@@ -1078,7 +1078,7 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
     // Cutting the chain into launches costs nothing (24 launches behind a finished expansion: 23.5 ms, as one launch);
     // the expansion beside it costs the chain 3.5 ms and hides 5.2 of its own 5.9.
     const uint32_t n_phases = [] {  // read per call (tests switch it); ms per step at configs[2]: 1: 65.5, 12: 64.1, 24: 63.8, 32: 63.75
-        const char* e = getenv("XSI_DEC_PHASES");
+        const char* e = tuning_env("XSI_DEC_PHASES");
         const int v = e ? atoi(e) : 24;
         return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
     }();
@@ -1088,7 +1088,7 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
         // 0.51 ms visible, the first range's expansion 0.68 -> 0.48).  Short rows only: a long-row chain fills the CUs
         // (section 5.6 of DESIGN.md), the second part just takes its turn there (configs[3] shard 493.2 against 494.0 ms).
         // (XSI_DEC_BOUNDARIES_WHOLE=1: all of it in front, as before - A/B runs)
-        const bool split = getenv("XSI_DEC_BOUNDARIES_WHOLE") == nullptr && L.y_stride64 * 8u <= 16384u;
+        const bool split = tuning_env("XSI_DEC_BOUNDARIES_WHOLE") == nullptr && L.y_stride64 * 8u <= 16384u;
         if (split)
             HIP_TRY(launch_wah_boundaries_part(s, f, P.d_blocks, P.n_blocks, L, 4u * n_phases, 7u, 1));  // run_wah_phases' first three ranges
         else

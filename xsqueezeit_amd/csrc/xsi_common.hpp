@@ -2,8 +2,24 @@
 #pragma once
 
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace xsi {
+
+// Environment switches.  The library reads NO tuning or testing variable unless the process opted in: a stray XSI_*
+// variable in the environment of an HTSLIB caller must not change kernels, thresholds or inject failures.
+//   XSI_ENABLE_TUNING_ENV=1   makes the variables of README.md "Environment switches" effective (dispatch thresholds,
+//                             kernel variants for A/B runs and parity tests, profiling prints)
+//   XSI_ENABLE_TEST_HOOKS=1   makes the three failure-injection hooks effective (tests only)
+// Both are looked up on every read, like the variables themselves (tests switch them inside one process).
+inline const char* tuning_env(const char* name) {
+    const char* on = ::getenv("XSI_ENABLE_TUNING_ENV");
+    return (on && on[0] == '1') ? ::getenv(name) : nullptr;
+}
+inline const char* test_hook_env(const char* name) {
+    const char* on = ::getenv("XSI_ENABLE_TEST_HOOKS");
+    return (on && on[0] == '1') ? ::getenv(name) : nullptr;
+}
 
 // GT block dictionary keys (gt_block.hpp:34-60)
 enum : uint32_t {

@@ -255,6 +255,11 @@ using LdsCU32 = const __attribute__((address_space(3))) uint32_t;
 using LdsU32W = __attribute__((address_space(3))) uint32_t;
 constexpr int WAH_UNIT_ROUNDS = 3;  // 3 x 64 units x 32 groups = 6144 groups >= ceil(65 536 / 15)
 constexpr uint32_t WAH_UNIT_ROW_WORDS = 64u * 15u * (uint32_t)WAH_UNIT_ROUNDS;
+// (hand-scheduled wave64 assembly whose SGPR write-to-read spacing is gfx950's; the hazard recognizer does not look inside
+// inline asm, so building it for any other target is refused rather than left to chance - ADVICE r4)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "xsi_wah_classify.inc is scheduled by hand for gfx950: regenerate it (tools/gen_wah_classify.py) for another target"
+#endif
 #include "xsi_wah_classify.inc"
 struct WahUnit {
     uint32_t H, F, O;  // heads, fill groups, all-ones groups of my unit (bit k = group k of the unit)

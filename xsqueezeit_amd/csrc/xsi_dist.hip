@@ -29,6 +29,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // (optional symbol)
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -47,6 +48,7 @@ const RcclApi& rccl() {
         XSI_SYM(GetUniqueId, "ncclGetUniqueId");
         XSI_SYM(CommInitRank, "ncclCommInitRank");
         XSI_SYM(CommDestroy, "ncclCommDestroy");
+        XSI_SYM(CommAbort, "ncclCommAbort");
         XSI_SYM(AllGather, "ncclAllGather");
         XSI_SYM(Send, "ncclSend");
         XSI_SYM(Recv, "ncclRecv");
@@ -86,6 +88,7 @@ struct xsi_hip_comm {
     xsi_hip_ctx* ctx = nullptr;
     hipStream_t cs = nullptr;    // the exchange runs here, ordered behind the context's stream by ev_in, so that
     hipEvent_t ev_in = nullptr, ev_done = nullptr;  // work the caller enqueues next (the decode) overlaps with it
+    bool broken = false;         // a group was launched with only part of its posts (see gather_block_streams_round): aborted, unusable
     uint64_t* d_meta = nullptr;  // [world + 1][4]: every rank's {bytes, blocks, region capacity, offsets capacity}; the last is this rank's (send buffer)
 };
 
@@ -172,6 +175,7 @@ int xsi_hip_gather_block_streams_round(xsi_hip_comm* c, const void* d_region, ui
                                        uint64_t* d_offsets_all, uint64_t offsets_capacity, uint64_t region_base,
                                        uint64_t blocks_base, uint64_t* h_bytes_per_rank, uint64_t* h_blocks_per_rank) {
     if (!c || dst < 0 || dst >= c->world) return set_error(XSI_ERR_ARG, "gather_block_streams: bad communicator / dst");
+    if (c->broken) return set_error(XSI_ERR_HIP, "gather_block_streams: this communicator was aborted by an earlier failed exchange");
     if ((nbytes && !d_region) || (n_blocks && !d_offsets)) return set_error(XSI_ERR_ARG, "gather_block_streams: null input");
     const RcclApi& R = rccl();
     hipStream_t s = c->cs;
@@ -218,18 +222,21 @@ int xsi_hip_gather_block_streams_round(xsi_hip_comm* c, const void* d_region, ui
     // box; XSI_DIST_TEST_BAD_RECV=1 makes the FIRST receive of the group fail with ncclInvalidArgument as a refused post
     // would (reported here: nothing invalid is handed to RCCL and nothing has been queued yet, so no peer is left
     // waiting for a message that never comes).
-    const bool self_send = getenv("XSI_DIST_SELF_SEND") != nullptr;
-    const bool bad_recv = getenv("XSI_DIST_TEST_BAD_RECV") != nullptr;
+    const bool self_send = test_hook_env("XSI_DIST_SELF_SEND") != nullptr;
+    const bool bad_recv = test_hook_env("XSI_DIST_TEST_BAD_RECV") != nullptr;
     uint8_t* const reg_all = static_cast<uint8_t*>(d_region_all) + region_base;
     uint64_t* const off_all = d_offsets_all ? d_offsets_all + blocks_base : nullptr;
     ncclResult_t first = ncclSuccess;
     const char* what = "";
+    int posted = 0;
     auto post = [&](const char* name, auto&& call) {
         if (first != ncclSuccess) return;
         const ncclResult_t r = call();
         if (r != ncclSuccess) {
             first = r;
             what = name;
+        } else {
+            ++posted;
         }
     };
     NCCL_TRY(R.GroupStart());
@@ -250,7 +257,19 @@ int xsi_hip_gather_block_streams_round(xsi_hip_comm* c, const void* d_region, ui
         if (n_blocks) post("ncclSend(offsets)", [&] { return R.Send(d_offsets, n_blocks, ncclUint64, dst, c->comm, s); });
     }
     const ncclResult_t ge = R.GroupEnd();  // always: a group left open poisons the communicator's next call
-    if (first != ncclSuccess) return set_error(XSI_ERR_HIP, "gather_block_streams: %s: %s", what, R.GetErrorString(first));
+    if (first != ncclSuccess) {
+        // Posts that went through before the refused one were launched by ncclGroupEnd: their peers have matching
+        // operations outstanding and this rank's share of the group is incomplete.  Nothing sound can follow on this
+        // communicator: it is aborted, so that the operations already launched do not wait for ever, and every
+        // later call on it fails at once.  (A first post that is refused leaves nothing behind: the communicator stays usable.)
+        if (posted > 0) {
+            if (R.CommAbort) (void)R.CommAbort(c->comm);
+            c->comm = nullptr;
+            c->broken = true;
+        }
+        return set_error(XSI_ERR_HIP, "gather_block_streams: %s: %s%s", what, R.GetErrorString(first),
+                         posted > 0 ? " (communicator aborted: part of the group had been posted)" : "");
+    }
     if (ge != ncclSuccess) return set_error(XSI_ERR_HIP, "gather_block_streams: ncclGroupEnd: %s", R.GetErrorString(ge));
     if (me == dst) {
         uint64_t bb = 0, bn = 0;

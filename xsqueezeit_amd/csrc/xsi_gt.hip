@@ -879,7 +879,7 @@ int dot_planes(xsi_hip_ctx* ctx, const DecodePlan& P, const uint32_t* planes, ui
     bool any_haploid = false;
     for (auto& b : P.blocks_h)
         if (b.off_line_haploid != VAL_UNDEFINED) any_haploid = true;
-    if (n_pheno >= 8u && !any_haploid && !getenv("XSI_DOT_SCALAR")) {
+    if (n_pheno >= 8u && !any_haploid && !tuning_env("XSI_DOT_SCALAR")) {
         for (uint32_t k0 = 0; k0 < n_pheno; k0 += 16u)
             k_dot_mfma<<<dim3((P.n_bin + 255u) / 256u), dim3(256), 0, ctx->stream>>>(planes, stride_w, P.n_bin, P.L.N, d_y,
                                                                                       n_pheno, k0, d_out);

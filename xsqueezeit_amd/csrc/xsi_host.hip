@@ -345,7 +345,7 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
         uint64_t k = (uint64_t)(2.0 * gpu_ms / (host_ms_per_block > 1e-3 ? host_ms_per_block : 1e-3)) + 1u;
         if (k > 64) k = 64;
         if (k > fit) k = fit;
-        if (const char* e = getenv("XSI_WRITER_BATCH_BLOCKS")) k = strtoull(e, nullptr, 10);
+        if (const char* e = tuning_env("XSI_WRITER_BATCH_BLOCKS")) k = strtoull(e, nullptr, 10);
         if (k < 1 || p->zstd_level) k = 1;
         w->batch_blocks = (uint32_t)k;
     }
@@ -789,7 +789,7 @@ static int accessor_load_block(xsi_accessor* a, uint64_t block, uint32_t need_bi
         }
     ++a->cache_misses;
     // XSI_ACCESSOR_PROF=1: wall clock of the pieces of a first touch (synchronising between them) on stderr
-    const bool prof = getenv("XSI_ACCESSOR_PROF") != nullptr;
+    const bool prof = tuning_env("XSI_ACCESSOR_PROF") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prof = prof ? now() : 0.0;
     auto lap = [&](const char* what) {
@@ -819,7 +819,7 @@ static int accessor_load_block(xsi_accessor* a, uint64_t block, uint32_t need_bi
     a->cnt_block = -1;
     a->win_n = 0;
     const bool want_prefix = need_bin && need_bin < a->P.n_bin && a->P.n_wah >= 64u && decode_partial_supported(a->P) &&
-                             !getenv("XSI_ACCESSOR_FULL_DECODE");
+                             !tuning_env("XSI_ACCESSOR_FULL_DECODE");
     if (want_prefix) {
         hipStream_t s = a->ctx->stream;
         std::vector<uint8_t> kind(a->P.n_bin);
@@ -892,7 +892,7 @@ static int accessor_compose(xsi_accessor* a, uint32_t first, uint32_t n, uint32_
     // kernel reads / writes directly (a few hundred bytes over PCIe): the only copy per call is the rows
     // A single line for a page-locked caller array: the compose kernel stores it there itself (the array's device
     // address; posted writes over PCIe) - one submission and one completion less than kernel + copy.
-    const bool zero_copy = getenv("XSI_ACCESSOR_NO_ZEROCOPY") == nullptr;  // read per call: tests switch it
+    const bool zero_copy = tuning_env("XSI_ACCESSOR_NO_ZEROCOPY") == nullptr;  // read per call: tests switch it
     const bool direct = n == 1u && a->direct_dst;  // only ever set for a registered array of at least N values
     const bool stores_direct = direct && zero_copy && a->reg_dev && a->direct_dst == a->reg_dst;
     int rc = compose_lines(a->ctx, a->P, a->D, a->h_meta, a->h_meta + a->win_rows, n, stores_direct ? a->reg_dev : a->d_rows, N,
@@ -1080,7 +1080,7 @@ int xsi_accessor_open(xsi_accessor** out, xsi_hip_ctx* ctx, const char* path) {
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
         a->cache_budget = free_b / 2;
         if (a->cache_budget > (64ull << 30)) a->cache_budget = 64ull << 30;
-        if (const char* e = getenv("XSI_ACCESSOR_CACHE_MB")) a->cache_budget = (size_t)strtoull(e, nullptr, 10) << 20;
+        if (const char* e = tuning_env("XSI_ACCESSOR_CACHE_MB")) a->cache_budget = (size_t)strtoull(e, nullptr, 10) << 20;
     }
     *out = a;
     return XSI_OK;
@@ -1143,15 +1143,20 @@ static void accessor_drop_registration(xsi_accessor* a) {
 }
 
 // Is [p, p + bytes) page-locked memory the device can address (hipHostMalloc / the caller's own hipHostRegister)?
+// Every page is asked about, not only the two ends: two pinned allocations with pageable or unmapped memory between
+// them would pass an end-point test, and the compose kernels store straight through the mapping.  Done once
+// per registration (a 200 MB array: 50 000 queries, tens of milliseconds).
 static bool page_locked_range(const void* p, size_t bytes) {
     hipPointerAttribute_t at;
-    const unsigned char* b = static_cast<const unsigned char*>(p);
-    for (const unsigned char* q : {b, b + (bytes ? bytes - 1 : 0)}) {
-        if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+    const uintptr_t b = reinterpret_cast<uintptr_t>(p), e = b + (bytes ? bytes - 1 : 0);
+    for (uintptr_t q = b;; q = (q | 4095u) + 1u) {
+        if (q > e) q = e;
+        if (hipPointerGetAttributes(&at, reinterpret_cast<const void*>(q)) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
         if (at.type != hipMemoryTypeHost) return false;
+        if (q == e) break;
     }
     return true;
 }
@@ -1188,7 +1193,7 @@ int xsi_accessor_register_array(xsi_accessor* a, int32_t* h_gt, uint64_t n_value
                          (unsigned long long)n_values, (unsigned long long)a->n_full);
     if (a->ctx) HIP_TRY(hipStreamSynchronize(a->ctx->stream));
     accessor_drop_registration(a);
-    if (getenv("XSI_ACCESSOR_NO_REGISTER")) return XSI_OK;  // measurement: every line through the pinned window + memcpy
+    if (tuning_env("XSI_ACCESSOR_NO_REGISTER")) return XSI_OK;  // measurement: every line through the pinned window + memcpy
     const size_t bytes = (size_t)n_values * sizeof(int32_t);  // the whole array: a batch fills many rows of it
     // Only memory that IS page-locked is taken - xsi_accessor_alloc_array's, or an allocation the caller page-locked
     // itself.  The accessor does not hipHostRegister pageable caller memory any more: on this runtime the unregister
@@ -1294,7 +1299,7 @@ int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint
     a->win_n = 0;  // the single-line window does not survive a batch
     // Destination: rows inside the registered array are stored there by the compose kernels themselves (posted PCIe
     // writes, one completion per chunk); any other memory goes through the device window and one copy per chunk.
-    const bool zero_copy = getenv("XSI_ACCESSOR_NO_ZEROCOPY") == nullptr;
+    const bool zero_copy = tuning_env("XSI_ACCESSOR_NO_ZEROCOPY") == nullptr;
     const uint8_t* rb = reinterpret_cast<const uint8_t*>(a->reg_dst);
     const uint8_t* hb = reinterpret_cast<const uint8_t*>(h_rows);
     const bool direct = zero_copy && a->reg_dst && a->reg_dev && hb >= rb &&
@@ -1313,6 +1318,12 @@ int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint
     uint32_t* ng = oi + a->bmeta_cap;
     std::vector<uint32_t> order;
     int64_t total = 0;
+    // an error inside a chunk leaves compose kernels of its earlier groups in flight, storing into the caller's array
+    // (direct path): they are waited for before the call returns
+    auto bail = [&](int rc) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    };
     for (uint64_t c0 = 0; c0 < n; c0 += chunk_cap) {
         const uint32_t m = (uint32_t)(n - c0 < chunk_cap ? n - c0 : chunk_cap);
         // queries of a chunk grouped by block (stable): one compose launch per block touched
@@ -1338,23 +1349,23 @@ int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint
                 // the composes that read it must have finished
                 if (a->cur_in_workspace) HIP_TRY(hipStreamSynchronize(s));
                 int rc = accessor_load_block(a, block, need);
-                if (rc) return rc;
+                if (rc) return bail(rc);
             }
             for (uint32_t g = g0; g < g1; ++g) {
                 const uint64_t q = c0 + order[g];
                 const uint32_t offset = (uint32_t)(positions[q] & ((1u << BM_BLOCK_BITS) - 1u));
-                if (n_alleles[q] < 2u) return set_error(XSI_ERR_ARG, "get_genotypes_batch: query %llu: n_alleles < 2", (unsigned long long)q);
+                if (n_alleles[q] < 2u) return bail(set_error(XSI_ERR_ARG, "get_genotypes_batch: query %llu: n_alleles < 2", (unsigned long long)q));
                 if (offset + (n_alleles[q] - 1u) > a->P.n_bin)
-                    return set_error(XSI_ERR_ARG, "get_genotypes_batch: query %llu: offset %u (+%u alleles) beyond the %u binary lines of block %llu",
-                                     (unsigned long long)q, offset, n_alleles[q] - 1u, a->P.n_bin, (unsigned long long)block);
+                    return bail(set_error(XSI_ERR_ARG, "get_genotypes_batch: query %llu: offset %u (+%u alleles) beyond the %u binary lines of block %llu",
+                                          (unsigned long long)q, offset, n_alleles[q] - 1u, a->P.n_bin, (unsigned long long)block));
                 fb[g] = offset;
                 na[g] = n_alleles[q];
                 oi[g] = order[g];
             }
             int rc = accessor_ensure_lines(a, need);
-            if (rc) return rc;
+            if (rc) return bail(rc);
             rc = compose_lines(a->ctx, a->P, a->D, fb + g0, na + g0, g1 - g0, d_dst, d_stride, ng, nullptr, 0, oi + g0);
-            if (rc) return rc;
+            if (rc) return bail(rc);
             g0 = g1;
         }
         if (!direct) {
@@ -1364,11 +1375,9 @@ int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint
                 HIP_TRY(hipMemcpy2DAsync(h_rows + c0 * row_stride, row_stride * sizeof(int32_t), a->d_rows, N * sizeof(int32_t),
                                          N * sizeof(int32_t), m, hipMemcpyDeviceToHost, s));
         }
-        // one completion per chunk: the pinned metadata is reused by the next chunk, and the rows must have landed
-        hipError_t qe;
-        while ((qe = hipStreamQuery(s)) == hipErrorNotReady) {
-        }
-        HIP_TRY(qe);
+        // one completion per chunk: the pinned metadata is reused by the next chunk, and the rows must have landed (a chunk
+        // is milliseconds of work: a blocking wait, not the single query's poll loop, which holds a core)
+        HIP_TRY(hipStreamSynchronize(s));
         for (uint32_t i = 0; i < m; ++i) {
             if (h_ngt) h_ngt[c0 + i] = ng[i];
             total += ng[i];

@@ -202,7 +202,7 @@ hipError_t launch_count_rows(hipStream_t s, const uint32_t* planes, uint32_t str
                                                                           stride_w / 4u, nbits, n_rows, cnt);
         return hipGetLastError();
     }
-    if ((stride_w & 3u) == 0 && (reinterpret_cast<uintptr_t>(planes) & 15u) == 0 && !getenv("XSI_COUNT_DWORD")) {
+    if ((stride_w & 3u) == 0 && (reinterpret_cast<uintptr_t>(planes) & 15u) == 0 && !tuning_env("XSI_COUNT_DWORD")) {
         k_count_rows_wide<<<dim3((n_rows + 3u) / 4u), dim3(256), 0, s>>>(reinterpret_cast<const uint4*>(planes), stride_w / 4u,
                                                                         nbits, n_rows, cnt);
         return hipGetLastError();
@@ -1306,7 +1306,7 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
         // encode: A.only_haploid_blocks arrives as "some block has fully haploid lines"
         const bool any_haploid = A.only_haploid_blocks != 0;
         if (!DECODE) A.only_haploid_blocks = A.plain_done;  // rank tracking done: only the haploid blocks are left
-        if (!DECODE && !A.plain_done && A.cw <= 1024u * STREAM_ROW_REGS && !getenv("XSI_NO_STREAM_CHAIN")) {
+        if (!DECODE && !A.plain_done && A.cw <= 1024u * STREAM_ROW_REGS && !tuning_env("XSI_NO_STREAM_CHAIN")) {
             // streaming kernel for the blocks without fully haploid lines, the two-pass kernel for the rest
             const uint32_t seg = (((A.N + 15u) / 16u) + 63u) & ~63u;  // positions per wave
             const uint32_t lds = (2u * A.cw + 3u * 16u) * 4u;
@@ -1332,11 +1332,11 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
     A.segments = 1;
     if (!DECODE && g.chunks <= 16 && !A.only_haploid_blocks) {
         static const int env_s = [] {
-            const char* e = getenv("XSI_CHAIN_SEGMENTS");
+            const char* e = tuning_env("XSI_CHAIN_SEGMENTS");
             return e ? atoi(e) : 0;
         }();
         static const double rho = [] {
-            const char* e = getenv("XSI_CHAIN_RHO");
+            const char* e = tuning_env("XSI_CHAIN_RHO");
             return e ? atof(e) : 0.55;  // measured best at the bench size (0.25 ... 0.65 swept)
         }();
         uint32_t S = 256u / n_blocks;
@@ -1400,7 +1400,7 @@ static hipError_t launch_chain(hipStream_t s, const EncBlock* eb, const DecBlock
 //   decode  always the element-major kernels of xsi_rank.hip (launch_rank_decode picks the geometry).
 // XSI_RANKENC_MIN_N overrides the size rule (testing: force the kernel for every N); read per call.
 static bool use_rank_encode(uint32_t N, uint32_t n_blocks) {
-    const char* ev = getenv("XSI_RANKENC_MIN_N");
+    const char* ev = tuning_env("XSI_RANKENC_MIN_N");
     const int env = ev ? atoi(ev) : -1;
     if (!chain_rank_enc_supported(N)) return false;
     if (env >= 0) return N >= (uint32_t)env;
@@ -1410,7 +1410,7 @@ static bool use_rank_encode(uint32_t N, uint32_t n_blocks) {
 const char* chain_kernel_name(uint32_t N, uint32_t n_blocks, bool decode) {
     if (decode) return rank_decode_kernel_name(N, ((N + 63u) / 64u) * 2u, n_blocks);
     if (use_rank_encode(N, n_blocks)) return "k_chain_rank_enc";
-    if (N > 65536u && N <= 524288u && !getenv("XSI_NO_RANKENC_MULTI")) return "k_chain_rank_enc_multi";
+    if (N > 65536u && N <= 524288u && !tuning_env("XSI_NO_RANKENC_MULTI")) return "k_chain_rank_enc_multi";
     return N <= 65536u ? "k_chain_lds" : "k_chain_stream";
 }
 
@@ -1587,7 +1587,7 @@ __global__ void __launch_bounds__(256) k_wah_units_small(EncLines L, const uint3
 
 // rows the small-row kernel takes: at least two lines per wave, and none of the longer-row kernels applies
 static uint32_t wah_units_small_upl(const EncLines& L) {
-    static const bool off = getenv("XSI_WAH_NO_SMALL") != nullptr;
+    static const bool off = tuning_env("XSI_WAH_NO_SMALL") != nullptr;
     const uint32_t G = (L.N + WAH_BITS - 1u) / WAH_BITS, upl = (G + 31u) / 32u;
     return (!off && upl >= 1u && upl <= 32u && !wah_units_any(L.y_stride64)) ? upl : 0u;
 }
@@ -1837,7 +1837,7 @@ __global__ void __launch_bounds__(1024) k_wah_units_wide(const EncBlock* __restr
 }
 
 static bool wah_units_wide_ok(uint32_t y_stride64) {
-    const bool off = getenv("XSI_WAH_NO_UNITS") != nullptr;
+    const bool off = tuning_env("XSI_WAH_NO_UNITS") != nullptr;
     // rows of whole 16-byte units (y_stride64 even) of at most 65 536 groups
     return !off && y_stride64 > 64u * (uint32_t)WAH_STAGE_Q && (y_stride64 % 2u) == 0u &&
            (uint64_t)y_stride64 * 64u <= (uint64_t)WAH_WIDE_UNITS * 32u * WAH_BITS;
@@ -1858,7 +1858,7 @@ static hipError_t launch_wah_units_wide(hipStream_t s, const EncBlock* blocks, c
 }
 
 bool wah_units_ok(uint32_t y_stride64) {
-    static const bool off = getenv("XSI_WAH_NO_UNITS") != nullptr;
+    static const bool off = tuning_env("XSI_WAH_NO_UNITS") != nullptr;
     // below ~12 000 haplotypes a line has fewer than 26 units for 64 lanes: the serial encoder with its scratch
     // copy is faster there (5008 hap x 1 M: sizing + writing 0.85 ms against 1.81 ms)
     return !off && y_stride64 >= 192u && y_stride64 <= 64u * (uint32_t)WAH_STAGE_Q;
@@ -1869,20 +1869,16 @@ bool wah_units_any(uint32_t y_stride64) { return wah_units_ok(y_stride64) || wah
 hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_total_wah, uint32_t max_wah) {
     if (!max_wah) return hipSuccess;
     const uint32_t per_wg = 4u * WAH_LINES_PER_WAVE;
-    if (wah_units_wide_ok(L.y_stride64))
-        return L.wah_inplace ? launch_wah_units_wide<2>(s, nullptr, L, d_total_wah, max_wah, nullptr, nullptr)
-                             : launch_wah_units_wide<0>(s, nullptr, L, d_total_wah, max_wah, nullptr, nullptr);
+    // the unit encoders size a line AND leave its words in the line's own row (MODE 2, L.wah_inplace; the size-only /
+    // write-only modes 0 and 1 of round 2 - two classifications per line - are no longer instantiated)
+    if (wah_units_wide_ok(L.y_stride64)) return launch_wah_units_wide<2>(s, nullptr, L, d_total_wah, max_wah, nullptr, nullptr);
     if (wah_units_ok(L.y_stride64)) {
         const uint32_t row_words = wah_units_row_words(L.y_stride64);
         const uint32_t lds = 4u * 4u * (row_words + WAH_UNIT_SCRATCH_WORDS);
-        const void* fn = L.wah_inplace ? reinterpret_cast<const void*>(&k_wah_units<2>) : reinterpret_cast<const void*>(&k_wah_units<0>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         const dim3 grid((max_wah + per_wg - 1u) / per_wg);
-        if (L.wah_inplace)
-            k_wah_units<2><<<grid, dim3(256), lds, s>>>(nullptr, L, d_total_wah, max_wah, nullptr, nullptr, row_words);
-        else
-            k_wah_units<0><<<grid, dim3(256), lds, s>>>(nullptr, L, d_total_wah, max_wah, nullptr, nullptr, row_words);
+        k_wah_units<2><<<grid, dim3(256), lds, s>>>(nullptr, L, d_total_wah, max_wah, nullptr, nullptr, row_words);
         return hipGetLastError();
     }
     if (const uint32_t upl = wah_units_small_upl(L)) {
@@ -1969,18 +1965,6 @@ hipError_t launch_wah_write(hipStream_t s, const EncBlock* blocks, const EncLine
                             uint8_t* out, const uint64_t* d_result) {
     if (!max_wah) return hipSuccess;
     const uint32_t per_wg = 4u * WAH_LINES_PER_WAVE;
-    if (!L.wah_scratch && !L.wah_inplace && wah_units_wide_ok(L.y_stride64))
-        return launch_wah_units_wide<1>(s, blocks, L, nullptr, max_wah, out, d_result);
-    if (!L.wah_scratch && !L.wah_inplace && wah_units_ok(L.y_stride64)) {  // classify again, words straight into place
-        const uint32_t row_words = wah_units_row_words(L.y_stride64);
-        const uint32_t lds = 4u * 4u * (row_words + WAH_UNIT_SCRATCH_WORDS);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_units<1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        k_wah_units<1><<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), lds, s>>>(blocks, L, nullptr, max_wah, out,
-                                                                                     d_result, row_words);
-        return hipGetLastError();
-    }
     k_wah_write<<<dim3((max_wah + per_wg - 1u) / per_wg), dim3(256), 0, s>>>(blocks, L, max_wah, out, d_result);
     return hipGetLastError();
 }
@@ -3004,167 +2988,14 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
     }
 }
 
-// Rows above 16 KiB: one 1024-thread workgroup per WAH line.  The one-wave-per-line kernel above keeps the row in
-// LDS, so at 500 000 haplotypes (62.5 KB) only two of its one-wave workgroups fit a CU: 46 ms per launch.  Here
-// all 16 waves expand the words into the LDS row, 1024 words a round (group counts scanned per wave, the 16 wave
-// totals scanned in LDS), and all 16 waves turn the row into {bits, ones before} pairs: thread t works on words
-// 2 t, 2 t + 1 of a stripe of 2048 words, a wave scan per stripe, the 16 x stripes totals scanned in row order by
-// wave 0.  39 ms for the 750 k lines of a configs[3] shard by itself (94 GB of pairs: 2.4 TB/s).
 constexpr int WAH_WIDE_STRIPES = 20;  // 20 x 1024 words: rows up to 655 360 bits
-__global__ void __launch_bounds__(1024) k_wah_expand_wide(const uint8_t* __restrict__ file, const DecBlock* __restrict__ blocks,
-                                                          DecLines L, const uint32_t* __restrict__ d_totals,
-                                                          const uint32_t* __restrict__ ph_start,
-                                                          const uint32_t* __restrict__ ph_gpre, uint32_t n_blocks) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* row = reinterpret_cast<uint32_t*>(smem);
-    const uint32_t rw = L.y_stride64 * 2u;
-    uint32_t* tot = row + rw;  // [stripes][16] + [1]
-    uint32_t j = blockIdx.x;
-    if (ph_start) {  // one range of every block's lines (phased decode), one line per group: see k_wah_expand
-        uint32_t lo = 0, hi = n_blocks;
-        while (hi - lo > 1u) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (ph_gpre[mid] <= j) lo = mid;
-            else hi = mid;
-        }
-        j = ph_start[lo] + (j - ph_gpre[lo]);
-    }
-    if (j >= d_totals[1] || d_totals[3]) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    // The line's metadata is a chain of three dependent loads and its first words a fourth: with two workgroups per CU
-    // nothing else covers them, so they are issued before the row is cleared, and every round of 1024 words fetches
-    // the next round's words before it works on its own (38.5 -> 36.1 ms for the WAH lines of a configs[3] shard).
-    const uint32_t l = L.wah_lines[j];
-    const DecBlock& D = blocks[L.line_block[l]];
-    const uint32_t start = L.wah_start[j];
-    const uint32_t nbits = (L.kind[l] & KIND_HAPLOID) ? L.n_samples : L.N;
-    using GlobU16W = const __attribute__((address_space(1))) uint16_t;
-    GlobU16W* src = (GlobU16W*)(reinterpret_cast<const uint16_t*>(file + D.gt_off + D.off_wah) + start);  // global, not flat
-    const uint32_t max_words = D.wah_words - start;
-    uint32_t nxt_word = (uint32_t)src[tid < max_words ? tid : 0u];
-    for (uint32_t i = tid; i < rw; i += 1024u) row[i] = 0;
-    __syncthreads();
-    {
-        // all 16 waves expand the line's words, 1024 at a time (wave_wah_expand_row's logic with the first group of
-        // a word taken from a workgroup scan): a line of 500 000 bits has some 2500 words
-        const uint32_t G = (nbits + WAH_BITS - 1u) / WAH_BITS;
-        const uint32_t row_bits = ((nbits + 31u) >> 5) << 5;
-        uint32_t gbase = 0, cnt1 = 0;
-        for (uint32_t wbase = 0; wbase < max_words && gbase < G; wbase += 1024u) {
-            const uint32_t wi = wbase + tid;
-            const bool have = wi < max_words;
-            const uint32_t word = have ? nxt_word : 0u;
-            nxt_word = (uint32_t)src[wi + 1024u < max_words ? wi + 1024u : 0u];  // unconditional: in flight across this round
-            const bool fill = (word & 0x8000u) != 0u;
-            const uint32_t ng = have ? (fill ? (word & WAH_MAXC) : 1u) : 0u;
-            const uint32_t inc = wave_scan_incl_dpp(ng);
-            if (lane == 63u) tot[w] = inc;
-            __syncthreads();
-            const uint32_t sc = row16_scan_incl(lane < 16u ? tot[lane] : 0u);
-            const uint32_t wave_base = w ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)w - 1) : 0u;
-            const uint32_t chunk_groups = (uint32_t)__builtin_amdgcn_readlane((int)sc, 15);
-            const uint32_t sg = gbase + wave_base + inc - ng;  // first group covered by this word
-            const bool active = have && sg < G;
-            if (active) {
-                if (!fill) {
-                    const uint32_t o = sg * WAH_BITS;
-                    const uint32_t v = word & 0x7FFFu;
-                    cnt1 += (uint32_t)__popc(v);
-                    if (v && o < row_bits) {
-                        atomicOr(&row[o >> 5], v << (o & 31u));
-                        if ((o & 31u) > 17u && (o >> 5) + 1u < (row_bits >> 5)) atomicOr(&row[(o >> 5) + 1u], v >> (32u - (o & 31u)));
-                    }
-                } else if (word & 0x4000u) {
-                    cnt1 += ng * WAH_BITS;
-                }
-            }
-            uint64_t F = __ballot(active && fill && (word & 0x4000u) && ng);  // ones-fills: the wave paints each run
-            while (F) {
-                const int f = __ffsll((long long)F) - 1;
-                F &= F - 1ull;
-                const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)sg, f);
-                const uint32_t fn = (uint32_t)__builtin_amdgcn_readlane((int)ng, f);
-                uint32_t b0 = fs * WAH_BITS, b1 = b0 + fn * WAH_BITS;
-                if (b1 > row_bits) b1 = row_bits;
-                if (b0 >= b1) continue;
-                const uint32_t w0 = b0 >> 5, w1 = (b1 - 1u) >> 5;
-                for (uint32_t x = w0 + lane; x <= w1; x += 64u) {
-                    uint32_t m = 0xFFFFFFFFu;
-                    if (x == w0) m &= 0xFFFFFFFFu << (b0 & 31u);
-                    if (x == w1 && (b1 & 31u)) m &= (1u << (b1 & 31u)) - 1u;
-                    atomicOr(&row[x], m);
-                }
-            }
-            gbase += chunk_groups;
-            __syncthreads();  // tot[] is reused by the next round (and by the scan below)
-        }
-        const uint32_t wsum = wave_sum(cnt1);
-        if (lane == 0) tot[16 + w] = wsum;
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t ones = 0;
-            for (int i = 0; i < 16; ++i) ones += tot[16 + i];
-            L.ones[l] = ones;
-        }
-    }
-    __syncthreads();
-    // thread t works on words 2 t, 2 t + 1 of a stripe of 2048 words: its two pairs leave as ONE 16-byte store
-    // (8-byte accesses reach 0.54-0.70 of the 16-byte rate on this chip, MI355X_MICROARCH.md; yp_stride is even)
-    constexpr int STR2 = WAH_WIDE_STRIPES / 2;
-    const uint32_t stripes = (L.yp_stride + 2047u) / 2048u;  // <= STR2
-    uint32_t excl[STR2], w0s[STR2], w1s[STR2];
-#pragma unroll
-    for (int i = 0; i < STR2; ++i) {
-        excl[i] = 0;
-        w0s[i] = w1s[i] = 0;
-        if ((uint32_t)i < stripes) {  // uniform
-            const uint32_t idx = (uint32_t)i * 2048u + 2u * tid;
-            if (idx < rw) {  // rw is even
-                const uint2 v = *reinterpret_cast<const uint2*>(row + idx);
-                w0s[i] = v.x;
-                w1s[i] = v.y;
-            }
-            const uint32_t c = (uint32_t)__popc(w0s[i]) + (uint32_t)__popc(w1s[i]);
-            const uint32_t inc = wave_scan_incl_dpp(c);
-            excl[i] = inc - c;
-            if (lane == 63u) tot[i * 16 + (int)w] = inc;
-        }
-    }
-    __syncthreads();
-    if (w == 0) {
-        constexpr int PER = (STR2 * 16 + 63) / 64;
-        uint32_t a[PER], sum = 0;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const uint32_t idx = lane * (uint32_t)PER + (uint32_t)k;
-            a[k] = idx < stripes * 16u ? tot[idx] : 0u;
-            sum += a[k];
-        }
-        uint32_t run = wave_scan_incl_dpp(sum) - sum;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const uint32_t idx = lane * (uint32_t)PER + (uint32_t)k;
-            if (idx < stripes * 16u) tot[idx] = run;
-            run += a[k];
-        }
-        if (lane == 63u) L.wah_z[j] = nbits - run;
-    }
-    __syncthreads();
-    uint4* dst = reinterpret_cast<uint4*>(L.yp + (size_t)j * L.yp_stride);
-#pragma unroll
-    for (int i = 0; i < STR2; ++i)
-        if ((uint32_t)i < stripes) {
-            const uint32_t idx = (uint32_t)i * 2048u + 2u * tid;
-            const uint32_t pre0 = tot[i * 16 + (int)w] + excl[i];
-            if (idx < L.yp_stride) dst[idx >> 1] = make_uint4(w0s[i], pre0, w1s[i], pre0 + (uint32_t)__popc(w0s[i]));
-        }
-}
-
 // Rows above 16 KiB by TOGGLES (round 4; see "expansion by TOGGLES" in xsi_device.hpp for the idea): one 1024-thread
-// workgroup walks WAH_WIDE_LPG consecutive lines.  Per line: (A) a thread takes four consecutive words of a round of
+// workgroup walks WAH_WIDE_LPG consecutive lines.  (The one-wave-per-line kernel above keeps the row in LDS, so at 500 000
+// haplotypes - 62.5 KB - only two of its one-wave workgroups fit a CU: 46 ms per launch; round 3's workgroup-per-line
+// kernel that PAINTED every fill into the row took 37.9 ms and is gone: docs/EXPERIMENTS.md.)  Per line: (A) a thread takes four consecutive words of a round of
 // 4096 (one 8-byte load; a line of 500 000 bits has some 2500 words, so one round as a rule), the groups in front of
 // each word come from one workgroup scan, every word deposits its toggles with at most two LDS atomic XORs - no loop
-// over the fills, which is what the painting kernel above spends its time in; (B) thread t turns words 2 t, 2 t + 1 of
+// over the fills, which is what a painting kernel spends its time in; (B) thread t turns words 2 t, 2 t + 1 of
 // every 2048-word stripe into the line's bits (prefix_xor32, a ballot's parity from lane to lane) and counts them AS IF
 // its wave started outside a run; a wave that starts inside one has exactly the complement (64 - c ones per lane), so
 // one pass of wave 0 over the (stripe, wave) parities and totals settles both the carries and the "ones before" of
@@ -3227,6 +3058,10 @@ __global__ void __launch_bounds__(1024) k_wah_expand_wide_t(const uint8_t* __res
         const uint64_t at = D.gt_off + D.off_wah + 2ull * start;
         const uint64_t sw = at < L.file_len ? (L.file_len - at) / 2u : 0u;
         m_safe = sw < 0xFFFFFFFFull ? (uint32_t)sw : 0xFFFFFFFFu;
+        if (sw < 4u) {  // fewer than 8 bytes between the line's start and the image's end (a truncated or hostile image): the
+            m_src = reinterpret_cast<uint64_t>(file);  // fallback 8-byte load of load4 would run past the end - it reads the
+            m_safe = 0;                                 // header instead, and the line has no words
+        }
     }
     using GlobU16W = const __attribute__((address_space(1))) uint16_t;
     using GlobU32A2 = const __attribute__((address_space(1))) u32_align2;
@@ -3404,23 +3239,19 @@ __global__ void __launch_bounds__(1024) k_wah_expand_wide_t(const uint8_t* __res
 }
 
 static bool wah_expand_is_wide(const DecLines& L) {
-    return L.y_stride64 * 8u > 16384u && L.yp_stride <= 1024u * (uint32_t)WAH_WIDE_STRIPES && !getenv("XSI_NO_WIDE_EXPAND");
+    return L.y_stride64 * 8u > 16384u && L.yp_stride <= 1024u * (uint32_t)WAH_WIDE_STRIPES && !tuning_env("XSI_NO_WIDE_EXPAND");
 }
 
-static bool wah_expand_paints() { return getenv("XSI_WAH_EXPAND_PAINT") != nullptr; }  // read per call (tests and A/B runs switch)
-
-uint32_t wah_expand_lines_per_group(const DecLines& L) {
-    return wah_expand_is_wide(L) ? (wah_expand_paints() ? 1u : WAH_WIDE_LPG) : WAH_LINES_PER_WAVE;
-}
+uint32_t wah_expand_lines_per_group(const DecLines& L) { return wah_expand_is_wide(L) ? WAH_WIDE_LPG : WAH_LINES_PER_WAVE; }
 
 // ph_start == nullptr: all WAH lines of the batch (n_groups ignored); else one range of every block's lines
 static hipError_t launch_wah_expand_any(hipStream_t s, const uint8_t* file, const DecBlock* blocks, const DecLines& L,
                                         uint32_t max_wah, const uint32_t* d_totals, const uint32_t* ph_start,
                                         const uint32_t* ph_cnt, const uint32_t* ph_gpre, uint32_t n_blocks, uint32_t n_groups) {
     const uint32_t lds = L.y_stride64 * 8u;
-    if (wah_expand_is_wide(L) && !wah_expand_paints()) {
+    if (wah_expand_is_wide(L)) {
         const uint32_t lds_w = lds + 4u * (32u + 2u * (uint32_t)(WAH_WIDE_STRIPES / 2) * 16u + 1u);
-        const bool prof = getenv("XSI_WIDE_PROF") != nullptr;
+        const bool prof = tuning_env("XSI_WIDE_PROF") != nullptr;
         auto kern = prof ? &k_wah_expand_wide_t<true> : &k_wah_expand_wide_t<false>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
         if (e != hipSuccess) return e;
@@ -3433,15 +3264,6 @@ static hipError_t launch_wah_expand_any(hipStream_t s, const uint8_t* file, cons
             fprintf(stderr, "[xsi wide prof] cumulative us of wave 0 of the middle workgroup: start %.1f, A %.1f, B1 %.1f, barrier %.1f, wave-0 pass %.1f, barrier %.1f, B2 %.1f\n",
                     pr[0] * 1e-2, pr[1] * 1e-2, pr[2] * 1e-2, pr[3] * 1e-2, pr[4] * 1e-2, pr[5] * 1e-2, pr[6] * 1e-2);
         }
-        return hipGetLastError();
-    }
-    if (wah_expand_is_wide(L)) {
-        const uint32_t lds_w = lds + 4u * ((uint32_t)WAH_WIDE_STRIPES * 16u + 16u);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_expand_wide),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
-        if (e != hipSuccess) return e;
-        k_wah_expand_wide<<<dim3(ph_start ? n_groups : max_wah), dim3(1024), lds_w, s>>>(file, blocks, L, d_totals, ph_start, ph_gpre,
-                                                                                       n_blocks);
         return hipGetLastError();
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wah_expand),
@@ -3629,7 +3451,7 @@ hipError_t launch_sparse_fill(hipStream_t s, const uint8_t* file, const DecBlock
     if (!max_sparse) return hipSuccess;
     const uint32_t lds = out_stride_w * 4u;
     if (lds > 16384u && (out_stride_w & 3u) == 0u && (reinterpret_cast<uintptr_t>(out_rows) & 15u) == 0u &&
-        !getenv("XSI_SPARSE_FILL_LDS")) {
+        !tuning_env("XSI_SPARSE_FILL_LDS")) {
         k_sparse_fill_direct<<<dim3(max_sparse), dim3(256), 0, s>>>(file, blocks, L, d_totals, out_rows, out_stride_w, apply_negation);
         return hipGetLastError();
     }

@@ -4,6 +4,8 @@
 #include <cstdint>
 #include <cstdlib>
 
+#include "xsi_common.hpp"
+
 namespace xsi {
 bool pack_bit_row(const int32_t* gt, uint32_t n, int dp, uint8_t* out);  // declared for the library in xsi_ctx.hpp
 
@@ -80,9 +82,9 @@ static bool pack_bit_row_scalar(const int32_t* gt, uint32_t n, int dp, uint8_t* 
 }
 bool pack_bit_row(const int32_t* gt, uint32_t n, int dp, uint8_t* out) {
     static const int isa = [] {
-        if (getenv("XSI_WRITER_NO_PACK")) return -1;  // testing: every line the int32 way
+        if (tuning_env("XSI_WRITER_NO_PACK")) return -1;  // testing: every line the int32 way
         __builtin_cpu_init();
-        if (const char* e = getenv("XSI_PACK_ISA")) {  // testing: 0 scalar, 1 AVX2 (the tests run every form the CPU has)
+        if (const char* e = tuning_env("XSI_PACK_ISA")) {  // testing: 0 scalar, 1 AVX2 (the tests run every form the CPU has)
             const int want = atoi(e);
             if (want == 0 || (want == 1 && __builtin_cpu_supports("avx2"))) return want;
         }

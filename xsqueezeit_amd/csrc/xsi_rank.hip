@@ -614,12 +614,12 @@ static RankGeom rank_geometry(uint32_t N, uint32_t yp_stride, uint32_t n_blocks)
     // haplotypes over S workgroups multiplies that L2 traffic by S.  Prefer the largest workgroup
     // that still gives about one workgroup per CU, and at most 8 chunks per wave.
     static const int env_e = [] {
-        const char* e = getenv("XSI_DEC_E");
+        const char* e = tuning_env("XSI_DEC_E");
         const int v = e ? atoi(e) : 0;
         return (v >= 1 && v <= 8) ? v : 0;
     }();
     static const int env_t = [] {
-        const char* e = getenv("XSI_DEC_T");
+        const char* e = tuning_env("XSI_DEC_T");
         const int v = e ? atoi(e) : 0;
         return (v == 256 || v == 512 || v == 1024) ? v : 0;
     }();
@@ -649,7 +649,7 @@ static RankGeom rank_geometry(uint32_t N, uint32_t yp_stride, uint32_t n_blocks)
         // A batch costs a barrier, a flush and a wait for its rows whatever its size (configs[1], 1024 threads: 8 lines
         // per batch 2.58 ms, 16: 2.15, 24: 2.06, 32: 2.05), so batches are as long as the registers
         // (RANK_RP pairs per thread) and LDS allow: 64 KB when several workgroups share a CU, 128 KB when one has it.
-        static const uint32_t bcap = [] { const char* e = getenv("XSI_DEC_BCAP"); const int v = e ? atoi(e) : 32; return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
+        static const uint32_t bcap = [] { const char* e = tuning_env("XSI_DEC_BCAP"); const int v = e ? atoi(e) : 32; return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
         if (B > bcap) B = bcap;
         if (B < 1u) B = 1u;
         auto need = [&](uint32_t b) { return 2u * b * yp_stride * 8u + 3u * b * 8u + 2u * b * per_wg * 8u + 64u; };
@@ -697,7 +697,7 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) 
     const uint32_t lds = ((A.yp_stride / 2u + 1023u) / 1024u) * 16384u;  // whole 1024-unit pieces (see the kernel's store_row)
     auto splits_of = [&](uint32_t e) { return (nch + 16u * e - 1u) / (16u * e); };
     static const int env_e = [] {
-        const char* e = getenv("XSI_DEC_BIG_E");
+        const char* e = tuning_env("XSI_DEC_BIG_E");
         return e ? atoi(e) : 0;
     }();
     const uint32_t RP = A.yp_stride <= 8u * 1024u ? 8u : (A.yp_stride <= 16u * 1024u ? 16u : 20u);
@@ -718,7 +718,7 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) 
         if (e != hipSuccess) return e;                                                                       \
         A.big_splits = splits_of(EE);                                                                        \
         A.big_n_blocks = n_blocks;                                                                           \
-        A.big_prof = getenv("XSI_BIG_PROF") ? 1u : 0u;                                                       \
+        A.big_prof = tuning_env("XSI_BIG_PROF") ? 1u : 0u;                                                       \
         if (A.big_prof) {                                                                                    \
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank_big<EE, RR, true>),   \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
@@ -756,7 +756,7 @@ uint32_t rank_decode_big_wgs_per_block(uint32_t N, uint32_t yp_stride) {
     const uint32_t nch = (N + 63u) / 64u;
     const uint32_t RP = yp_stride <= 8u * 1024u ? 8u : (yp_stride <= 16u * 1024u ? 16u : 20u);
     uint32_t e_max = RP == 20u ? 16u : 64u;
-    if (const char* e = getenv("XSI_DEC_BIG_E")) {
+    if (const char* e = tuning_env("XSI_DEC_BIG_E")) {
         const uint32_t v = (uint32_t)atoi(e);
         if ((v == 8u || v == 16u || v == 32u || v == 64u) && v <= e_max) e_max = v;
     }
@@ -765,7 +765,7 @@ uint32_t rank_decode_big_wgs_per_block(uint32_t N, uint32_t yp_stride) {
 
 // one workgroup per block: batches with about as many blocks as CUs, rows that fit a 16 KiB LDS slot
 static bool use_rank_wg(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
-    const char* ev = getenv("XSI_RANK_WG_MIN_BLOCKS");  // read per call (tests switch kernels in one process)
+    const char* ev = tuning_env("XSI_RANK_WG_MIN_BLOCKS");  // read per call (tests switch kernels in one process)
     const uint32_t min_blocks = ev ? (uint32_t)atoi(ev) : 192u;
     return yp_stride <= 2048u && N >= 16384u && n_blocks >= min_blocks;
 }
@@ -804,22 +804,22 @@ static hipError_t launch_rank_wg(hipStream_t s, uint32_t n_blocks, const RankArg
 static int rank_decode_family(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
     if (use_rank_wg(N, yp_stride, n_blocks)) return 1;
     static const uint32_t big_min = [] {
-        const char* e = getenv("XSI_BIG_RANK_MIN_N");
+        const char* e = tuning_env("XSI_BIG_RANK_MIN_N");
         return e ? (uint32_t)atoi(e) : 49152u;  // measured: 11.3 ms against 14.2 ms at 64 976 hap x 64 blocks, slower at 40 000
     }();
     const bool stage = N <= 65536u;
-    if ((!stage || N >= big_min) && yp_stride <= 1024u * 20u && yp_stride * 8u <= 160u * 1024u && !getenv("XSI_NO_BIG_RANK")) return 2;
+    if ((!stage || N >= big_min) && yp_stride <= 1024u * 20u && yp_stride * 8u <= 160u * 1024u && !tuning_env("XSI_NO_BIG_RANK")) return 2;
     return 0;
 }
 
 // Every element-major decode kernel can park its ranks, but the small-N kernels do not gain: at 5008 haplotypes x 123
 // blocks the twelve ranges cost the chain 0.6 ms for 0.6 ms of expansion hidden (8.76 against 8.67 ms per step).
 bool rank_decode_phased_ok(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
-    return rank_decode_family(N, yp_stride, n_blocks) != 0 || getenv("XSI_DEC_PHASES_SMALL") != nullptr;
+    return rank_decode_family(N, yp_stride, n_blocks) != 0 || tuning_env("XSI_DEC_PHASES_SMALL") != nullptr;
 }
 
 bool rank_decode_takes_compact(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
-    return N <= 65536u && rank_decode_family(N, yp_stride, n_blocks) == 1 && !getenv("XSI_NO_COMPACT_YP");
+    return N <= 65536u && rank_decode_family(N, yp_stride, n_blocks) == 1 && !tuning_env("XSI_NO_COMPACT_YP");
 }
 
 static void rank_args_rows(RankArgs& R, const DecLines& L) {
@@ -875,7 +875,7 @@ hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_
     R.out_stride_w = out_stride_w;
     R.N = L.N;
     RankGeom g = rank_geometry(L.N, L.yp_stride, n_blocks);
-    if (const char* e = getenv("XSI_DEC_B")) { uint32_t b = (uint32_t)atoi(e); if (b >= 1 && b < g.batch) g.batch = b; }
+    if (const char* e = tuning_env("XSI_DEC_B")) { uint32_t b = (uint32_t)atoi(e); if (b >= 1 && b < g.batch) g.batch = b; }
     R.batch = g.batch;
     R.log2_cwp = g.log2_cwp;
     const int fam = rank_decode_family(L.N, L.yp_stride, n_blocks);

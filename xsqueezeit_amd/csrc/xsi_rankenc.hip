@@ -253,13 +253,9 @@ hipError_t launch_rank_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_
     if (!e) return hipErrorInvalidValue;
     const uint32_t CW = 16u * (uint32_t)e * 64u / 32u;
     const uint32_t lds = 16384u + 4u * CW + 64u;
-    static const int rg = [] {
-        const char* e = getenv("XSI_RANKENC_G");
-        return (e && atoi(e) == 4) ? 4 : 8;
-    }();
 #define XSI_RE_CASE(EE)                                                                               \
     if (e == EE) {                                                                                    \
-        auto kern = rg == 4 ? &k_chain_rank_enc<EE, 4> : &k_chain_rank_enc<EE, 8>;                    \
+        auto kern = &k_chain_rank_enc<EE, 8>;  /* (groups of four gathers measured the same: not instantiated) */ \
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         if (err != hipSuccess) return err;                                                            \
@@ -900,7 +896,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
 }
 
 bool chain_rank_enc_multi_supported(const EncLines& L) {
-    const bool off = getenv("XSI_NO_RANKENC_MULTI") != nullptr;  // read per call (tests force the other kernel)
+    const bool off = tuning_env("XSI_NO_RANKENC_MULTI") != nullptr;  // read per call (tests force the other kernel)
     return !off && !L.no_multi && L.chain_sync && L.chain_lists && L.chain_slices && L.chain_bmps && L.N > 65536u && L.N <= 524288u &&
            (L.y_stride64 % 2u) == 0u;
 }
@@ -921,7 +917,7 @@ static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* b
     while (A.gpx > 1u && 8u * (A.gpx - 1u) >= n_blocks) --A.gpx;  // no more groups than blocks need
     if (8u * A.gpx * A.S > CHAIN_MAX_WGS) return hipErrorInvalidValue;
     static_assert(CHAIN_SLICEFLAG_WORDS >= (CHAIN_MAX_WGS / 2u) * 32u, "16 flags of 8 bytes per group");
-    const char* thr = getenv("XSI_MULTI_LIST_THR");
+    const char* thr = tuning_env("XSI_MULTI_LIST_THR");
     A.thr = thr ? (uint32_t)atoi(thr) : 49152u;
     A.sync = L.chain_sync;
     A.list_flags = L.chain_sync + CHAIN_SYNC_WORDS;
@@ -929,10 +925,10 @@ static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* b
     A.lists = L.chain_lists;
     A.bmps = L.chain_bmps;
     A.slices = reinterpret_cast<v4u*>(L.chain_slices);
-    A.test_desert = getenv("XSI_MULTI_TEST_DESERT") ? 1u : 0u;
-    A.prof = getenv("XSI_MULTI_PROF") ? (uint32_t)atoi(getenv("XSI_MULTI_PROF")) : 0u;
+    A.test_desert = test_hook_env("XSI_MULTI_TEST_DESERT") ? 1u : 0u;
+    A.prof = tuning_env("XSI_MULTI_PROF") ? (uint32_t)atoi(tuning_env("XSI_MULTI_PROF")) : 0u;
     A.xcc_ids = L.chain_sync + CHAIN_SYNC_WORDS + CHAIN_LISTFLAG_WORDS + CHAIN_SLICEFLAG_WORDS;
-    const char* tmo = getenv("XSI_MULTI_TIMEOUT_MS");
+    const char* tmo = tuning_env("XSI_MULTI_TIMEOUT_MS");
     A.timeout_ticks = 100000ull * (uint64_t)(tmo && atoi(tmo) > 0 ? atoi(tmo) : 2000);
     hipError_t e = hipMemsetAsync(L.chain_sync, 0, 4ull * CHAIN_SYNC_TOTAL_WORDS, s);
     if (e != hipSuccess) return e;
