@@ -63,6 +63,66 @@ LDS_CYCLES_PER_CHUNK_LINE = {"k_chain_rank_enc": 9.7, "k_chain_decode_rank_wg": 
                              "k_chain_decode_rank_big": 7.4, "k_chain_rank_enc_multi": 9.7}
 
 
+HBM_BYTES = 288 * 10**9  # MI355X, per GPU
+
+
+def job_shape(args, world, rank):
+    """What rank `rank` of `world` encodes and decodes: config 3 is ONE job whose blocks are sharded over the ranks
+    (dist.shard_blocks: contiguous block ranges, so the gathered streams concatenate in file order; strong scaling);
+    the other configs run one shape per rank on its own site range (weak scaling)."""
+    from xsqueezeit_amd import dist as xdist, synth
+    cfg = CONFIGS[args.config]
+    N = args.haps if args.haps is not None else cfg["haps"]
+    blen = args.block_len
+    one_job = cfg["scaling"] == "strong" and args.sites is None
+    if one_job:
+        total_sites = max(blen, int(cfg["sites"] * args.sites_fraction))
+        total_blocks = (total_sites + blen - 1) // blen
+        b_lo, b_hi = xdist.shard_blocks(total_blocks, world, rank)
+        first_site = b_lo * blen
+        S = max(0, min(b_hi * blen, total_sites) - first_site)
+        cells_job = float(N) * total_sites
+    else:
+        S = args.sites if args.sites is not None else cfg["sites"]
+        first_site = rank * S  # weak scaling: rank r owns sites [r*S, (r+1)*S)
+        total_sites = S * world
+        total_blocks = ((S + blen - 1) // blen) * world
+        cells_job = float(N) * S * world
+    return dict(N=N, S=S, first_site=first_site, total_sites=total_sites, total_blocks=total_blocks, cells_job=cells_job,
+                strong=one_job, block_len=blen, n_blocks=(S + blen - 1) // blen, stride=synth.row_stride_bytes(N))
+
+
+def out_capacity(N, S, bound):
+    """Bytes provided for a rank's blocks region: the worst-case bound (every line incompressible) is ~N/7.5 bytes per
+    line; the synthetic generator needs < 0.03 B per cell at 5008 haplotypes and 0.0076 at 500 000, so large jobs get 8 GiB
+    or 0.02 B per cell instead (the encoder reports XSI_ERR_CAPACITY instead of overrunning)."""
+    cap = bound if bound <= (8 << 30) else max(8 << 30, int(0.02 * float(N) * S))
+    return min(cap, bound)
+
+
+GATHER_BYTES_PER_CELL = 0.009  # planning figure for the writer rank's receive buffer (measured at configs[3]: 0.0076)
+
+
+def memory_plan(shape, world, rank, bound=None):
+    """HBM a rank holds beside the library's workspace: packed input, decoded output, the file image (blocks region at
+    its capacity + header + index) and, on the writer rank of a multi-rank job, the gathered block streams.  The
+    workspace (permuted rows / rank-select rows: the bulk) takes what is left - the library cuts a job into batches of
+    whole blocks that fit its budget - so the plan only has to leave room for ONE block's rows."""
+    N, S, stride, nb = shape["N"], shape["S"], shape["stride"], shape["n_blocks"]
+    if bound is None:
+        bound = int((N / 7.5 + 64.0) * S) + 4096 * nb  # (no library without a build: the same order as xsi_hip_encode_bound)
+    plan = {"input": S * stride, "decoded": S * stride, "file_image": 256 + out_capacity(N, S, bound) + 8 * nb + 64,
+            "gathered": int(GATHER_BYTES_PER_CELL * shape["cells_job"]) + 8 * (shape["total_blocks"] + world) if (world > 1 and rank == 0) else 0,
+            "row_counts": 4 * S}
+    held = sum(plan.values())
+    one_block_rows = 2 * shape["block_len"] * ((N + 63) // 64) * 8  # a block's permuted rows, and its rank-select rows at twice that
+    plan["held"] = held
+    plan["left_for_workspace"] = HBM_BYTES - held
+    plan["workspace_floor"] = 2 * one_block_rows + (1 << 30)
+    plan["fits"] = bool(plan["left_for_workspace"] >= plan["workspace_floor"])
+    return plan
+
+
 def launch_ranks(n):
     """python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <the same arguments>, one rank
     per GPU; returns its exit code."""
@@ -92,13 +152,21 @@ def dry_launch_rank(args, real_stdout):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    mine = torch.tensor([float(rank), float(os.getpid())], dtype=torch.float64)
-    got = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+    shape = job_shape(args, world, rank)
+    plan = memory_plan(shape, world, rank)
+    mine = torch.tensor([float(rank), float(os.getpid()), float(shape["n_blocks"]), float(shape["S"]), float(plan["held"]),
+                         1.0 if plan["fits"] else 0.0], dtype=torch.float64)
+    got = [torch.zeros(6, dtype=torch.float64) for _ in range(world)]
     tdist.all_gather(got, mine)
     tdist.barrier()
     if rank == 0:
         out = {"dry_launch": True, "n_gpus": world, "ranks_reported": [int(t[0]) for t in got],
-               "pids": [int(t[1]) for t in got]}
+               "pids": [int(t[1]) for t in got], "config": args.config,
+               "blocks_per_rank": [int(t[2]) for t in got], "sites_per_rank": [int(t[3]) for t in got],
+               "held_bytes_per_rank": [int(t[4]) for t in got], "fits_per_rank": [bool(t[5]) for t in got],
+               "hbm_bytes": HBM_BYTES, "memory_plan_rank0": plan,
+               "also_runs": ("--config 3 strong-scaled over the same ranks, attached as other_configs"
+                             if (world > 1 and args.config == 2 and not args.no_other_configs) else None)}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     tdist.destroy_process_group()
     return 0
@@ -453,11 +521,41 @@ def main():
         # The other single-GPU configurations of BASELINE.json in the same process, attached to the same line, so
         # that they are timed by whoever runs this command and not only by the builder (VERDICT r3 #1b).
         out["other_configs"] = run_other_configs(args, t_start)
+    if world > 1 and args.config == 2 and not custom and not args.no_other_configs:
+        # N > 1: the north_star job itself - BASELINE configs[3], 500 000 hap x 10 M sites, its 1221 blocks sharded over
+        # these same ranks (strong scaling), with gather_ms, the ranks' times and its own roofline - attached to the
+        # weak-scaling line, so that a driver that only runs the default command at N = 1, 2, 4, 8 records it
+        sub = north_star_args(args)
+        try:
+            o3, ok3 = run_roundtrip(sub, emit=False, dist_sub=True)
+        except (Exception, SystemExit) as e:  # (every rank raises or none: the failure modes are collective)
+            o3, ok3 = {"error": "%s: %s" % (type(e).__name__, e)}, False
+        if rank == 0:
+            o3["wall_s"] = time.perf_counter() - t_start
+            out["other_configs"] = {"configs[3] strong-scaled over %d GPUs (the north_star job)" % world: o3}
+    close_process_group()
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if rank == 0 and not ok:
         raise SystemExit("round trip mismatch")
+
+
+def north_star_args(args):
+    import copy
+    a = copy.copy(args)
+    a.config, a.haps, a.sites, a.seed, a.sites_fraction = 3, None, None, None, 1.0
+    a.steps, a.warmup, a.cpu_sample_cells = 2, 1, 4.2e9
+    return a
+
+
+def close_process_group():
+    try:
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized():
+            tdist.destroy_process_group()
+    except Exception:
+        pass
 
 
 def run_other_configs(args, t_start):
@@ -497,10 +595,11 @@ def run_other_configs(args, t_start):
     return res
 
 
-def run_roundtrip(args, emit=True):
+def run_roundtrip(args, emit=True, dist_sub=False):
     """One encode+decode configuration; returns (the JSON object of rank 0 or None, round trip equal).  emit=False:
-    a sub-run of the default command (one GPU, no process group, a smaller CPU-oracle sample: encode only, for the
-    byte comparison of the first blocks)."""
+    a sub-run of the default command (a smaller CPU-oracle sample: encode only, for the byte comparison of the first
+    blocks); dist_sub: a sub-run that every rank of a multi-rank job makes together (the process group of the main
+    line is reused)."""
     cfg = CONFIGS[args.config]
     custom = args.haps is not None or args.sites is not None
     N = args.haps if args.haps is not None else cfg["haps"]
@@ -516,7 +615,7 @@ def run_roundtrip(args, emit=True):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    distributed = (world > 1 or args.force_dist) and emit
+    distributed = (world > 1 or args.force_dist) and (emit or dist_sub)
     if distributed:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -525,7 +624,8 @@ def run_roundtrip(args, emit=True):
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if not tdist.is_initialized():  # (one group per process: main() closes it)
+            tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         tdist = None
         torch.cuda.set_device(local_rank)
@@ -538,21 +638,8 @@ def run_roundtrip(args, emit=True):
     ctx = binding.Context(local_rank, stream.cuda_stream)
 
     bl = args.block_len
-    strong = cfg["scaling"] == "strong" and args.sites is None
-    if strong:
-        # one job, its blocks sharded over the ranks (dist.shard_blocks: contiguous block ranges, so the
-        # gathered streams concatenate in file order)
-        total_sites = max(bl, int(cfg["sites"] * args.sites_fraction))
-        total_blocks = (total_sites + bl - 1) // bl
-        b_lo, b_hi = xdist.shard_blocks(total_blocks, world, rank)
-        first_site = b_lo * bl
-        S = min(b_hi * bl, total_sites) - first_site
-        cells_job = float(N) * total_sites
-    else:
-        S = args.sites if args.sites is not None else cfg["sites"]
-        first_site = rank * S  # weak scaling: rank r owns sites [r*S, (r+1)*S)
-        total_sites = S * world
-        cells_job = float(N) * S * world
+    shape = job_shape(args, world, rank)
+    strong, S, first_site, total_sites, cells_job = shape["strong"], shape["S"], shape["first_site"], shape["total_sites"], shape["cells_job"]
     n_samples = N // 2
     thr = int(float(N) * args.maf)
     stride = synth.row_stride_bytes(N)
@@ -575,11 +662,12 @@ def run_roundtrip(args, emit=True):
     count_in_step = not args.producer_counts
     cnt_ptr = None if count_in_step else d_cnt.data_ptr()
     bound = int(L.xsi_hip_encode_bound(ctypes.byref(p), S, S))
-    # the worst-case bound (every line incompressible) is ~N/7.5 bytes per line; this generator needs
-    # < 0.03 B per cell, so large jobs get 8 GiB or 0.04 B per cell instead of the bound (the encoder
-    # reports XSI_ERR_CAPACITY instead of overrunning)
-    cap = bound if bound <= (8 << 30) else max(8 << 30, int(0.04 * float(N) * S))
-    cap = min(cap, bound)
+    cap = out_capacity(N, S, bound)
+    plan = memory_plan(shape, world if distributed else 1, rank, bound)
+    if distributed and rank == 0 and world > 1 and plan["left_for_workspace"] < (140 << 30):
+        # the writer rank also receives every rank's block streams (allocated at the first exchange, behind the first
+        # encode): the library's workspace - by default half of what is free when it is sized - must leave that room
+        binding.check(L.xsi_hip_ctx_set_workspace_budget(ctx.handle, max(plan["workspace_floor"], int(0.9 * plan["left_for_workspace"]) - (4 << 30))))
     # the file image (header + blocks region + index) is assembled in place: the encoder writes the
     # blocks region straight behind the 256 header bytes
     d_file = torch.empty(256 + cap + 8 * n_blocks + 64, dtype=torch.uint8, device=dev)
@@ -738,13 +826,13 @@ def run_roundtrip(args, emit=True):
         # MI355X_MICROARCH.md); labelled with the commit they were taken at, null for other workloads
         traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and not custom and world == 1:
+        if os.path.exists(tpath) and not custom and (world == 1 or not strong):  # weak scaling: every rank runs the profiled shape
             try:
                 tj = json.load(open(tpath)).get("config%d" % args.config, {})
                 ent = tj.get("kernels", {}).get(kname)
                 if ent:
                     traffic = ent["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at %s" % tj.get("measured_at", "?")
+                    traffic_src = "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on one GPU at %s" % tj.get("measured_at", "?")
             except Exception:
                 traffic = None
         pipeline_gbs = (cells / 4.0 + 2.0 * xsi_bytes) / (dt / steps) / 1e9
@@ -767,6 +855,7 @@ def run_roundtrip(args, emit=True):
                                       "--producer-counts: handed over with the rows (xsi_hip_encode_packed_counted); the counting "
                                       "pass alone takes count_rows_ms and is NOT in ms_per_step"),
                        "count_rows_ms": count_rows_ms,
+                       "memory_plan_bytes": plan,
                        "parallelism": "blocks sharded over %d GPU(s); RCCL gather of block streams" % world
                        if distributed else "1 GPU"},
             "roofline": {"bound": "hbm", "kernel": "%s (PBWT chain, %s)" % (kname, "decode" if dom_decode else "encode"),
@@ -803,7 +892,7 @@ def run_roundtrip(args, emit=True):
                                else "torch.distributed point-to-point (the library's communicator failed: %s)" % gat_error}
 
     # ---- CPU baseline: the oracle (parity-pinned restatement of the reference), 1 thread ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:  # (N > 1: rank 0's host cores, while the other ranks wait at the group's next collective)
         from oracle import oracle
         full_leg = emit  # a sub-run only encodes its sample with the oracle, for the byte comparison
         cs = int(args.cpu_sample_cells / N)
@@ -886,11 +975,17 @@ def run_roundtrip(args, emit=True):
                                                           "(slowest thread's encode+decode time)" % par_blocks}
     elif rank == 0:
         out["cpu_baseline"] = None
+    if distributed:
+        tdist.barrier()  # (rank 0 comes out of its CPU leg)
     if gat is not None:
         gat.close()
     ctx.close()
     if distributed:
-        tdist.destroy_process_group()
+        ok_t = torch.tensor([1 if roundtrip_ok else 0], dtype=torch.int32, device=dev)
+        tdist.all_reduce(ok_t, op=tdist.ReduceOp.MIN)  # the verdict of the job: every rank's round trip
+        roundtrip_ok = bool(int(ok_t.item()))
+        if out is not None:
+            out["roundtrip_equal"] = roundtrip_ok
     return out, roundtrip_ok
 
 

@@ -276,6 +276,107 @@ def test_two_rank_gather_reproduces_single_process_file(tmp_path):
     assert got == ref
 
 
+def _fake_block(b):
+    """Stand-in for an encoded block: a length (multiple of 4, as interfaces.hpp:254-263 pads them) and bytes that
+    depend on the block's number only."""
+    n = 4 * (2 + (b * 7) % 9)
+    return bytes(((b * 131 + i * 17) & 0xFF) for i in range(n))
+
+
+def _fake_rank_main(rank, world, port, n_blocks, rounds, q):
+    import torch
+    import torch.distributed as tdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    region_all, offs_all, shards = bytearray(), [], []
+    for rd in range(rounds):  # a job gathered piece by piece: round rd covers a contiguous range of the file's blocks
+        r_lo, r_hi = rd * n_blocks // rounds, (rd + 1) * n_blocks // rounds
+        lo, hi = xdist.shard_blocks(r_hi - r_lo, world, rank)
+        shards.append(hi - lo)
+        parts = [_fake_block(r_lo + b) for b in range(lo, hi)]
+        offs = np.cumsum([0] + [len(x) for x in parts[:-1]], dtype=np.int64) if parts else np.zeros(0, dtype=np.int64)
+        region = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+        got = xdist.gather_block_streams(torch.from_numpy(region), torch.from_numpy(offs), tdist)
+        if rank == 0:
+            base = len(region_all)  # what the writer rank already holds (xsi_hip_gather_block_streams_round's region_base)
+            region_all += got[0].numpy().tobytes()
+            offs_all += [int(o) + base for o in got[1].numpy().tolist()]
+    every = [None] * world
+    tdist.all_gather_object(every, shards)
+    if rank == 0:
+        q.put((bytes(region_all), offs_all, every))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_blocks,rounds", [
+    (4, 1221, 1),   # BASELINE configs[3]: 1221 blocks of 8192 lines
+    (8, 1221, 1),   # ... over the 8 GPUs of a node: shards of 152 and 153 blocks
+    (8, 1221, 3),   # gathered in three rounds (a shard encoded and sent piece by piece)
+    (4, 3, 1),      # fewer blocks than ranks: a rank with nothing to send
+])
+def test_gather_at_world_4_and_8(world, n_blocks, rounds):
+    """The multi-rank path at the world sizes of the driver's scaling run (gloo on the CPU): block b goes to
+    rank floor(b G / B), every rank sends exactly its bytes and offsets, the writer rank's concatenation is the
+    single-process stream with ascending offsets."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fake_rank_main, args=(r, world, port, n_blocks, rounds, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    region, offs, shards = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    blocks = [_fake_block(b) for b in range(n_blocks)]
+    assert region == b"".join(blocks)
+    assert offs == np.cumsum([0] + [len(x) for x in blocks[:-1]]).tolist()
+    per_rank = [sum(sh) for sh in shards]
+    assert sum(per_rank) == n_blocks
+    if rounds == 1:
+        assert max(per_rank) - min(per_rank) <= 1
+        if n_blocks == 1221 and world == 8:
+            assert sorted(set(per_rank)) == [152, 153]
+        if n_blocks < world:
+            assert 0 in per_rank
+        # the C ABI's shard arithmetic is the same function
+        L = binding.lib()
+        for r in range(world):
+            lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+            L.xsi_hip_shard_blocks(n_blocks, world, r, ctypes.byref(lo), ctypes.byref(hi))
+            assert (lo.value, hi.value) == xdist.shard_blocks(n_blocks, world, r)
+            for b in (lo.value, hi.value - 1):
+                if lo.value < hi.value:
+                    assert L.xsi_hip_shard_of_block(n_blocks, world, b) == r
+
+
+def test_bench_dry_launch_plans_the_north_star_job():
+    """`bench.py --gpus 8 --config 3 --dry-launch`: the eight ranks of the north_star job (500 000 haplotypes x 10 M sites,
+    1221 blocks) report their shards and their HBM plans without a GPU: input + decoded output + file image + (on the
+    writer rank) the gathered streams leave room for the library's workspace on every rank of a 288 GB card."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "3", "--dry-launch"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_reported"] == list(range(8))
+    assert sum(out["blocks_per_rank"]) == 1221 and sorted(set(out["blocks_per_rank"])) == [152, 153]
+    assert sum(out["sites_per_rank"]) == 10_000_000
+    assert all(out["fits_per_rank"])
+    plan = out["memory_plan_rank0"]
+    assert plan["gathered"] > 0 and plan["held"] == max(out["held_bytes_per_rank"])  # the writer rank holds the most
+    assert plan["held"] + plan["workspace_floor"] <= out["hbm_bytes"]
+    assert plan["left_for_workspace"] >= 60 * 10**9  # the shard's 47 GB of permuted rows in ONE encode launch, as on a rank that gathers nothing
+
+
 def test_header_is_plain_c():
     """include/xsi_hip.h is the drop-in boundary: it must compile as C99 on its own (no C++ / HIP types)."""
     import shutil
