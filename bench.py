@@ -58,7 +58,7 @@ CONFIGS = {
 SIMDS, MODEL_CLOCK_HZ, CYCLES_PER_VALU = 256 * 4, 2.4e9, 2.8
 VALU_PER_CHUNK_LINE = {"k_chain_rank_enc": 9.8, "k_chain_decode_rank_wg": 12.9, "k_chain_lds": 27.0,
                        "k_chain_decode_rank": 14.0, "k_chain_decode_rank_big": 14.0, "k_chain_stream": 40.0,
-                       "k_chain_rank_enc_multi": 15.0}  # _multi: 9.8 of the main phase + the per-line exchange
+                       "k_chain_rank_enc_multi": 12.0}  # _multi: 8 for gathers + updates, ~4 for appends / deposits; the per-line exchange is not in the model
 LDS_CYCLES_PER_CHUNK_LINE = {"k_chain_rank_enc": 9.7, "k_chain_decode_rank_wg": 7.4, "k_chain_decode_rank": 7.4,
                              "k_chain_decode_rank_big": 7.4, "k_chain_rank_enc_multi": 9.7}
 
@@ -489,7 +489,7 @@ def main():
     ap.add_argument("--count-on-device", action="store_true", help="(the default since round 4; kept for old command lines)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default command only: do not run configs[1], the configs[3] shard and configs[4] after configs[2]")
-    ap.add_argument("--other-configs-budget-s", type=float, default=240.0,
+    ap.add_argument("--other-configs-budget-s", type=float, default=300.0,
                     help="wall-time budget after which the remaining other configs are skipped")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (process group + RCCL gather) even with one rank (testing)")
@@ -558,6 +558,135 @@ def close_process_group():
         pass
 
 
+def run_general_path(n_haps, sites, steps=2):
+    """The int32 entry points an HTSLIB caller lands on (xsi_hip_encode_gt / xsi_hip_decode_gt: htslib-encoded int32 rows
+    resident in HBM -> .xsi blocks -> int32 rows; gt_block.hpp:207-406, accessor_internals_new.hpp:198-384) at a BASELINE
+    shape, bi-allelic phased rows made from the bench generator's bit matrix on the device.  Algorithmic bytes per SURVEY 8d:
+    4 x cells in + xsi written, xsi read + 4 x cells out."""
+    import torch
+    from xsqueezeit_amd import binding, synth
+    L = binding.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream(dev)
+    ctx = binding.Context(dev.index, stream.cuda_stream)
+    N, S = n_haps, sites
+    n, bl = N // 2, 8192
+    thr = int(N * 0.001)
+    stride = synth.row_stride_bytes(N)
+    p = binding.EncodeParams(n, bl, thr, 1, 0, 0)
+    d_gt = torch.empty((S, N), dtype=torch.int32, device=dev)
+    shifts = torch.arange(8, device=dev, dtype=torch.uint8)
+    odd = (torch.arange(N, device=dev) & 1).to(torch.int32)
+    chunk = max(64, min(16384, int(2e9 / (4 * N))))
+    d_bits = torch.empty(chunk * stride, dtype=torch.uint8, device=dev)
+    for r0 in range(0, S, chunk):
+        m = min(chunk, S - r0)
+        binding.check(L.xsi_hip_synth_packed(ctx.handle, 42, r0, m, N, d_bits.data_ptr(), stride))
+        rows = d_bits[:m * stride].view(m, stride)
+        b = ((rows.unsqueeze(-1) >> shifts) & 1).reshape(m, -1)[:, :N].to(torch.int32)
+        d_gt[r0:r0 + m] = ((b + 1) << 1) | odd
+        del b, rows
+    del d_bits
+    ngt = np.full(S, N, dtype=np.uint32)
+    nal = np.full(S, 2, dtype=np.uint32)
+    bound = int(L.xsi_hip_encode_gt_bound(ctypes.byref(p), S, S))
+    cap = out_capacity(N, S, bound)
+    n_blocks = (S + bl - 1) // bl
+    d_file = torch.empty(cap + 256 + 8 * n_blocks + 64, dtype=torch.uint8, device=dev)
+    d_out = d_file[256:256 + cap]
+    d_off = torch.zeros(n_blocks, dtype=torch.int64, device=dev)
+    res = binding.EncodeResult()
+    d_dec = torch.empty((S, N), dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros((S, 2), dtype=torch.int64, device=dev)
+    ngt_out = np.zeros(S, dtype=np.uint32)
+    wall = {"encode_gt": 0.0, "decode_gt": 0.0}
+
+    def step():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        binding.check(L.xsi_hip_encode_gt(ctx.handle, ctypes.byref(p), d_gt.data_ptr(), N, S, ngt.ctypes.data,
+                                          nal.ctypes.data, d_out.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(res)))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nb = res.blocks_bytes
+        pad = (-(256 + nb)) % 8
+        io = 256 + nb + pad
+        so = io + 8 * n_blocks
+        hf = binding.HeaderFields(n, 2, bl, thr, 1, 0, S, S, io, so)
+        hdr = (ctypes.c_uint8 * 256)()
+        binding.check(L.xsi_hip_make_header(ctypes.byref(hf), hdr))
+        d_file[:256] = torch.frombuffer(bytearray(hdr), dtype=torch.uint8).to(dev, non_blocking=True)
+        d_file[256 + nb:io] = 0
+        d_file[io:so] = d_off.view(torch.uint8)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        binding.check(L.xsi_hip_decode_gt(ctx.handle, d_file.data_ptr(), so, 0, n_blocks, nal.ctypes.data, S,
+                                          d_dec.data_ptr(), N, ngt_out.ctypes.data, d_cnt.data_ptr(), 2))
+        torch.cuda.synchronize()
+        wall["encode_gt"] += t1 - t0
+        wall["decode_gt"] += time.perf_counter() - t2
+
+    step()
+    wall = {k: 0.0 for k in wall}
+    ctx.set_timing(True)
+    for _ in range(steps):
+        step()
+    stages = {k: round(v[0] / steps, 4) for k, v in ctx.timing().items() if v[1]}
+    ok = bool(torch.equal(d_dec, d_gt))
+    cells = float(N) * S
+    xsi = int(res.blocks_bytes)
+    t_enc, t_dec = wall["encode_gt"] / steps, wall["decode_gt"] / steps
+    alg = 8.0 * cells + 2.0 * xsi
+    gbs = alg / (t_enc + t_dec) / 1e9
+    ctx.close()
+    return {"metric": "GT cells/sec (hap x site) encode+decode round-trip through the int32 entry points", "value": cells / (t_enc + t_dec),
+            "unit": "GT cells/s", "ms_per_step": 1e3 * (t_enc + t_dec), "steps": steps, "dtype": "u16" if N <= 65535 else "u32",
+            "config": {"workload": "%d hap x %d bi-allelic sites, int32 genotype rows in HBM -> xsi_hip_encode_gt -> xsi_hip_decode_gt -> "
+                                   "int32 rows (the path an HTSLIB caller's rows take; the file image is assembled in place)" % (N, S),
+                       "haps": N, "sites": S, "xsi_bytes": xsi, "bytes_per_cell": xsi / cells},
+            "encode_ms": 1e3 * t_enc, "decode_ms": 1e3 * t_dec,
+            "encode_cells_per_s": cells / t_enc, "decode_cells_per_s": cells / t_dec,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "what": "SURVEY 8d: 4 x cells read + xsi written (encode), xsi read + 4 x cells written (decode), over the wall time of the two calls",
+                         "algorithmic_bytes_per_step": alg,
+                         "encode_frac": (4.0 * cells + xsi) / t_enc / 1e9 / HBM_PEAK_GBS, "decode_frac": (4.0 * cells + xsi) / t_dec / 1e9 / HBM_PEAK_GBS,
+                         "stage_ms_per_step": stages},
+            "rows_equal": ok}
+
+
+def run_file_boundary(n_samples, n_lines, zstd_level):
+    """The file-level boundary from a C program (tests/c/boundary_roundtrip.c: xsi_writer_append / xsi_accessor_get_genotypes,
+    host int32 rows in and out, no interpreter in the loop), PCIe-inclusive and never `value`; with zstd_level > 0 the
+    outer block layer of --zstd (interfaces.hpp:288-315) on write and read."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if not gcc:
+        return {"skipped": "no gcc on this box"}
+    exe = os.path.join(tempfile.gettempdir(), "xsi_boundary_roundtrip_%d" % os.getpid())
+    lib_dir = os.path.join(ROOT, "xsqueezeit_amd")
+    r = subprocess.run([gcc, "-std=c99", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "boundary_roundtrip.c"),
+                        "-o", exe, "-L", lib_dir, "-lxsi_hip", "-Wl,-rpath," + lib_dir], capture_output=True, text=True)
+    if r.returncode:
+        return {"error": "gcc: " + r.stderr[-500:]}
+    path = os.path.join(tempfile.gettempdir(), "xsi_bench_%d.xsi" % os.getpid())
+    try:
+        r = subprocess.run([exe, path, str(n_samples), str(n_lines), "8192", str(zstd_level)], capture_output=True, text=True, timeout=600)
+    finally:
+        for f in (exe, path):
+            if os.path.exists(f):
+                os.unlink(f)
+    line = (r.stdout.strip().splitlines() or [""])[-1]
+    if r.returncode or not line.startswith("ok"):
+        return {"error": (line + " " + r.stderr[-500:]).strip()}
+    kv = dict(x.split("=") for x in line.split()[1:])
+    return {"workload": "%d hap x %d lines through xsi_writer_append / xsi_accessor_get_genotypes[_batch] from C, host int32 rows, zstd level %d"
+                        % (2 * n_samples, n_lines, zstd_level),
+            "pcie_inclusive": True, "unit": "GT cells/s", "write": float(kv["write_cells_per_s"]), "read": float(kv["read_cells_per_s"]),
+            "batch_read": float(kv["batch_read_cells_per_s"]), "every_value_equal": kv["bad_lines"] == "0"}
+
+
 def run_other_configs(args, t_start):
     """configs[1], the configs[3] shard one of 8 GPUs gets, and configs[4] with 4 blocks, each with its own
     ms_per_step, roofline and parity flags; bounded by --other-configs-budget-s of wall time."""
@@ -569,6 +698,12 @@ def run_other_configs(args, t_start):
         ("configs[1]", dict(config=1, steps=5, warmup=2, cpu_sample_cells=0.6e9)),
         ("configs[3] shard (1 of 8 GPUs)", dict(config=3, sites_fraction=0.125, steps=2, warmup=1, cpu_sample_cells=4.2e9)),
         ("configs[4]", dict(config=4, blocks=4, queries=20000, windows=100, steps=1, warmup=1, cpu_queries=4)),
+        # what an HTSLIB caller actually lands on: the int32 entry points on the device, and the file-level boundary with
+        # and without the zstd layer (PCIe-inclusive), driver-timed since round 5
+        ("general path, configs[1] shape", dict(general=(5008, 1_000_000))),
+        ("general path, configs[2] haplotypes", dict(general=(64976, 262144))),
+        ("file boundary, 5008 hap", dict(boundary=(2504, 100000, 0))),
+        ("file boundary, 5008 hap, zstd 7", dict(boundary=(2504, 100000, 7))),
     ]
     for name, over in plan:
         gc.collect()
@@ -584,7 +719,11 @@ def run_other_configs(args, t_start):
             setattr(a, k, v)
         t = time.perf_counter()
         try:
-            if a.config == 4:
+            if "general" in over:
+                o = run_general_path(*over["general"])
+            elif "boundary" in over:
+                o = run_file_boundary(*over["boundary"])
+            elif a.config == 4:
                 o = run_config4(a, None, emit=False)
             else:
                 o, _ = run_roundtrip(a, emit=False)
@@ -804,9 +943,23 @@ def run_roundtrip(args, emit=True, dist_sub=False):
         launches_per_step = max(enc_n, 1) / steps  # > 1 when the job ran as several batches of blocks
         dom_decode = dec_ms > enc_ms
         kname = L.xsi_hip_chain_kernel(N, int(n_blocks / max(launches_per_step, 1)), 1 if dom_decode else 0).decode()
-        alg_bytes = (cells / 8.0 + xsi_bytes) / launches_per_step
         kern_ms = dec_ms if dom_decode else enc_ms
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        # The dominant kernel against ITS OWN compulsory bytes: the encode chain reads the input rows of the
+        # WAH lines and writes as many permuted rows; the decode chain reads a rank-select row per WAH line (10 bytes per 64
+        # positions in the one-workgroup kernel's compact form, 16 otherwise) and writes the line's packed row.  The
+        # headline `frac` is the whole round trip's: (cells/4 + 2 xsi_bytes) / step time, SURVEY 8d - every kernel's time in it.
+        row_b = ((N + 63) // 64) * 8.0
+        wah_l = float(res.n_wah_lines) / launches_per_step
+        if dom_decode:
+            kern_bytes = wah_l * (row_b * (1.25 if kname == "k_chain_decode_rank_wg" else 2.0) + row_b)
+            kern_bytes_what = "rank-select row read + packed row written per WAH line"
+        else:
+            kern_bytes = wah_l * 2.0 * row_b
+            kern_bytes_what = "input row read + permuted row written per WAH line"
+        kern_gbs = kern_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        # (what rounds 1-4 printed as `achieved`: the whole ENCODE's algorithmic bytes over the chain kernel's time alone)
+        alg_bytes = (cells / 8.0 + xsi_bytes) / launches_per_step
+        achieved_r4 = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in timing.items() if v[1]}  # per launch
         # per step: a job that runs as several batches of blocks launches a stage several times a step
         stages_step = {k: round(v[0] / steps, 4) for k, v in timing.items() if v[1]}
@@ -824,17 +977,25 @@ def run_roundtrip(args, emit=True, dist_sub=False):
         # HBM bytes of that kernel from the PMC passes kept under profiles/ (separate --pmc FETCH_SIZE /
         # WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 note in
         # MI355X_MICROARCH.md); labelled with the commit they were taken at, null for other workloads
-        traffic = traffic_src = None
+        traffic = traffic_src = kernel_traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and not custom and (world == 1 or not strong):  # weak scaling: every rank runs the profiled shape
             try:
                 tj = json.load(open(tpath)).get("config%d" % args.config, {})
-                ent = tj.get("kernels", {}).get(kname)
+                ks = tj.get("kernels", {})
+                ent = ks.get(kname)
                 if ent:
-                    traffic = ent["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on one GPU at %s" % tj.get("measured_at", "?")
+                    kernel_traffic = ent["hbm_bytes_per_launch"]
+                    # per STEP, like `achieved`: every kernel's bytes per launch x its launches per step of the profiled run
+                    steps_prof = float(tj.get("steps_profiled") or ks.get("k_classify", {}).get("launches_in_the_profiled_run") or 1)
+                    # (outside the steps the command launches the generator and two counting passes: not a step's traffic)
+                    setup = {"k_synth_packed": None, "k_count_rows_wide": 2, "k_count_rows": 2, "k_count_rows_v4": 2}
+                    traffic = sum(v["hbm_bytes_per_launch"] * (v["launches_in_the_profiled_run"] - (setup.get(k) or 0))
+                                  for k, v in ks.items() if not (k in setup and setup[k] is None)) / steps_prof
+                    traffic_src = ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on one GPU at %s; "
+                                   "all kernels of a step" % tj.get("measured_at", "?"))
             except Exception:
-                traffic = None
+                traffic = kernel_traffic = None
         pipeline_gbs = (cells / 4.0 + 2.0 * xsi_bytes) / (dt / steps) / 1e9
         out = {
             "metric": "GT cells/sec (hap x site) encode+decode round-trip",
@@ -858,10 +1019,14 @@ def run_roundtrip(args, emit=True, dist_sub=False):
                        "memory_plan_bytes": plan,
                        "parallelism": "blocks sharded over %d GPU(s); RCCL gather of block streams" % world
                        if distributed else "1 GPU"},
-            "roofline": {"bound": "hbm", "kernel": "%s (PBWT chain, %s)" % (kname, "decode" if dom_decode else "encode"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
+            "roofline": {"bound": "hbm", "achieved": pipeline_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pipeline_gbs / HBM_PEAK_GBS,
+                         "what": "whole encode + decode round trip: (cells/4 + 2 x xsi_bytes) algorithmic bytes of this GPU / ms_per_step",
+                         "algorithmic_bytes_per_step": cells / 4.0 + 2.0 * xsi_bytes,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_traffic": kernel_traffic,
+                         "kernel": "%s (PBWT chain, %s)" % (kname, "decode" if dom_decode else "encode"),
+                         "kernel_ms": kern_ms, "kernel_bytes_per_launch": kern_bytes, "kernel_bytes_are": kern_bytes_what,
+                         "kernel_achieved": kern_gbs, "kernel_frac": kern_gbs / HBM_PEAK_GBS,
+                         "kernel_achieved_by_round4_accounting": achieved_r4,
                          "issue_model": {"what": "floor of this launch: max(vector issue: chunk-lines x VALU per 64-haplotype chunk "
                                                  "per line x 2.8 cycles / (1024 SIMDs x 2.4 GHz), LDS pipe: chunk-lines x LDS array "
                                                  "cycles per chunk-line (random ds_read_b64 gather 7.1 + deposits) / (busy CUs x 2.4 GHz))",
@@ -870,7 +1035,7 @@ def run_roundtrip(args, emit=True, dist_sub=False):
                                          "bound": ("lds" if (lds_ms or 0) >= (valu_ms or 0) else "valu") if model_ms else None,
                                          "achieved_over_model": (model_ms / kern_ms) if model_ms and kern_ms else None},
                          "chain_encode_ms": enc_ms, "chain_decode_ms": dec_ms,
-                         "pipeline_achieved_GBps": pipeline_gbs, "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
+                         "pipeline_achieved_GBps": pipeline_gbs, "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,  # (= achieved / frac; kept for readers of rounds 1-4)
                          "stage_ms": stages, "stage_ms_per_step": stages_step, "chain_launches_per_step": launches},
             "roundtrip_equal": roundtrip_ok,
         }

@@ -5,7 +5,7 @@
  * Accessor::get_genotypes, include/accessor.hpp:58-67) and checks every value.  Also the honest way to
  * time the per-line boundary: no interpreter between the caller and the library.
  *
- *   usage: boundary_roundtrip <out.xsi> [n_samples] [n_lines] [block_len]
+ *   usage: boundary_roundtrip <out.xsi> [n_samples] [n_lines] [block_len] [zstd_level]
  * Prints one line: "ok lines=.. haps=.. write_cells_per_s=.. read_cells_per_s=.." ; exit code 0 on success.
  */
 #define _POSIX_C_SOURCE 199309L /* clock_gettime */
@@ -50,7 +50,7 @@ static double now_s(void) {
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s out.xsi [n_samples] [n_lines] [block_len]\n", argv[0]);
+        fprintf(stderr, "usage: %s out.xsi [n_samples] [n_lines] [block_len] [zstd_level]\n", argv[0]);
         return 2;
     }
     const uint32_t n_samples = argc > 2 ? (uint32_t)atoi(argv[2]) : 2504;
@@ -66,6 +66,7 @@ int main(int argc, char** argv) {
     p.n_samples = n_samples;
     p.block_len = block_len;
     p.mac_threshold = xsi_mac_threshold(n_samples, 2, 0.001);
+    p.zstd_level = argc > 5 ? (uint32_t)atoi(argv[5]) : 0; /* --zstd --zl <level>: the outer block layer (interfaces.hpp:288-315) */
     /* rows are generated up front so that the timed loops contain the boundary calls only */
     int32_t* rows = (int32_t*)malloc((size_t)n_lines * n_haps * sizeof(int32_t));
     if (!rows) return 4;
