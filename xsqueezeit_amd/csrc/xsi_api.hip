@@ -330,6 +330,8 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
         WS(L.chain_lists, "enc.chain_lists", 4ull * CHAIN_LIST_WORDS);
         WS(L.chain_slices, "enc.chain_slices", CHAIN_SLICE_BYTES);
         WS(L.chain_bmps, "enc.chain_bmps", CHAIN_BMP_BYTES);
+        WS(L.chain_items, "enc.chain_items", 4ull * 64u + 16ull * ((size_t)n_blocks + CHAIN_MAX_WGS / 4u + 2u));
+        WS(L.chain_park, "enc.chain_park", CHAIN_PARK_BYTES);
     }
     // WAH16 words per line, worst case ceil(N/15) (+1 for the saturation split): encode once, then copy
     L.wah_scratch_stride = ((N + 14u) / 15u + 3u) & ~1u;  // even: rows stay 4-byte aligned for k_wah_write

@@ -43,6 +43,8 @@ struct EncLines {
     uint32_t* chain_lists;
     void* chain_slices;
     uint32_t* chain_bmps;       // the members' private bitmaps of a row (bitmap exchange), CHAIN_BMP_BYTES
+    uint32_t* chain_items;      // the launch's schedule: 64 words of per-group begins, then 16-byte items (k_multi_schedule)
+    uint32_t* chain_park;       // ranks handed from a block's head part to its tail part, CHAIN_PARK_BYTES
     uint32_t no_multi;
     uint16_t* wah_scratch;      // [rank][wah_scratch_stride] WAH16 words of each line (encoded once, copied to place)
     uint32_t wah_scratch_stride;
@@ -199,6 +201,7 @@ constexpr uint32_t CHAIN_SLICEFLAG_WORDS = CHAIN_MAX_WGS * 2u * 16u * 2u;  // 8 
 constexpr uint32_t CHAIN_XCC_WORDS = (CHAIN_MAX_WGS / 2u) * 8u;
 constexpr uint32_t CHAIN_SYNC_TOTAL_WORDS = CHAIN_SYNC_WORDS + CHAIN_LISTFLAG_WORDS + CHAIN_SLICEFLAG_WORDS + CHAIN_XCC_WORDS;
 constexpr uint64_t CHAIN_SLICE_BYTES = (uint64_t)CHAIN_MAX_WGS * 2u * 16384u;
+constexpr uint64_t CHAIN_PARK_BYTES = (uint64_t)CHAIN_MAX_WGS * 64u * 1024u * 4u;  // per workgroup 64 x 1024 ranks
 constexpr uint64_t CHAIN_BMP_BYTES = (uint64_t)CHAIN_MAX_WGS * 8u * 8192u;  // per workgroup a bitmap of up to 8 slices
 bool chain_rank_enc_multi_supported(const EncLines& L);
 hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L);

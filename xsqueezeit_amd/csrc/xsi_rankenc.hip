@@ -328,6 +328,11 @@ hipError_t launch_rank_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_
 // the per-line choice 265.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t MULTI_LIST_CAP = 4096u;  // ranks per wave and line: every one of its 64 x 64 haplotypes
+struct MultiItem {
+    uint32_t block, first, count;  // WAH lines [first, first + count) of the block (counted among its WAH lines)
+    uint32_t flags;                // MULTI_ITEM_LOAD: the ranks in front of `first` are parked in slot flags >> 8; _STORE: park mine there
+};
+constexpr uint32_t MULTI_ITEM_LOAD = 1u, MULTI_ITEM_STORE = 2u;
 
 struct RankEncMultiArgs {
     const uint32_t* wah_lines;
@@ -353,7 +358,95 @@ struct RankEncMultiArgs {
     uint64_t timeout_ticks;
     uint64_t* prof_buf;
     uint32_t prof_cap;
+    // the launch's work, cut into per-group item lists by k_multi_schedule (below)
+    const uint32_t* item_begin;  // [n_groups + 1]
+    const MultiItem* items;
+    uint32_t* park;              // [slot][member][64][1024]: the ranks a block's head part hands to its tail part
+    uint32_t* park_flags;        // [slot][8]: 1 = that member's ranks are parked
 };
+
+// ---- the schedule.  A launch has B blocks for G groups; block b is a serial chain of n_wah(b) lines.  Walked block by
+// block (b += G), the groups that get one block fewer idle for a whole block at the end: 153 blocks on 32 groups take five
+// rounds for 4.78 rounds of work.  Here every group gets the same number of LINES (McNaughton's wrap-around rule): the
+// blocks are laid end to end and cut every T = total / G lines; a block that straddles a cut is run in two parts by two
+// groups - its HEAD lines open the timeline of group g + 1, its TAIL lines close the timeline of group g (so the head is
+// long finished when the tail begins: n_wah(b) <= T), and the ranks travel through memory in between (`park`: 4 N bytes,
+// once per cut, device-scope release / acquire: the two groups sit on different XCDs as a rule).
+__global__ void k_multi_schedule(const EncBlock* __restrict__ eblocks, uint32_t n_blocks, uint32_t n_groups, uint32_t* item_begin,
+                                 MultiItem* items, uint32_t round_robin) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (round_robin) {  // (A/B runs: whole blocks dealt out b, b + G, b + 2 G, ... as rounds 2 - 4 did)
+        uint32_t n = 0;
+        for (uint32_t g = 0; g < n_groups; ++g) {
+            item_begin[g] = n;
+            for (uint32_t b = g; b < n_blocks; b += n_groups)
+                if (!eblocks[b].has_haploid && eblocks[b].n_wah) items[n++] = MultiItem{b, 0u, eblocks[b].n_wah, 0u};
+        }
+        item_begin[n_groups] = n;
+        return;
+    }
+    constexpr uint32_t MIN_PART = 96u;  // no part shorter than this (its fixed costs: a park, a wait, a first row)
+    uint64_t total = 0;
+    uint32_t live = 0, longest = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b)
+        if (!eblocks[b].has_haploid && eblocks[b].n_wah) {
+            total += eblocks[b].n_wah;
+            longest = eblocks[b].n_wah > longest ? eblocks[b].n_wah : longest;
+            ++live;
+        }
+    uint64_t T = (total + n_groups - 1u) / n_groups;
+    const bool whole_only = live <= n_groups || T < longest;  // (fewer blocks than groups: nothing to balance, and a chain longer than T cannot wrap)
+    uint32_t g = 0, n = 0;
+    uint64_t load = 0;
+    item_begin[0] = 0;
+    // a head part is written at the front of the NEXT group's list: kept aside until that list is opened
+    MultiItem pending{};
+    bool have_pending = false;
+    auto open_next = [&]() {
+        item_begin[++g] = n;
+        load = 0;
+        if (have_pending) {
+            items[n++] = pending;
+            load = pending.count;
+            have_pending = false;
+        }
+    };
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const uint32_t wl = (eblocks[b].has_haploid || !eblocks[b].n_wah) ? 0u : eblocks[b].n_wah;
+        if (!wl) continue;
+        if (whole_only) {
+            if (load && load + wl > T && g + 1u < n_groups) open_next();
+            items[n++] = MultiItem{b, 0u, wl, 0u};
+            load += wl;
+            continue;
+        }
+        for (;;) {
+            const uint64_t room = T > load ? T - load : 0u;
+            if (wl <= room || g + 1u >= n_groups) {  // fits (the last group takes what is left)
+                items[n++] = MultiItem{b, 0u, wl, 0u};
+                load += wl;
+                break;
+            }
+            if (room < MIN_PART) {  // this group is full
+                open_next();
+                continue;
+            }
+            if (wl - room < MIN_PART) {  // a sliver would be left: the whole block here
+                items[n++] = MultiItem{b, 0u, wl, 0u};
+                load += wl;
+                break;
+            }
+            // tail lines [wl - room, wl) close this group's list, head lines [0, wl - room) open the next one's
+            const uint32_t cut = wl - (uint32_t)room;
+            items[n++] = MultiItem{b, cut, (uint32_t)room, MULTI_ITEM_LOAD | (g << 8)};
+            pending = MultiItem{b, 0u, cut, MULTI_ITEM_STORE | (g << 8)};
+            have_pending = true;
+            open_next();
+            break;
+        }
+    }
+    while (g < n_groups) open_next();
+}
 
 template <bool PROF>
 __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* __restrict__ eblocks, RankEncMultiArgs A) {
@@ -371,7 +464,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
-    const uint32_t group = xcd * A.gpx + q / S, member = q % S, n_groups = 8u * A.gpx;
+    const uint32_t group = xcd * A.gpx + q / S, member = q % S;
     const uint32_t n_lists = S * W;
     if (A.test_desert && member == 1u) return;
     const uint32_t bmp_units = S * (SL_WORDS / 4u);  // 16-byte units of a bitmap
@@ -706,20 +799,46 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
     uint32_t seq = 0;
     const uint32_t c0 = member * 1024u + w * (uint32_t)E;  // my first chunk of the row
     const uint32_t full_chunks = N >> 6, rem_bits = N & 63u;
-    for (uint32_t blk = group; blk < A.n_blocks; blk += n_groups) {
+    const uint32_t it_end = as_const(A.item_begin)[group + 1u];
+    for (uint32_t it = as_const(A.item_begin)[group]; it < it_end; ++it) {
+        // (blocks with fully haploid lines are not in the lists: the position-major kernels take them)
+        const ConstU32* item = as_const(reinterpret_cast<const uint32_t*>(A.items + it));
+        const uint32_t blk = item[0], part_first = item[1], n_wah = item[2], iflags = item[3];
         const EncBlock& B = eblocks[blk];
-        if (B.has_haploid) continue;  // the position-major kernels take the blocks with fully haploid lines
-        const uint32_t wah_first = B.wah_first, n_wah = B.n_wah;
-        if (n_wah == 0) continue;
+        const uint32_t wah_first = B.wah_first + part_first;
         const ConstU32* lines = as_const(A.wah_lines) + wah_first;
         uint32_t lane_here = lane;
-        asm volatile("" : "+v"(lane_here));  // the identity ranks are formed in this block's code, not kept across the blocks
+        asm volatile("" : "+v"(lane_here));  // formed in this item's code, not kept across the items
+        // (pointers and thread offsets of the parking are formed where they are used: kept across the line loop they cost it registers)
+        auto park_of = [&](uint32_t fl) -> uint32_t* {
+            uint32_t t = threadIdx.x;
+            asm volatile("" : "+v"(t));
+            return A.park + ((size_t)(fl >> 8) * S + member) * ((size_t)E * T) + t;
+        };
+        auto park_flag_of = [&](uint32_t fl) -> uint32_t* { return A.park_flags + (fl >> 8) * 8u + member; };
         uint32_t r[E];
-        static_for<0, E>([&](auto ec) {
-            constexpr int e = decltype(ec)::value;
-            const uint32_t h = (c0 + (uint32_t)e) * 64u + lane_here;
-            r[e] = h < N ? h : 0u;
-        });
+        if (iflags & MULTI_ITEM_LOAD) {
+            uint32_t* const park_flag = park_flag_of(iflags);
+            // the ranks behind the block's head lines, parked by the same member of another group (another XCD as a rule)
+            uint32_t spins = 0;
+            t_start = 0;
+            while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(park_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+                if (give_up(spins)) return;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const uint32_t* const park = park_of(iflags);
+            static_for<0, E>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                r[e] = __builtin_nontemporal_load(park + (size_t)e * T);
+            });
+        } else {
+            static_for<0, E>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                const uint32_t h = (c0 + (uint32_t)e) * 64u + lane_here;
+                r[e] = h < N ? h : 0u;
+            });
+        }
         // ---- lists: ranks on their way to my wave's list pass through a LINEAR 128-entry buffer in LDS, so that they
         // leave as whole 256-byte stores (a store of one to three lanes per chunk is one fabric write per lane): the ranks
         // not yet stored sit at its front (fewer than 64), a chunk's new ones go behind them at `wpos` - a scalar LDS byte
@@ -888,7 +1007,18 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                 }
             }
         }
-        // (the next block's first row: a list pass touches neither table nor bitmap, clear_bitmap starts with a barrier)
+        const uint32_t iflags_end = as_const(reinterpret_cast<const uint32_t*>(A.items + it))[3];  // (read again: not kept across the lines)
+        if (iflags_end & MULTI_ITEM_STORE) {  // the block goes on in another group's list
+            uint32_t* const park = park_of(iflags_end);
+            static_for<0, E>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                park[(size_t)e * T] = r[e];
+            });
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (with the wait for my stores: visible beyond this XCD's L2)
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(park_flag_of(iflags_end), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (the next item's first row: a list pass touches neither table nor bitmap, clear_bitmap starts with a barrier)
     }
     if constexpr (PROF) {
         if (profiling && lane == 0) A.sync[2] = pidx;
@@ -897,7 +1027,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
 
 bool chain_rank_enc_multi_supported(const EncLines& L) {
     const bool off = tuning_env("XSI_NO_RANKENC_MULTI") != nullptr;  // read per call (tests force the other kernel)
-    return !off && !L.no_multi && L.chain_sync && L.chain_lists && L.chain_slices && L.chain_bmps && L.N > 65536u && L.N <= 524288u &&
+    return !off && !L.no_multi && L.chain_sync && L.chain_lists && L.chain_slices && L.chain_bmps && L.chain_items && L.chain_park && L.N > 65536u && L.N <= 524288u &&
            (L.y_stride64 % 2u) == 0u;
 }
 
@@ -931,6 +1061,17 @@ static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* b
     const char* tmo = tuning_env("XSI_MULTI_TIMEOUT_MS");
     A.timeout_ticks = 100000ull * (uint64_t)(tmo && atoi(tmo) > 0 ? atoi(tmo) : 2000);
     hipError_t e = hipMemsetAsync(L.chain_sync, 0, 4ull * CHAIN_SYNC_TOTAL_WORDS, s);
+    if (e != hipSuccess) return e;
+    const uint32_t n_groups = 8u * A.gpx;
+    static_assert(CHAIN_SYNC_WORDS >= 16u + (CHAIN_MAX_WGS / 8u) * 8u, "a parking flag per group and member");
+    A.item_begin = L.chain_items;
+    A.items = reinterpret_cast<const MultiItem*>(L.chain_items + 64u);  // (16-byte aligned: at most 33 begins in front)
+    A.park = L.chain_park;
+    A.park_flags = L.chain_sync + 16u;
+    if (n_groups + 1u > 64u || !L.chain_items || !L.chain_park) return hipErrorInvalidValue;
+    k_multi_schedule<<<dim3(1), dim3(64), 0, s>>>(blocks, n_blocks, n_groups, L.chain_items, reinterpret_cast<MultiItem*>(L.chain_items + 64u),
+                                                  tuning_env("XSI_MULTI_ROUND_ROBIN") ? 1u : 0u);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     static uint64_t* prof_buf = nullptr;  // (profiling runs only; never freed)
     constexpr uint32_t PROF_CAP = 1u << 20;
