@@ -694,6 +694,11 @@ int xsi_hip_decode_packed(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_le
                     if (nb % quantum == 0) best = nb;
                 }
                 if (b0 + nb == n_blocks64 || best == 0) best = nb ? nb : 1;  // the tail, or fewer blocks fit than a round holds
+                // a remainder of less than one round would run at a fraction of the chip (128 + 25 of 153 blocks: the 25 on
+                // 200 of 256 CUs, or on smaller workgroups that stage the row twice as often): a round less here, a round
+                // more there (96 + 57)
+                const uint64_t rest = n_blocks64 - (b0 + best);
+                if (rest && rest < quantum && best % quantum == 0 && best >= 2u * quantum) best -= quantum;
                 b0 += best;
                 cuts.push_back(b0);
             }
@@ -946,7 +951,10 @@ static int run_wah_phases(xsi_hip_ctx* ctx, const uint8_t* f, DecodePlan& P, uin
         for (uint32_t p = 0; p <= K; ++p) cuts.push_back(p);
     }
     K = (uint32_t)cuts.size() - 1u;
-    // per phase and block: first WAH line (batch-wide rank), lines, and the running number of 4-line groups
+    // per phase and block: first WAH line (batch-wide rank), lines, and the running number of 4-line groups.
+    // (Launch p takes range p of EVERY block.  Round 5 tried launches that take whole rounds' worth of blocks only - a
+    // rotating window over a 57-block batch on 32 slots, 43 full launches instead of 24 of 1.78 rounds: 162 against 157 ms
+    // for the decode of the configs[3] shard.  The partly filled round is where the expansion of the next range runs.)
     P.phase_tab.assign((size_t)K * (3u * nb + 1u), 0u);
     for (uint32_t p = 0; p < K; ++p) {
         uint32_t* start = P.phase_tab.data() + (size_t)p * (3u * nb + 1u);

@@ -172,7 +172,7 @@ bool rank_decode_takes_compact(uint32_t N, uint32_t yp_stride, uint32_t n_blocks
 uint64_t rank_decode_state_words(uint32_t N, uint32_t n_blocks);
 hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                                     uint32_t* out_rows, uint32_t out_stride_w, const uint32_t* ph_start,
-                                    const uint32_t* ph_cnt, uint32_t* state);
+                                    const uint32_t* ph_cnt, uint32_t* state, uint32_t active_blocks = 0);
 uint32_t rank_decode_big_wgs_per_block(uint32_t N, uint32_t yp_stride);
 // element-major decode chain (xsi_rank.hip): all blocks without fully haploid lines
 hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,

@@ -692,7 +692,10 @@ static hipError_t launch_rank(hipStream_t s, const RankGeom& g, uint32_t n_block
 
 // Long-row decode: RP by the row length, E by how many workgroups it takes to fill the chip
 // (and by what still fits 128 VGPRs next to the RP prefetch registers).
-static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) {
+// `active`: blocks that have lines in this launch (a batch's launches all pass the same figure - the parked ranks' layout
+// depends on the geometry chosen from it)
+static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A, uint32_t active = 0) {
+    if (!active || active > n_blocks) active = n_blocks;
     const uint32_t nch = (A.N + 63u) / 64u;
     const uint32_t lds = ((A.yp_stride / 2u + 1023u) / 1024u) * 16384u;  // whole 1024-unit pieces (see the kernel's store_row)
     auto splits_of = [&](uint32_t e) { return (nch + 16u * e - 1u) / (16u * e); };
@@ -704,12 +707,20 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A) 
     // every workgroup of a block stages the whole rank-select row of each line: the fewer workgroups per block
     // (the more chunks per wave) the less of that, as long as the launch still fills the chip
     const uint32_t e_max = RP == 20u ? 16u : 64u;  // <64, 16> fits since the row travels as 16-byte pieces (it spilled 60 VGPRs)
+    // rounds of the chip the launch takes x what a round costs: a workgroup with half the chunks per wave does a little more
+    // than half the work (it stages the same row: 0.59 of the time at 500 000 haplotypes, profiles/r05_config3_kernel_stats.csv)
+    // - 25 blocks: one round of <64> at 25 / 32 of the chip (1.0) beats two of <32> (1.18); 12 blocks: <32> in one round
     uint32_t E = 8;
-    for (uint32_t e : {64u, 32u, 16u})
-        if (e <= e_max && (uint64_t)n_blocks * splits_of(e) >= 224u) {
+    double best_cost = 1e30;
+    for (uint32_t e : {64u, 32u, 16u, 8u}) {
+        if (e > e_max) continue;
+        const double rounds = (double)(((uint64_t)active * splits_of(e) + 255u) / 256u);
+        const double cost = rounds * (e == 64u ? 1.0 : e == 32u ? 0.59 : e == 16u ? 0.36 : 0.23);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
             E = e;
-            break;
         }
+    }
     if ((env_e == 8 || env_e == 16 || env_e == 32 || env_e == 64) && (uint32_t)env_e <= e_max) E = (uint32_t)env_e;
 #define XSI_BIG_CASE(EE, RR)                                                                                 \
     if (E == EE && RP == RR) {                                                                               \
@@ -841,7 +852,7 @@ uint64_t rank_decode_state_words(uint32_t N, uint32_t n_blocks) {  // ranks of e
 
 hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                                     uint32_t* out_rows, uint32_t out_stride_w, const uint32_t* ph_start,
-                                    const uint32_t* ph_cnt, uint32_t* state) {
+                                    const uint32_t* ph_cnt, uint32_t* state, uint32_t active_blocks) {
     if (!n_blocks) return hipSuccess;
     RankArgs R{};
     R.blocks = blocks;
@@ -856,7 +867,7 @@ hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint3
     R.state = state;
     const int fam = rank_decode_family(L.N, L.yp_stride, n_blocks);
     if (fam == 1) return launch_rank_wg(s, n_blocks, R);
-    if (fam == 2) return launch_rank_big(s, n_blocks, R);
+    if (fam == 2) return launch_rank_big(s, n_blocks, R, active_blocks);
     const RankGeom g = rank_geometry(L.N, L.yp_stride, n_blocks);
     R.batch = g.batch;
     R.log2_cwp = g.log2_cwp;
