@@ -68,6 +68,39 @@ def main():
     stats = p("%s_stats" % tag, "p_kernel_stats.csv")
     if os.path.exists(stats):
         shutil.copy(stats, os.path.join(dst, "%s_kernel_stats.csv" % tag))
+    c3 = p("%s_c3stats" % tag, "p_kernel_stats.csv")
+    if os.path.exists(c3):
+        shutil.copy(c3, os.path.join(dst, "%s_config3_kernel_stats.csv" % tag))
+    clocks = p("%s_config3_phase_clocks.txt" % tag)
+    if os.path.exists(clocks) and os.path.getsize(clocks):
+        with open(os.path.join(dst, "%s_config3_phase_clocks.txt" % tag), "w") as out:
+            out.write("XSI_MULTI_PROF=983041 (wave 15 of workgroup 0) of k_chain_rank_enc_multi over the configs[3] shard, %s:\n"
+                      "time between consecutive phase records of that wave, summed per phase (the records cost the chain ~10 %%).\n\n" % when)
+            out.write(open(clocks).read())
+    sq3 = {}
+    for part in ("c3sq1", "c3sq2"):
+        f = p("%s_%s" % (tag, part), "p_counter_collection.csv")
+        if os.path.exists(f):
+            sq3.update(per_kernel(f))
+    if sq3:
+        with open(os.path.join(dst, "%s_pmc_sq_config3.txt" % tag), "w") as out:
+            out.write("rocprofv3 --pmc (two passes of SQ counters) of `python3 bench.py --config 3 --sites-fraction 0.125 --steps 1 --warmup 1\n"
+                      "--no-cpu-baseline` (500 000 hap x 153 blocks), %s; counters summed over all waves, mean per launch.\n"
+                      "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md).\n\n" % when)
+            for kern in sorted({k[0] for k in sq3}):
+                if "chain" not in kern and "wah" not in kern:
+                    continue
+                out.write("%s\n" % kern)
+                for (kk, c), (v, n) in sorted(sq3.items()):
+                    if kk == kern:
+                        out.write("  %-22s %18.0f   (%d launches)\n" % (c, v, n))
+                wc = sq3.get((kern, "SQ_WAVE_CYCLES"), (0, 0))[0]
+                if wc:
+                    for c, label in (("SQ_ACTIVE_INST_ANY", "issuing"), ("SQ_WAIT_ANY", "waiting"), ("SQ_WAIT_INST_ANY", "waiting to issue")):
+                        v = sq3.get((kern, c))
+                        if v:
+                            out.write("  %-22s %17.1f %% of wave cycles\n" % (label, 100.0 * v[0] / wc))
+                out.write("\n")
     fetch, write = p("%s_fetch" % tag, "p_counter_collection.csv"), p("%s_write" % tag, "p_counter_collection.csv")
     if os.path.exists(fetch) and os.path.exists(write):
         f, w = per_kernel(fetch), per_kernel(write)

@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxsi_hip.so")
+LIB_PATH = os.environ.get("XSI_LIB_PATH") or os.path.join(_HERE, "libxsi_hip.so")  # (XSI_LIB_PATH: A/B runs of two builds on one box)
 
 XSI_OK = 0
 XSI_ERR_ARG = -1

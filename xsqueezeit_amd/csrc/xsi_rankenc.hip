@@ -519,12 +519,15 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
     // every wave is done with the table: the bitmap takes its place
     auto clear_bitmap = [&]() {
         lds_barrier();
-        uint32_t tid_here = tid;
+        uint32_t tid_here = tid, z0, z1, z2, z3;
         asm volatile("" : "+v"(tid_here));
+        // the zeros are made HERE: as a constant the compiler kept one zero quad for the whole kernel - in scratch, and
+        // loaded it back in front of every one of these stores, a round trip to memory each (four per line)
+        asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
 #pragma unroll
         for (int k = 0; k < SMAX / 2; ++k) {
             const uint32_t unit = (uint32_t)k * T + tid_here;
-            if (unit < bmp_units) *reinterpret_cast<LdsV4*>((uintptr_t)(unit * 16u)) = v4u{0u, 0u, 0u, 0u};
+            if (unit < bmp_units) *reinterpret_cast<LdsV4*>((uintptr_t)(unit * 16u)) = v4u{z0, z1, z2, z3};
         }
         lds_barrier();
     };
