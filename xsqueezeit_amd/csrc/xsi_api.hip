@@ -1041,6 +1041,7 @@ int decode_planes_partial(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, u
     }
     L.yp_rows = P.n_wah ? P.n_wah : 1u;
     L.yp_compact = rank_decode_takes_compact(L.N, L.yp_stride, P.n_blocks) ? 1u : 0u;
+    L.yp_rev = (wah_expand_wide(L) && rank_decode_takes_reversed(L.N, L.yp_stride, P.n_blocks)) ? 1u : 0u;
     stage_mark(ctx, XSI_ST_DEC_BOUND);
     HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
     if (wah_hi > wah_lo) {
@@ -1080,6 +1081,7 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
     // rows for the one-workgroup-per-block chain in the compact form (10 instead of 16 bytes per 64 positions)
     L.yp_rows = P.n_wah ? P.n_wah : 1u;
     L.yp_compact = (!any_haploid && rank_decode_takes_compact(L.N, L.yp_stride, P.n_blocks)) ? 1u : 0u;
+    L.yp_rev = (!any_haploid && wah_expand_wide(L) && rank_decode_takes_reversed(L.N, L.yp_stride, P.n_blocks)) ? 1u : 0u;
     stage_mark(ctx, XSI_ST_DEC_BOUND);
     // Phased: the chain needs line j of every block at its step j, so the WAH lines of every block are cut into K
     // ranges; the expansion of range p+1 (side stream) runs underneath the chain of range p, which parks its

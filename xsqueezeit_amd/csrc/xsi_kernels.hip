@@ -3231,7 +3231,12 @@ __global__ void __launch_bounds__(1024) k_wah_expand_wide_t(const uint8_t* __res
             const uint32_t c = (uint32_t)__popc(f0) + (uint32_t)__popc(f1);
             const uint32_t inc = wave_scan_incl_dpp(c);
             const uint32_t pre0 = in ? (info & 0x7FFFFFFFu) + inc - c : row_ones;
-            if (idx < L.yp_stride) dst[idx >> 1] = make_uint4(f0, pre0, f1, pre0 + (uint32_t)__popc(f0));
+            if (idx < L.yp_stride) {
+                if (L.yp_rev)  // for k_chain_decode_rank_big<.., REV>: bits reversed, minus the ones up to the word's end
+                    dst[idx >> 1] = make_uint4(__brev(f0), 0u - (pre0 + (uint32_t)__popc(f0)), __brev(f1), 0u - (pre0 + c));
+                else
+                    dst[idx >> 1] = make_uint4(f0, pre0, f1, pre0 + (uint32_t)__popc(f0));
+            }
         }
         prof(6);  // B2
         // (b_info / b_base / a_ones of the next line are written behind at least one more barrier)
@@ -3241,6 +3246,7 @@ __global__ void __launch_bounds__(1024) k_wah_expand_wide_t(const uint8_t* __res
 static bool wah_expand_is_wide(const DecLines& L) {
     return L.y_stride64 * 8u > 16384u && L.yp_stride <= 1024u * (uint32_t)WAH_WIDE_STRIPES && !tuning_env("XSI_NO_WIDE_EXPAND");
 }
+bool wah_expand_wide(const DecLines& L) { return wah_expand_is_wide(L); }
 
 uint32_t wah_expand_lines_per_group(const DecLines& L) { return wah_expand_is_wide(L) ? WAH_WIDE_LPG : WAH_LINES_PER_WAVE; }
 

@@ -125,6 +125,8 @@ struct DecLines {
     // of y_stride64 64-bit chunks, then - behind all yp_rows of them - 16-bit "ones before the chunk": 10 bytes
     // per 64 positions instead of 16; the chain kernel forms the pairs while it stages a row in LDS
     uint32_t yp_compact;
+    uint32_t yp_rev;            // long rows (k_wah_expand_wide_t -> k_chain_decode_rank_big): pairs {row bits bit-reversed, MINUS the
+                                // ones up to the END of the word}: the bit and the ones before a position from ONE shift (round 5)
     uint32_t yp_rows;
     uint32_t* wah_z;       // [wah rank] zeros of the line (line bits - ones)
     uint32_t y_stride64;   // ceil(N/64): 64-bit words of a plain bit row
@@ -169,6 +171,8 @@ hipError_t launch_wah_expand_phase(hipStream_t s, const uint8_t* file, const Dec
 // the one-workgroup-per-block decode chain over one range of lines; ranks parked in `state` between the launches
 bool rank_decode_phased_ok(uint32_t N, uint32_t yp_stride, uint32_t n_blocks);
 bool rank_decode_takes_compact(uint32_t N, uint32_t yp_stride, uint32_t n_blocks);
+bool rank_decode_takes_reversed(uint32_t N, uint32_t yp_stride, uint32_t n_blocks);  // (the chain side; the expansion side: wah_expand_wide)
+bool wah_expand_wide(const DecLines& L);
 uint64_t rank_decode_state_words(uint32_t N, uint32_t n_blocks);
 hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                                     uint32_t* out_rows, uint32_t out_stride_w, const uint32_t* ph_start,

@@ -60,6 +60,7 @@ struct RankArgs {
     uint32_t yc_stride;
     uint32_t big_splits, big_n_blocks;  // k_chain_decode_rank_big: workgroups per block, blocks of the launch
     uint32_t big_prof;
+    uint32_t yp_rev;            // rows in the reversed form (DecLines::yp_rev)
 };
 
 constexpr int RANK_RP = 8;  // {bits, prefix} pairs a thread carries while a batch is in flight
@@ -273,7 +274,10 @@ __global__ void __launch_bounds__(T) k_chain_decode_rank(RankArgs A) {
 // the same XCD, and share the row through that XCD's L2 (see the kernel's first lines).
 __device__ unsigned long long g_big_prof[4];  // XSI_BIG_PROF: 100 MHz ticks of workgroup 0, wave 0: main, barrier, row to LDS + stores + barrier
 
-template <int E, int RP, bool PROF = false>
+// REV: the rows come as {bits reversed within the word, -(ones up to the word's end)} (DecLines::yp_rev): shifted left by
+// my position the word has MY bit on top and the positions behind me below it, so one v_lshlrev serves both the bit
+// (sign) and the count (v_bcnt with the negated prefix gives -(ones before me)): 10 instead of 11 vector instructions a chunk.
+template <int E, int RP, bool PROF = false, bool REV = false>
 __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
     // G: gathers in flight per wave (4 where 64 ranks and 32 prefetch registers leave no room for 8 pairs)
     constexpr int T = 1024, W = 16, G = (E == 64 && RP >= 16) ? 4 : 8;
@@ -403,10 +407,18 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
             static_for<0, G>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
                 const uint32_t rr = r[g0 + e];
-                const uint32_t bit = __builtin_amdgcn_ubfe(pr[e][0], rr, 1u);
-                const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
-                const uint64_t m = __ballot(bit != 0u);
-                r[g0 + e] = __builtin_amdgcn_inverse_ballot_w64(m) ? Zs + ob : rr - ob;
+                uint64_t m;
+                if constexpr (REV) {
+                    const uint32_t sh = pr[e][0] << (rr & 31u);            // my bit on top, the positions behind me below it
+                    const uint32_t nob = (uint32_t)__popc(sh) + pr[e][1];  // -(ones before me)
+                    m = __ballot((int32_t)sh < 0);
+                    r[g0 + e] = __builtin_amdgcn_inverse_ballot_w64(m) ? Zs - nob : rr + nob;
+                } else {
+                    const uint32_t bit = __builtin_amdgcn_ubfe(pr[e][0], rr, 1u);
+                    const uint32_t ob = (uint32_t)__popc(__builtin_amdgcn_ubfe(pr[e][0], 0u, rr)) + pr[e][1];
+                    m = __ballot(bit != 0u);
+                    r[g0 + e] = __builtin_amdgcn_inverse_ballot_w64(m) ? Zs + ob : rr - ob;
+                }
                 mine_lo = write_lane(mine_lo, (uint32_t)m, (uint32_t)(g0 + e));
                 mine_hi = write_lane(mine_hi, (uint32_t)(m >> 32), (uint32_t)(g0 + e));
             });
@@ -723,6 +735,15 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A, 
     }
     if ((env_e == 8 || env_e == 16 || env_e == 32 || env_e == 64) && (uint32_t)env_e <= e_max) E = (uint32_t)env_e;
 #define XSI_BIG_CASE(EE, RR)                                                                                 \
+    if (E == EE && RP == RR && A.yp_rev) {                                                                   \
+        auto kern = &k_chain_decode_rank_big<EE, RR, false, true>;                                           \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                       \
+        A.big_splits = splits_of(EE);                                                                        \
+        A.big_n_blocks = n_blocks;                                                                           \
+        kern<<<dim3(splits_of(EE) * ((n_blocks + 7u) & ~7u)), dim3(1024), lds, s>>>(A);                      \
+        return hipGetLastError();                                                                            \
+    }                                                                                                        \
     if (E == EE && RP == RR) {                                                                               \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_decode_rank_big<EE, RR>),  \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
@@ -829,6 +850,10 @@ bool rank_decode_phased_ok(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
     return rank_decode_family(N, yp_stride, n_blocks) != 0 || tuning_env("XSI_DEC_PHASES_SMALL") != nullptr;
 }
 
+bool rank_decode_takes_reversed(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
+    return rank_decode_family(N, yp_stride, n_blocks) == 2 && !tuning_env("XSI_NO_REVERSED_YP");
+}
+
 bool rank_decode_takes_compact(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
     return N <= 65536u && rank_decode_family(N, yp_stride, n_blocks) == 1 && !tuning_env("XSI_NO_COMPACT_YP");
 }
@@ -839,6 +864,7 @@ static void rank_args_rows(RankArgs& R, const DecLines& L) {
     R.yc = nullptr;
     R.ypre = nullptr;
     R.yc_stride = 0;
+    R.yp_rev = L.yp_rev;
     if (L.yp_compact) {
         R.yc = reinterpret_cast<const uint2*>(L.yp);
         R.ypre = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(L.yp) + 8ull * L.y_stride64 * L.yp_rows);
