@@ -23,6 +23,10 @@ def main():
     ap.add_argument("--cells", type=int, default=24_000_000, help="packed cases: haplotypes x lines at most")
     ap.add_argument("--max-lines", type=int, default=400)
     ap.add_argument("--files", action="store_true", help="every fourth case through xsi_writer_* / xsi_accessor_*")
+    ap.add_argument("--long-rows", action="store_true",
+                    help="packed cases at 140 000 .. 524 288 haplotypes with a density of its own per line (sparse, dense and "
+                         "mostly-ones lines next to each other: both exchange forms of k_chain_rank_enc_multi and the "
+                         "long-row decode, 3 to 8 workgroups per block)")
     args = ap.parse_args()
     import gpu_util as G
     from oracle import oracle
@@ -99,15 +103,22 @@ def main():
             if 32768 * 2 <= n_haps <= 65535 * 2:   # the reference's A_T mismatch window is refused by design
                 n_haps = 131072 + 2 * int(rng.integers(0, 3000))
             cells_budget = args.cells
+            if args.long_rows:
+                n_haps = (int(rng.choice([140000, 196608, 200000, 262144, 330000, 400002, 500000, 524288])) - 2 * int(rng.integers(0, 40))) & ~1
+                cells_budget = max(cells_budget, 30_000_000)
             n_lines = int(min(max(1, cells_budget // n_haps), rng.integers(1, args.max_lines)))
             block_len = int(rng.choice([1, 3, 8, 16, 64, 100, 8192]))
             thr = int(rng.choice([0, 1, n_haps // 1000, n_haps // 100, n_haps // 10]))
             dens = float(rng.choice([0.0005, 0.01, 0.1, 0.5, 0.9]))
-            bits = (rng.random((n_lines, n_haps)) < dens).astype(np.uint8)
+            if args.long_rows:
+                block_len = int(rng.choice([max(1, n_lines // 2 + 1), 7, 8192]))
+                thr = int(rng.choice([0, n_haps // 1000]))
+                dens = rng.choice([0.002, 0.01, 0.05, 0.12, 0.3, 0.5, 0.8, 0.97, 0.999], size=(n_lines, 1))
+            bits = (rng.random((n_lines, n_haps), dtype=np.float32) < dens).astype(np.uint8)
             # runs: copy founders so that PBWT produces long fills
             if rng.random() < 0.5 and n_lines > 4:
                 f = rng.integers(0, 8, size=n_haps)
-                fb = (rng.random((n_lines, 8)) < dens).astype(np.uint8)
+                fb = (rng.random((n_lines, 8)) < dens).astype(np.uint8)  # (dens: a scalar, or one value per line)
                 bits = fb[:, f] ^ (rng.random((n_lines, n_haps)) < 0.002).astype(np.uint8)
             stride = synth.row_stride_bytes(n_haps)
             packed = synth.pack_rows(bits, stride)
@@ -120,7 +131,7 @@ def main():
             out, counts = G.decode_packed(got, n_haps, stride)
             ok2 = np.array_equal(out, packed) and np.array_equal(counts, bits.sum(1).astype(np.int32))
             print("%3d packed  haps=%6d lines=%4d block=%4d thr=%5d dens=%.4f bytes=%8d  encode %s decode %s  (%.0f s)"
-                  % (c, n_haps, n_lines, block_len, thr, dens, len(got), "ok" if ok else "MISMATCH", "ok" if ok2 else "MISMATCH",
+                  % (c, n_haps, n_lines, block_len, thr, float(np.mean(dens)), len(got), "ok" if ok else "MISMATCH", "ok" if ok2 else "MISMATCH",
                      time.time() - t0), flush=True)
             if not (ok and ok2):
                 sys.exit(1)
