@@ -527,6 +527,10 @@ def main():
         # weak-scaling line, so that a driver that only runs the default command at N = 1, 2, 4, 8 records it
         sub = north_star_args(args)
         try:
+            import gc
+            import torch
+            gc.collect()
+            torch.cuda.empty_cache()  # (the library sizes its workspace by what the device reports free)
             o3, ok3 = run_roundtrip(sub, emit=False, dist_sub=True)
         except (Exception, SystemExit) as e:  # (every rank raises or none: the failure modes are collective)
             o3, ok3 = {"error": "%s: %s" % (type(e).__name__, e)}, False
