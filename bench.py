@@ -521,7 +521,7 @@ def main():
         # The other single-GPU configurations of BASELINE.json in the same process, attached to the same line, so
         # that they are timed by whoever runs this command and not only by the builder (VERDICT r3 #1b).
         out["other_configs"] = run_other_configs(args, t_start)
-    if world > 1 and args.config == 2 and not custom and not args.no_other_configs:
+    if (world > 1 or args.force_dist) and args.config == 2 and not custom and not args.no_other_configs:
         # N > 1: the north_star job itself - BASELINE configs[3], 500 000 hap x 10 M sites, its 1221 blocks sharded over
         # these same ranks (strong scaling), with gather_ms, the ranks' times and its own roofline - attached to the
         # weak-scaling line, so that a driver that only runs the default command at N = 1, 2, 4, 8 records it
@@ -548,7 +548,9 @@ def main():
 def north_star_args(args):
     import copy
     a = copy.copy(args)
-    a.config, a.haps, a.sites, a.seed, a.sites_fraction = 3, None, None, None, 1.0
+    a.config, a.haps, a.sites, a.seed = 3, None, None, None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        a.sites_fraction = 1.0  # the whole job; (--force-dist on one GPU: the fraction given, a rehearsal of this path)
     a.steps, a.warmup, a.cpu_sample_cells = 2, 1, 4.2e9
     return a
 

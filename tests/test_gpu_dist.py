@@ -167,3 +167,26 @@ def test_bench_multi_rank_path_with_one_rank(torch_gather):
     assert g["ranks"] == 1 and g["own_part_equals_encode_output"] and g["offsets_ascending"]
     assert g["bytes"] == out["config"]["xsi_bytes_this_gpu"] and g["blocks"] == out["config"]["blocks_this_gpu"]
     assert ("torch.distributed" in g["via"]) == torch_gather
+
+
+def test_bench_attaches_the_north_star_job_on_the_multi_rank_path():
+    """At N > 1 `python bench.py` runs BASELINE configs[3] sharded over the same ranks after the weak-scaling line and
+    attaches it as other_configs.  Rehearsed here with one rank (--force-dist) and a fraction of the
+    sites: one process group for both runs, a second RCCL communicator, gather_ms, CPU sample and byte comparison of
+    the first blocks in the sub-run too."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MASTER_PORT"] = "29579"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--sites-fraction", "0.007",
+                        "--cpu-sample-cells", "3e8", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["roundtrip_equal"] and out["scaling"] == "weak" and out["gather_ms"] > 0
+    assert out["cpu_baseline"] and out["bit_exact_vs_oracle"]
+    (name, sub), = out["other_configs"].items()
+    assert "configs[3]" in name and "north_star" in name and "error" not in sub
+    assert sub["scaling"] == "strong" and sub["roundtrip_equal"] and sub["gather_ms"] > 0
+    assert sub["config"]["haps"] == 500000 and sub["gathered"]["own_part_equals_encode_output"]
+    assert sub["config"]["memory_plan_bytes"]["fits"]
