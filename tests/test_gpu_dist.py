@@ -177,7 +177,7 @@ def test_bench_attaches_the_north_star_job_on_the_multi_rank_path():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["MASTER_PORT"] = "29579"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--sites-fraction", "0.007",
-                        "--cpu-sample-cells", "3e8", "--steps", "1", "--warmup", "1"],
+                        "--cpu-sample-cells", "6e8", "--steps", "1", "--warmup", "1"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
