@@ -348,7 +348,7 @@ struct RankEncMultiArgs {
     uint32_t thr;           // lines with at most this many minor alleles travel as lists
     uint32_t* sync;         // [0] abort, [2] profile records written
     uint32_t* list_flags;   // [group][parity][member][32 words]: per wave {length, seq}
-    uint32_t* lists;        // [group][parity][S * 16 waves][MULTI_LIST_CAP] ranks, whole 64-entry stores (padding: ~0)
+    uint32_t* lists;        // [group][parity][S * 16 waves][MULTI_LIST_CAP] ranks, whole 64-entry stores; the length a multiple of 4 (padding: copies of the last entry)
     uint64_t* flags;        // [group][16]: [0, 8) bitmap flags (seq), [8, 16) slice flags (seq << 32 | ones of the slice)
     uint32_t* bmps;         // [group][member][S * 2048] words: the members' private bitmaps of the row
     v4u* slices;            // [group][member][1024]: two table entries each
@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
         }
         v4u rk[SMAX];
         auto load_piece = [&](int k, uint32_t i0) {
-            // lists are whole 64-entry stores; beyond a list the range check returns 0 (no memory request), masked below
+            // beyond a list the range check returns 0 (no memory request), masked below
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(lst + (size_t)k * 16u * MULTI_LIST_CAP), 0, (int)(cnt[k] * 4u), 0x00020000);
             rk[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (i0 + lane * 4u) * 4u, 0, 16);
@@ -592,14 +592,12 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
         for (uint32_t i0 = 0; i0 < longest; i0 += 256u) {
 #pragma unroll
             for (int k = 0; k < SMAX; ++k) {
-                if (i0 + lane * 4u < cnt[k]) {
+                if (i0 + lane * 4u < cnt[k]) {  // (a list's length is a multiple of four: a lane's four entries are all there or all beyond)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const uint32_t e = rk[k][u];
-                        if (e != ~0u) {  // (padding of a list's last 64-entry store)
-                            LdsU32* p = reinterpret_cast<LdsU32*>((uintptr_t)((e >> 3) & 0x1FFFCu));
-                            __hip_atomic_fetch_or(p, 1u << (e & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
+                        LdsU32* p = reinterpret_cast<LdsU32*>((uintptr_t)((e >> 3) & 0x1FFFCu));
+                        __hip_atomic_fetch_or(p, 1u << (e & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
                 load_piece(k, i0 + 256u);
@@ -881,8 +879,14 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
         auto publish = [&]() {
             const uint32_t left = (wpos - ring_lds) >> 2;
             if (left) {
-                my_list[n_out + lane] = lane < left ? ring[lane] : ~0u;
-                n_out += 64u;
+                // The rest leaves as one more 64-entry store, but the list's LENGTH only grows to the next multiple of four
+                // (readers take four entries per lane), the one to three entries of padding being copies of the last real
+                // one: setting a bit twice changes nothing, so the readers need no test for padding (a third of the apply
+                // loop's instructions).  (Padding the whole store with copies put up to 63 atomics on one LDS word: +40 ms.)
+                const uint32_t v = ring[lane];
+                const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(left - 1u));  // (every lane enabled here)
+                my_list[n_out + lane] = lane < left ? v : last;
+                n_out += (left + 3u) & ~3u;
             }
             if (lane == 0) wtot[64u + w] = n_out;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
