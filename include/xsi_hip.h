@@ -58,9 +58,10 @@ int xsi_hip_ctx_synchronize(xsi_hip_ctx* ctx);
 /* Bytes of device workspace currently held by the context. */
 uint64_t xsi_hip_ctx_workspace_bytes(const xsi_hip_ctx* ctx);
 
-/* Encode batches this context has run a second time with the one-workgroup-per-block streaming chain because
- * the launch of the chain that spreads a block over several workgroups (65 536 < haplotypes <= 524 288) was
- * aborted: its workgroups must all be resident at once, which another process, stream or CU mask can prevent.
+/* Encode batches this context has run with the one-workgroup-per-block streaming chain although the chain that
+ * spreads a block over several workgroups (65 536 < haplotypes <= 524 288) was eligible: its launch was aborted
+ * (its workgroups must all be resident at once, which another process, stream or CU mask can prevent) and the
+ * batch was run a second time, or it could not be launched at all (a device too small for one group).
  * The bytes written are the same either way (pbwt_sort, include/internal_gt_record.hpp:32-59). */
 uint64_t xsi_hip_ctx_chain_fallbacks(const xsi_hip_ctx* ctx);
 uint32_t xsi_hip_ctx_reencode_ranges(const xsi_hip_ctx* ctx);

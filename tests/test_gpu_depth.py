@@ -129,6 +129,27 @@ def test_long_row_encode_exchange_forms(n_haps, block_len, n_blocks, list_thr, m
     assert got == ref
 
 
+def test_long_row_encode_with_more_groups_than_a_round_of_eight_member_blocks():
+    """140 000 haplotypes are 3 workgroups per block: 80 groups of a 256-CU chip, 90 blocks on them - the balanced line
+    schedule with several cuts, parking slots and flags indexed by (group, member) beyond the 32 groups of the 500 000-
+    haplotype shape.  Bytes == the oracle's, and the long-row kernel itself ran (no fallback to the streaming chain)."""
+    import gpu_util as G
+    L = binding.lib()
+    n_haps, block_len, n_blocks = 140000, 36, 90
+    n_lines = block_len * n_blocks
+    bits, packed, stride = _device_synth(n_haps, n_lines, 21)
+    p = G.params(n_haps // 2, block_len, 0)  # MAC threshold 0: every line with a carrier is a WAH line
+    ref = G.oracle_file_from_bits(bits, p)
+    before = L.xsi_hip_ctx_chain_fallbacks(G.ctx().handle)
+    region, offsets, res = G.encode_packed(packed, n_haps, p)
+    assert L.xsi_hip_ctx_chain_fallbacks(G.ctx().handle) == before
+    assert res.n_wah_lines > n_lines // 2
+    got = G.assemble_file(region, offsets, p, n_lines, n_lines, ["S%d" % i for i in range(n_haps // 2)])
+    assert got == ref
+    out, _ = G.decode_packed(got, n_haps, stride)
+    assert np.array_equal(out, packed)
+
+
 def test_multi_workgroup_chain_falls_back_instead_of_hanging(monkeypatch):
     """The encode chain over several workgroups per block exchanges rank lists and row slices once per line and
     needs every workgroup of a block resident at once.  If a workgroup never shows up (here: member 1 of every

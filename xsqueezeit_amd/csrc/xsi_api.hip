@@ -330,7 +330,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
         WS(L.chain_lists, "enc.chain_lists", 4ull * CHAIN_LIST_WORDS);
         WS(L.chain_slices, "enc.chain_slices", CHAIN_SLICE_BYTES);
         WS(L.chain_bmps, "enc.chain_bmps", CHAIN_BMP_BYTES);
-        WS(L.chain_items, "enc.chain_items", 4ull * 64u + 16ull * ((size_t)n_blocks + CHAIN_MAX_WGS / 4u + 2u));
+        WS(L.chain_items, "enc.chain_items", 4ull * CHAIN_ITEM_BEGIN_WORDS + 16ull * ((size_t)n_blocks + CHAIN_MAX_WGS / 2u + 2u));
         WS(L.chain_park, "enc.chain_park", CHAIN_PARK_BYTES);
     }
     // WAH16 words per line, worst case ceil(N/15) (+1 for the saturation split): encode once, then copy
@@ -382,7 +382,9 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     if (sp_scratch && !sparse_behind_chain)
         if (int rc = fork_sparse()) return rc;
     stage_mark(ctx, XSI_ST_CHAIN_ENC);
-    HIP_TRY(launch_chain_encode(s, d_blocks, n_blocks, L, scratch_a, L.bin_nbits != nullptr));
+    bool multi_refused = false;
+    HIP_TRY(launch_chain_encode(s, d_blocks, n_blocks, L, scratch_a, L.bin_nbits != nullptr, &multi_refused));
+    if (multi_refused) ctx->chain_fallbacks++;  // (the long-row kernel was eligible but could not be launched: the streaming chain ran)
     stage_mark(ctx, XSI_ST_WAH_SIZE);
     HIP_TRY(launch_wah_sizes(s, L, d_totals, n_bin));
     // (behind the sizing pass too: its 1024-thread workgroups take every wave slot, the lists would only queue up

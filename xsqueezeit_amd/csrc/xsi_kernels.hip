@@ -1415,14 +1415,16 @@ const char* chain_kernel_name(uint32_t N, uint32_t n_blocks, bool decode) {
 }
 
 hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
-                               uint32_t* scratch_a, bool any_haploid) {
+                               uint32_t* scratch_a, bool any_haploid, bool* multi_refused) {
     bool rank_done = false;
+    if (multi_refused) *multi_refused = false;
     if (chain_rank_enc_multi_supported(L)) {
         hipError_t e = launch_rank_encode_multi(s, blocks, n_blocks, L);
         if (e == hipErrorInvalidValue) {
             // the device (or the CU mask of this process) cannot hold a whole group of workgroups:
-            // k_chain_stream below takes the blocks
+            // k_chain_stream below takes the blocks (the caller counts it as a fallback)
             (void)hipGetLastError();
+            if (multi_refused) *multi_refused = true;
         } else {
             if (e != hipSuccess || !any_haploid) return e;
             rank_done = true;  // k_chain_global below only takes the blocks with fully haploid lines

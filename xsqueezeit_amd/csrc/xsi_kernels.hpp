@@ -43,7 +43,7 @@ struct EncLines {
     uint32_t* chain_lists;
     void* chain_slices;
     uint32_t* chain_bmps;       // the members' private bitmaps of a row (bitmap exchange), CHAIN_BMP_BYTES
-    uint32_t* chain_items;      // the launch's schedule: 64 words of per-group begins, then 16-byte items (k_multi_schedule)
+    uint32_t* chain_items;      // the launch's schedule: CHAIN_ITEM_BEGIN_WORDS of per-group begins, then 16-byte items (k_multi_schedule)
     uint32_t* chain_park;       // ranks handed from a block's head part to its tail part, CHAIN_PARK_BYTES
     uint32_t no_multi;
     uint16_t* wah_scratch;      // [rank][wah_scratch_stride] WAH16 words of each line (encoded once, copied to place)
@@ -85,7 +85,8 @@ hipError_t launch_classify(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, c
 hipError_t launch_scan_blocks_wah(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, uint32_t* totals);
 hipError_t launch_build_wah_list(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L);
 hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
-                               uint32_t* scratch_a /*global-memory variant only*/, bool any_haploid);
+                               uint32_t* scratch_a /*global-memory variant only*/, bool any_haploid,
+                               bool* multi_refused = nullptr /* out: the long-row kernel was eligible but could not be launched */);
 hipError_t launch_wah_sizes(hipStream_t s, const EncLines& L, const uint32_t* d_total_wah, uint32_t max_wah);
 // rows short enough for the unit encoder (no WAH scratch is needed then)
 bool wah_units_ok(uint32_t y_stride64);
@@ -205,6 +206,7 @@ constexpr uint32_t CHAIN_SLICEFLAG_WORDS = CHAIN_MAX_WGS * 2u * 16u * 2u;  // 8 
 constexpr uint32_t CHAIN_XCC_WORDS = (CHAIN_MAX_WGS / 2u) * 8u;
 constexpr uint32_t CHAIN_SYNC_TOTAL_WORDS = CHAIN_SYNC_WORDS + CHAIN_LISTFLAG_WORDS + CHAIN_SLICEFLAG_WORDS + CHAIN_XCC_WORDS;
 constexpr uint64_t CHAIN_SLICE_BYTES = (uint64_t)CHAIN_MAX_WGS * 2u * 16384u;
+constexpr uint32_t CHAIN_ITEM_BEGIN_WORDS = 132u;  // the schedule's per-group begins (up to 128 groups + 1), then its items
 constexpr uint64_t CHAIN_PARK_BYTES = (uint64_t)CHAIN_MAX_WGS * 64u * 1024u * 4u;  // per workgroup 64 x 1024 ranks
 constexpr uint64_t CHAIN_BMP_BYTES = (uint64_t)CHAIN_MAX_WGS * 8u * 8192u;  // per workgroup a bitmap of up to 8 slices
 bool chain_rank_enc_multi_supported(const EncLines& L);

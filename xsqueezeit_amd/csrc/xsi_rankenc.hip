@@ -362,7 +362,7 @@ struct RankEncMultiArgs {
     const uint32_t* item_begin;  // [n_groups + 1]
     const MultiItem* items;
     uint32_t* park;              // [slot][member][64][1024]: the ranks a block's head part hands to its tail part
-    uint32_t* park_flags;        // [slot][8]: 1 = that member's ranks are parked
+    uint32_t* park_flags;        // [slot][S]: 1 = that member's ranks are parked
 };
 
 // ---- the schedule.  A launch has B blocks for G groups; block b is a serial chain of n_wah(b) lines.  Walked block by
@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
             asm volatile("" : "+v"(t));
             return A.park + ((size_t)(fl >> 8) * S + member) * ((size_t)E * T) + t;
         };
-        auto park_flag_of = [&](uint32_t fl) -> uint32_t* { return A.park_flags + (fl >> 8) * 8u + member; };
+        auto park_flag_of = [&](uint32_t fl) -> uint32_t* { return A.park_flags + (fl >> 8) * S + member; };  // (groups x S <= 256 flags)
         uint32_t r[E];
         if (iflags & MULTI_ITEM_LOAD) {
             uint32_t* const park_flag = park_flag_of(iflags);
@@ -1070,13 +1070,15 @@ static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* b
     hipError_t e = hipMemsetAsync(L.chain_sync, 0, 4ull * CHAIN_SYNC_TOTAL_WORDS, s);
     if (e != hipSuccess) return e;
     const uint32_t n_groups = 8u * A.gpx;
-    static_assert(CHAIN_SYNC_WORDS >= 16u + (CHAIN_MAX_WGS / 8u) * 8u, "a parking flag per group and member");
+    static_assert(CHAIN_SYNC_WORDS >= 16u + CHAIN_MAX_WGS, "a parking flag per workgroup of the launch (group x member)");
+    static_assert(CHAIN_ITEM_BEGIN_WORDS % 4u == 0u && CHAIN_ITEM_BEGIN_WORDS >= CHAIN_MAX_WGS / 2u + 1u,
+                  "per-group begins (at most 128 groups: two workgroups per block), the items behind them 16-byte aligned");
     A.item_begin = L.chain_items;
-    A.items = reinterpret_cast<const MultiItem*>(L.chain_items + 64u);  // (16-byte aligned: at most 33 begins in front)
+    A.items = reinterpret_cast<const MultiItem*>(L.chain_items + CHAIN_ITEM_BEGIN_WORDS);
     A.park = L.chain_park;
     A.park_flags = L.chain_sync + 16u;
-    if (n_groups + 1u > 64u || !L.chain_items || !L.chain_park) return hipErrorInvalidValue;
-    k_multi_schedule<<<dim3(1), dim3(64), 0, s>>>(blocks, n_blocks, n_groups, L.chain_items, reinterpret_cast<MultiItem*>(L.chain_items + 64u),
+    if (n_groups + 1u > CHAIN_ITEM_BEGIN_WORDS || !L.chain_items || !L.chain_park) return hipErrorInvalidValue;
+    k_multi_schedule<<<dim3(1), dim3(64), 0, s>>>(blocks, n_blocks, n_groups, L.chain_items, reinterpret_cast<MultiItem*>(L.chain_items + CHAIN_ITEM_BEGIN_WORDS),
                                                   tuning_env("XSI_MULTI_ROUND_ROBIN") ? 1u : 0u);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
