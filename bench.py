@@ -985,7 +985,8 @@ def run_roundtrip(args, emit=True, dist_sub=False):
         # MI355X_MICROARCH.md); labelled with the commit they were taken at, null for other workloads
         traffic = traffic_src = kernel_traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and not custom and (world == 1 or not strong):  # weak scaling: every rank runs the profiled shape
+        # (weak scaling: every rank runs the profiled shape; configs[3]: the shard of one of 8 GPUs was profiled)
+        if os.path.exists(tpath) and not custom and (world == 1 or not strong) and (args.config != 3 or abs(args.sites_fraction - 0.125) < 1e-9):
             try:
                 tj = json.load(open(tpath)).get("config%d" % args.config, {})
                 ks = tj.get("kernels", {})

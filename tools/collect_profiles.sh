@@ -18,6 +18,8 @@ rocprofv3 --kernel-trace --stats -d $O/${TAG}_c3stats -o p --output-format csv -
 C3="bench.py --config 3 --sites-fraction 0.125 --steps 1 --warmup 1 --no-cpu-baseline"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $O/${TAG}_c3sq1 -o p --output-format csv -- python3 $C3 > /dev/null 2> $O/${TAG}_c3sq1.err
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SMEM --kernel-trace -d $O/${TAG}_c3sq2 -o p --output-format csv -- python3 $C3 > /dev/null 2> $O/${TAG}_c3sq2.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${TAG}_c3fetch -o p --output-format csv -- python3 $C3 > /dev/null 2> $O/${TAG}_c3fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${TAG}_c3write -o p --output-format csv -- python3 $C3 > /dev/null 2> $O/${TAG}_c3write.err
 XSI_ENABLE_TUNING_ENV=1 XSI_MULTI_PROF=983041 python3 $C3 > /dev/null 2> $O/${TAG}_config3_phase_clocks.err
 grep "xsi multi prof" $O/${TAG}_config3_phase_clocks.err > $O/${TAG}_config3_phase_clocks.txt || true
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_stats -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $O/${TAG}_stats.json 2> $O/${TAG}_stats.err

@@ -132,6 +132,29 @@ def main():
             tj = {}  # round-1 layout
         tj["config2"] = {"measured_at": when, "command": "python bench.py (BASELINE configs[2])", "kernels": kernels}
         json.dump(tj, open(tpath, "w"), indent=1, sort_keys=True)
+    # the same two passes over the configs[3] shard (the long-row kernels)
+    f3, w3 = p("%s_c3fetch" % tag, "p_counter_collection.csv"), p("%s_c3write" % tag, "p_counter_collection.csv")
+    if os.path.exists(f3) and os.path.exists(w3):
+        f, w = per_kernel(f3), per_kernel(w3)
+        kernels, rows = {}, []
+        for name in sorted({k[0] for k in f} | {k[0] for k in w}):
+            if not name.startswith("k_"):
+                continue
+            fk, launches = f.get((name, "FETCH_SIZE"), (0.0, 0))
+            fk *= 1024.0
+            wk = w.get((name, "WRITE_SIZE"), (0.0, 0))[0] * 1024.0
+            kernels[name] = {"fetch_size_bytes_raw": fk, "read_bytes_corrected": 2.0 * fk, "write_bytes": wk,
+                             "hbm_bytes_per_launch": 2.0 * fk + wk, "launches_in_the_profiled_run": launches}
+            rows.append((name, launches, fk, 2.0 * fk, wk, 2.0 * fk + wk))
+        with open(os.path.join(dst, "%s_config3_hbm_traffic.csv" % tag), "w") as out:
+            out.write("kernel,launches,FETCH_SIZE_bytes_raw,read_bytes_x2_gfx950,WRITE_SIZE_bytes,hbm_bytes_per_launch\n")
+            for r in sorted(rows, key=lambda x: -x[5] * max(x[1], 1)):
+                out.write("%s,%d,%.0f,%.0f,%.0f,%.0f\n" % r)
+        tpath = os.path.join(dst, "hbm_traffic.json")
+        tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        tj["config3"] = {"measured_at": when, "command": "python bench.py --config 3 --sites-fraction 0.125 (the shard of one of 8 GPUs)",
+                         "kernels": kernels}
+        json.dump(tj, open(tpath, "w"), indent=1, sort_keys=True)
     sq = {}
     for part in ("sq1", "sq2"):
         f = p("%s_%s" % (tag, part), "p_counter_collection.csv")
