@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                 *reinterpret_cast<LdsV4*>((uintptr_t)(unit * 32u + 16u)) = v4u{wv[i][2], p2, wv[i][3], p3};
                 // my slice of the row for the WAH pass (rows are whole 16-byte units)
                 if ((unit >> 9) == member && unit * 4u < A.dst_stride_w)
-                    *reinterpret_cast<v4u*>(A.dst + (size_t)rank * A.dst_stride_w + unit * 4u) = wv[i];
+                    __builtin_nontemporal_store(wv[i], reinterpret_cast<v4u*>(A.dst + (size_t)rank * A.dst_stride_w + unit * 4u));
             }
         }
         Zout = N - ones;
@@ -728,7 +728,11 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                     (__attribute__((address_space(1))) uint64_t*)(gsflags + member)) = ((uint64_t)seq << 32) | ones_slice;
             // my part of the row for the WAH pass: behind the flag, nobody in the chain waits for this store
             const uint32_t roww = member * SL_WORDS + 2u * tid_here;  // rows are whole 16-byte units
-            if (roww < A.dst_stride_w) *reinterpret_cast<uint2*>(A.dst + (size_t)rank * A.dst_stride_w + roww) = v;
+            if (roww < A.dst_stride_w) {
+                typedef uint32_t v2u_nt __attribute__((ext_vector_type(2)));
+                v2u_nt vv = {v.x, v.y};
+                __builtin_nontemporal_store(vv, reinterpret_cast<v2u_nt*>(A.dst + (size_t)rank * A.dst_stride_w + roww));
+            }
         }
         prof(6);  // slice ORed, scanned, stored, flagged
         uint32_t tot_l;
