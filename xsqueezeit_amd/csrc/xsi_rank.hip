@@ -436,8 +436,8 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
         Z = (uint32_t)__builtin_amdgcn_readfirstlane((int)Z_n);
         asm volatile("" : "+s"(line), "+s"(Z)::"memory");
         if (store_lane) {
-            uint2* orow = reinterpret_cast<uint2*>(A.out + orow_w);
-            orow[cg0 + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
+            rank_u32x2 ov = {mine_lo & vm_lo, mine_hi & vm_hi};
+            __builtin_nontemporal_store(ov, reinterpret_cast<rank_u32x2*>(A.out + orow_w) + cg0 + lane);
         }
         if (pad_writer)
             for (uint32_t i = row_words + tid; i < A.out_stride_w; i += T) A.out[orow_w + i] = 0;
@@ -607,7 +607,10 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
         line = (uint32_t)__builtin_amdgcn_readfirstlane((int)line_n);  // the two small loads are consumed here too
         Z = (uint32_t)__builtin_amdgcn_readfirstlane((int)Z_n);
         asm volatile("" : "+s"(line), "+s"(Z)::"memory");
-        if (store_lane) reinterpret_cast<uint2*>(orow)[cg0 + lane] = make_uint2(mine_lo & vm_lo, mine_hi & vm_hi);
+        if (store_lane) {  // nobody on the device reads the row again before the launch ends: keep it out of the L2's way
+            rank_u32x2 ov = {mine_lo & vm_lo, mine_hi & vm_hi};
+            __builtin_nontemporal_store(ov, reinterpret_cast<rank_u32x2*>(orow) + cg0 + lane);
+        }
         if (odd_tail && lane < (uint32_t)E) {
             const uint32_t wi = 2u * (cg0 + lane);
             if (wi < A.out_stride_w) orow[wi] = mine_lo & vm_lo;

@@ -156,7 +156,11 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc(const EncBlock* __restr
         const uint32_t inc = wave_scan_incl_dpp(c);
         if (lane == 63u) wtot[w] = inc;
         if (tid < A.dst_stride_w / 2u)
-            reinterpret_cast<uint2*>(A.dst + (size_t)rank * A.dst_stride_w)[tid] = make_uint2(w0, w1);
+        {
+            typedef uint32_t v2u_nt __attribute__((ext_vector_type(2)));
+            v2u_nt vv = {w0, w1};
+            __builtin_nontemporal_store(vv, reinterpret_cast<v2u_nt*>(A.dst + (size_t)rank * A.dst_stride_w) + tid);
+        }
         lds_barrier();
         uint32_t sc = row16_scan_incl(lane < W ? wtot[lane] : 0u);
         const uint32_t ones = (uint32_t)__builtin_amdgcn_readlane((int)sc, W - 1);
