@@ -154,6 +154,36 @@ def test_general_encode_bit_exact_and_decode(n_samples, n_lines, block_len, maf,
         assert np.array_equal(counts[i][:nal[i]], oref[i][1]), "allele counts line %d" % i
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_samples,n_lines,kw", [
+    (2, 40, dict(missing=True, eov=True, phase=True)),             # 4 values: one quad
+    (126, 60, dict(missing=True, eov=True, phase=True)),           # 252 values: less than a segment
+    (1026, 50, dict(missing=True, eov=True, phase=True, multi=True)),   # 2052 values: one super-group and a quad
+    (2504, 40, dict(missing=True, eov=True, phase=True, multi=True)),   # 5008: every wave's only super-group is partial
+    (16390, 12, dict(missing=True, phase=True)),                   # 32780 values: four super-groups per wave, ragged end
+    (70000, 6, dict(missing=True, eov=True, phase=True, multi=True)),
+])
+def test_quad_unpack_equals_ballot_unpack(n_samples, n_lines, kw, monkeypatch):
+    """Bi-allelic lines whose rows are 16-byte aligned take the lane-local unpack (unpack_quads, xsi_gt.hip); the file it
+    leads to is the oracle's, and byte-equal to what the ballot form (XSI_GT_NO_QUADS=1) writes for the same rows."""
+    import gpu_util as G
+    from oracle import oracle
+    rng = np.random.default_rng(n_samples * 13 + n_lines)
+    lines = _random_lines(rng, n_samples, n_lines, **kw)
+    dp = oracle.default_phased_of(lines, n_samples)
+    p = G.params(n_samples, 16, max(1, n_samples // 50), dp)
+    ref = oracle.encode_file(lines, n_samples, block_len=16, mac_thr=p.mac_threshold, default_phased=dp)
+    names = ["S%d" % i for i in range(n_samples)]
+    files = []
+    for no_quads in ("", "1"):
+        if no_quads:
+            monkeypatch.setenv("XSI_GT_NO_QUADS", "1")
+        region, offsets, res = G.encode_gt(lines, n_samples, p)
+        files.append(G.assemble_file(region, offsets, p, n_lines, G.num_variants(lines), names, 2))
+    assert files[0] == files[1], "the two unpack forms disagree"
+    assert files[0] == ref
+
+
 @pytest.mark.parametrize("n,n_lines,block_len", [(60, 240, 64), (1600, 160, 64), (2504, 96, 32), (70000, 24, 8),
                                                  (12000, 40, 8),    # rank tracking + LDS kernel for the haploid blocks
                                                  (20000, 24, 8)])   # rank tracking + global-memory kernel for them
