@@ -564,7 +564,7 @@ def close_process_group():
         pass
 
 
-def run_general_path(n_haps, sites, steps=2):
+def run_general_path(n_haps, sites, steps=4):
     """The int32 entry points an HTSLIB caller lands on (xsi_hip_encode_gt / xsi_hip_decode_gt: htslib-encoded int32 rows
     resident in HBM -> .xsi blocks -> int32 rows; gt_block.hpp:207-406, accessor_internals_new.hpp:198-384) at a BASELINE
     shape, bi-allelic phased rows made from the bench generator's bit matrix on the device.  Algorithmic bytes per SURVEY 8d:
