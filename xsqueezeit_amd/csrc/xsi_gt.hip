@@ -1270,14 +1270,6 @@ static int encode_gt_impl(xsi_hip_ctx* ctx, const xsi_encode_params* p, const in
         if (n_bin64 > 0x7FFFFFFFull) return set_error(XSI_ERR_ARG, "too many binary lines in one call");
     }
     const uint32_t n_bin = (uint32_t)n_bin64;
-    std::vector<uint32_t> parent(n_bin), nbits_bin(n_bin);
-    for (uint32_t l = 0; l < n_bcf; ++l) {
-        const uint32_t b = first_bin[l], na = h_n_allele[l] - 1u, ng = h_ngt[l];
-        for (uint32_t k = 0; k < na; ++k) {
-            parent[b + k] = l;
-            nbits_bin[b + k] = ng;
-        }
-    }
     for (uint32_t b = 0; b < n_blocks; ++b) {
         memset(&blocks[b], 0, sizeof(EncBlock));
         const uint32_t f = b * p->block_len;
@@ -1298,12 +1290,12 @@ static int encode_gt_impl(xsi_hip_ctx* ctx, const xsi_encode_params* p, const in
     WS(d_first_bin, "gt.bcf_first_bin", 4ull * n_bcf);
     WS(d_parent, "gt.bin_parent", 4ull * n_bin);
     WS(d_bin_nbits, "gt.bin_nbits", 4ull * n_bin);
+    // what the unpack kernel reads goes first; the per-binary-line arrays (read by the classification behind it) are
+    // formed and sent while it runs.  The host vectors live until this function returns, behind its last synchronisation.
     HIP_TRY(hipMemcpyAsync(d_nbits, h_ngt, 4ull * n_bcf, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_nallele, h_n_allele, 4ull * n_bcf, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_first_bin, first_bin.data(), 4ull * n_bcf, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_parent, parent.data(), 4ull * n_bin, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_bin_nbits, nbits_bin.data(), 4ull * n_bin, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // the host vectors above go out of scope with this call
+    std::vector<uint32_t> parent, nbits_bin;
 
     UnpackArgs U{};
     U.gt = d_gt;
@@ -1331,6 +1323,17 @@ static int encode_gt_impl(xsi_hip_ctx* ctx, const xsi_encode_params* p, const in
     stage_mark(ctx, XSI_ST_GT_UNPACK);
     k_unpack_gt<<<dim3(n_bcf), dim3(256), 0, s>>>(U);
     HIP_TRY(hipGetLastError());
+    parent.resize(n_bin);
+    nbits_bin.resize(n_bin);
+    for (uint32_t l = 0; l < n_bcf; ++l) {
+        const uint32_t b = first_bin[l], na = h_n_allele[l] - 1u, ng = h_ngt[l];
+        for (uint32_t k = 0; k < na; ++k) {
+            parent[b + k] = l;
+            nbits_bin[b + k] = ng;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(d_parent, parent.data(), 4ull * n_bin, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_bin_nbits, nbits_bin.data(), 4ull * n_bin, hipMemcpyHostToDevice, s));
 
     EncLines L{};
     L.planes = U.planes;
