@@ -2,7 +2,7 @@
 """Randomised parity sweep, GPU path against the CPU oracle (test infrastructure, like tests/): random shapes of the
 packed path (haplotypes 2 .. 140 000, block lengths, MAC thresholds) and of the general int32 path (multi-allelic,
 missing, end-of-vector, phase, haploid lines).  Not part of the pytest suite (minutes, not seconds):
-    gpurun -- python3 tools/stress_parity.py --seed 1 --cases 60
+    gpurun -- python3 tests/stress_parity.py --seed 1 --cases 60
 Prints one line per case and exits non-zero on the first mismatch."""
 import argparse
 import os
