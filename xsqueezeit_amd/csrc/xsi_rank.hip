@@ -301,6 +301,7 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
     const uint32_t CWP = A.yp_stride;
     uint2* row = reinterpret_cast<uint2*>(smem);
     const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    if (tab_lds != 0u) __builtin_trap();  // (the gathers address the row from 0)
     using LdsPairBig = __attribute__((address_space(3))) rank_u32x2;
 
     uint32_t r[E];
@@ -389,16 +390,16 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_big(RankArgs A) {
         const uint32_t Z_n = A.wah_z[wah_first + jn];
         uint32_t mine_lo = 0, mine_hi = 0;
         const uint32_t Zs = (uint32_t)__builtin_amdgcn_readfirstlane((int)Z);  // wave-uniform: keep it scalar
-        uint32_t tbase = tab_lds;
         static_for<0, E / G>([&](auto gcn) {
             constexpr int g0 = decltype(gcn)::value * G;
             // pins this group's gathers behind the previous group's rank updates (see k_chain_decode_rank_wg):
-            // left alone the compiler issues the gathers of all groups first and spills
-            asm volatile("" : "+s"(tbase));
+            // left alone the compiler issues the gathers of all groups first and spills.  The row sits at LDS address 0
+            // (the kernel has no other LDS; checked at its start), so the entry's offset IS the address: no add per gather.
+            asm volatile("" ::: "memory");  // (no load crosses it; asm volatile statements keep their order)
             rank_u32x2 pr[G];
             static_for<0, G>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
-                pr[e] = *reinterpret_cast<const LdsPairBig*>((uintptr_t)(((r[g0 + e] >> 2) & 0x3FFF8u) + tbase));
+                pr[e] = *reinterpret_cast<const LdsPairBig*>((uintptr_t)((r[g0 + e] >> 2) & 0x3FFF8u));
             });
             // all G gathers are issued before the first update: left to itself the scheduler interleaves them one by one
             // (ds_read, s_waitcnt lgkmcnt(0), update, ds_read, ...) in some instantiations - <64, 16> among them - and
@@ -550,7 +551,11 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
     uint32_t line = A.wah_lines[wah_first], Z = A.wah_z[wah_first];
     __syncthreads();
     using LdsPair = __attribute__((address_space(3))) rank_u32x2;
-    for (uint32_t j = 0; j < n_wah; ++j) {
+    if (tab_lds != 0u) __builtin_trap();  // (the gathers address the staged rows from LDS address 0)
+    // One line.  The half of the double buffer it reads is a compile-time constant (the line loop below runs two lines per
+    // turn), so the half's base rides in the gather's offset field: no add per gather (25.4 -> 25.2 ms at configs[2]).
+    auto line_step = [&](uint32_t j, auto half_c) {
+        constexpr uint32_t HALF = decltype(half_c)::value;
         // The prefetch is unconditional (the last line fetches its own row again): with it under a branch the
         // compiler cannot tell at the loop head whether the loads have been waited for and drains vmcnt there,
         // which also waits for the output stores of the line before.
@@ -559,19 +564,18 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
         const uint32_t line_n = A.wah_lines[wah_first + jn];
         const uint32_t Z_n = A.wah_z[wah_first + jn];
         const uint32_t Zs = (uint32_t)__builtin_amdgcn_readfirstlane((int)Z);  // wave-uniform: keep it scalar
-        uint32_t tbase = tab_lds + (j & 1u) * SLOT;
         uint32_t mine_lo = 0, mine_hi = 0;
         static_for<0, E / G>([&](auto gcn) {
             constexpr int g0 = decltype(gcn)::value * G;
             // The groups are straight-line code without a branch between them: left alone the compiler issues
             // the gathers of ALL groups first (2 E registers of pairs, E ballot masks in SGPRs) and spills.
-            // Passing the table base through an asm statement per group pins each group's gathers behind the
-            // previous group's rank updates (asm volatile statements keep their order).
-            asm volatile("" : "+s"(tbase));
+            // An asm statement no load may cross pins each group's gathers behind the previous group's rank
+            // updates (asm volatile statements keep their order).
+            asm volatile("" ::: "memory");
             rank_u32x2 pr[G];
             static_for<0, G>([&](auto ecn) {
                 constexpr int e = decltype(ecn)::value;
-                pr[e] = *reinterpret_cast<const LdsPair*>((uintptr_t)(((r[g0 + e] >> 2) & 0x3FF8u) + tbase));
+                pr[e] = *reinterpret_cast<const LdsPair*>((uintptr_t)(((r[g0 + e] >> 2) & 0x3FF8u) | (HALF * SLOT)));
             });
             // <56>: all eight gathers issued before the first update.  That instantiation came out with ONE in flight -
             // ds_read, s_waitcnt lgkmcnt(0), update, ds_read, ... (tools/isa_scan.py) -: 25.7 -> 23.2 ms at 50 000
@@ -603,7 +607,7 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
         // Park the prefetched row BEFORE this line's output stores: loads and stores share vmcnt and return in order,
         // so a wait for the row placed behind the stores would also wait for them to complete, every line.
         uint32_t* orow = A.out + (size_t)line * A.out_stride_w;
-        store_row((j + 1u) & 1u);
+        store_row(1u - HALF);
         line = (uint32_t)__builtin_amdgcn_readfirstlane((int)line_n);  // the two small loads are consumed here too
         Z = (uint32_t)__builtin_amdgcn_readfirstlane((int)Z_n);
         asm volatile("" : "+s"(line), "+s"(Z)::"memory");
@@ -619,7 +623,13 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
         // words of the output row beyond the chunks this workgroup holds (rows padded past 16*E chunks)
         for (uint32_t i = 2u * W * E + tid; i < A.out_stride_w; i += T) orow[i] = 0;
         __syncthreads();  // the next row is staged; everyone is done with this one
+    };
+    uint32_t j = 0;
+    for (; j + 1u < n_wah; j += 2u) {
+        line_step(j, std::integral_constant<uint32_t, 0u>{});
+        line_step(j + 1u, std::integral_constant<uint32_t, 1u>{});
     }
+    if (j < n_wah) line_step(j, std::integral_constant<uint32_t, 0u>{});
     if (A.ph_start && wah_first + n_wah != D.wah_first + D.n_wah) {
         static_for<0, E>([&](auto ecn) {
             constexpr int e = decltype(ecn)::value;
