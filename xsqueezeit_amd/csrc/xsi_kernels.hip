@@ -3234,10 +3234,13 @@ __global__ void __launch_bounds__(1024) k_wah_expand_wide_t(const uint8_t* __res
             const uint32_t inc = wave_scan_incl_dpp(c);
             const uint32_t pre0 = in ? (info & 0x7FFFFFFFu) + inc - c : row_ones;
             if (idx < L.yp_stride) {
+                typedef uint32_t yp_u32x4 __attribute__((ext_vector_type(4)));
+                yp_u32x4 o;
                 if (L.yp_rev)  // for k_chain_decode_rank_big<.., REV>: bits reversed, minus the ones up to the word's end
-                    dst[idx >> 1] = make_uint4(__brev(f0), 0u - (pre0 + (uint32_t)__popc(f0)), __brev(f1), 0u - (pre0 + c));
+                    o = yp_u32x4{__brev(f0), 0u - (pre0 + (uint32_t)__popc(f0)), __brev(f1), 0u - (pre0 + c)};
                 else
-                    dst[idx >> 1] = make_uint4(f0, pre0, f1, pre0 + (uint32_t)__popc(f0));
+                    o = yp_u32x4{f0, pre0, f1, pre0 + (uint32_t)__popc(f0)};
+                __builtin_nontemporal_store(o, reinterpret_cast<yp_u32x4*>(dst) + (idx >> 1));
             }
         }
         prof(6);  // B2
