@@ -2928,9 +2928,10 @@ __global__ void __launch_bounds__(64) k_wah_expand(const uint8_t* __restrict__ f
                     const uint32_t c = c0 + (uint32_t)__popc(v.z) + (uint32_t)__popc(v.w);
                     const uint32_t inc = wave_scan_incl_dpp(c);
                     const uint32_t p0 = base + inc - c;
-                    if (i < pairs) {
-                        reinterpret_cast<uint4*>(dc)[i] = v;
-                        reinterpret_cast<uint32_t*>(dp)[i] = (p0 & 0xFFFFu) | ((p0 + c0) << 16);
+                    if (i < pairs) {  // (read once by the chain's staging, a launch later: kept out of the L2's way)
+                        typedef uint32_t yc_u32x4 __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(yc_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<yc_u32x4*>(dc) + i);
+                        __builtin_nontemporal_store((p0 & 0xFFFFu) | ((p0 + c0) << 16), reinterpret_cast<uint32_t*>(dp) + i);
                     } else if (odd && i == pairs) {
                         dc[2u * i] = make_uint2(v.x, v.y);
                         dp[2u * i] = (uint16_t)p0;
