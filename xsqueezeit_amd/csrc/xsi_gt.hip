@@ -1291,7 +1291,7 @@ static int encode_gt_impl(xsi_hip_ctx* ctx, const xsi_encode_params* p, const in
     WS(d_parent, "gt.bin_parent", 4ull * n_bin);
     WS(d_bin_nbits, "gt.bin_nbits", 4ull * n_bin);
     // what the unpack kernel reads goes first; the per-binary-line arrays (read by the classification behind it) are
-    // formed and sent while it runs.  The host vectors live until this function returns, behind its last synchronisation.
+    // formed and sent while it runs; one synchronisation behind them.
     HIP_TRY(hipMemcpyAsync(d_nbits, h_ngt, 4ull * n_bcf, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_nallele, h_n_allele, 4ull * n_bcf, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_first_bin, first_bin.data(), 4ull * n_bcf, hipMemcpyHostToDevice, s));
@@ -1334,6 +1334,7 @@ static int encode_gt_impl(xsi_hip_ctx* ctx, const xsi_encode_params* p, const in
     }
     HIP_TRY(hipMemcpyAsync(d_parent, parent.data(), 4ull * n_bin, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_bin_nbits, nbits_bin.data(), 4ull * n_bin, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // every copy has left the host vectors (an error return below may destroy them early)
 
     EncLines L{};
     L.planes = U.planes;
