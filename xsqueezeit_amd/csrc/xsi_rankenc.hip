@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
     };
     using LdsV4 = __attribute__((address_space(3))) v4u;
     // every wave is done with the table: the bitmap takes its place
-    auto clear_bitmap = [&]() {
+    auto clear_bitmap_begin = [&]() {  // (the caller places the barrier behind the stores)
         lds_barrier();
         uint32_t tid_here = tid, z0, z1, z2, z3;
         asm volatile("" : "+v"(tid_here));
@@ -533,6 +533,9 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
             const uint32_t unit = (uint32_t)k * T + tid_here;
             if (unit < bmp_units) *reinterpret_cast<LdsV4*>((uintptr_t)(unit * 16u)) = v4u{z0, z1, z2, z3};
         }
+    };
+    auto clear_bitmap = [&]() {
+        clear_bitmap_begin();
         lds_barrier();
     };
     auto deposit = [&](uint64_t xm, uint32_t rr) {
@@ -556,6 +559,10 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
                 fl[1] = seq;
                 __builtin_amdgcn_raw_buffer_store_b64(fl, rs_lflags, w * 8u, (par * S + member) * 128u, 0);
             }
+            // My workgroup's part of the hand-off first: its waves are done with the table (barrier), the bitmap that takes
+            // the table's place is cleared - while the other members are still publishing (the wait below used to stand
+            // in front of this; the clear's second barrier stands behind the first pieces' loads now).
+            clear_bitmap_begin();
             const uint32_t ml = lane < S ? lane : 0u;
             uint32_t spins = 0;
             t_start = 0;
@@ -590,7 +597,7 @@ __global__ void __launch_bounds__(1024) k_chain_rank_enc_multi(const EncBlock* _
             load_piece(k, 0u);
             __builtin_amdgcn_sched_barrier(0);
         }
-        clear_bitmap();
+        lds_barrier();  // every wave's part of the clear has landed
         prof(8);  // bitmap cleared
         // ---- every list, every rank
         for (uint32_t i0 = 0; i0 < longest; i0 += 256u) {
