@@ -1115,9 +1115,9 @@ static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* b
         if (n > PROF_CAP) n = PROF_CAP;
         std::vector<uint64_t> rec(n);
         if (e == hipSuccess && n) e = hipMemcpy(rec.data(), prof_buf, 8ull * n, hipMemcpyDeviceToHost);
-        static const char* nm[12] = {"gathers+appends+publish", "gathers alone", "wait lists", "table entries written",
+        static const char* nm[12] = {"gathers+appends+publish", "gathers alone", "barrier + clear issued + wait lists", "table entries written",
                                      "bitmap stored + flagged", "waits (bitmap form)", "slice / table copy", "start",
-                                     "barrier + clear", "lists applied", "row read + wave scans", "clear + deposits"};
+                                     "clear landed (barrier)", "lists applied", "row read + wave scans", "clear + deposits"};
         uint64_t sum[12] = {0}, cntv[12] = {0};
         for (uint32_t i = 1; i < n; ++i) {
             const uint32_t tag = (uint32_t)(rec[i] >> 56) % 12u;
