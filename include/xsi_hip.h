@@ -69,7 +69,9 @@ uint32_t xsi_hip_ctx_reencode_ranges(const xsi_hip_ctx* ctx);
 /* Bytes of per-line device workspace one block-level call may hold.  A job that needs more (e.g. 153 blocks
  * of 500 000 haplotypes) is run as several batches of whole blocks inside the call; the bytes written are
  * those of a single pass, since blocks are independent.  0 (default) = half of the HBM that is free at the call plus what the context already holds and will reuse (never
- * more than the one buffer that takes the per-line rows can get); the environment variable XSI_WS_BUDGET_MB overrides the default. */
+ * more than the one buffer that takes the per-line rows can get); the environment variable XSI_WS_BUDGET_MB overrides the default -
+ * like every XSI_* variable named in this header it is read ONLY when the process opted in with XSI_ENABLE_TUNING_ENV=1
+ * (csrc/xsi_common.hpp); without that gate a stray XSI_* variable in a caller's environment changes nothing. */
 int xsi_hip_ctx_set_workspace_budget(xsi_hip_ctx* ctx, uint64_t bytes);
 
 /* Per-stage device timing with HIP events recorded on the context's stream (used by bench.py for
@@ -127,7 +129,7 @@ int xsi_hip_encode_packed(xsi_hip_ctx* ctx, const xsi_encode_params* p, const vo
  * bits of row l, in HBM): the pass over the matrix that only counts (GtBlock::scan_genotypes' allele histogram,
  * gt_block.hpp:207-269; 16.4 GB of reads at 64 976 haplotypes x 2 M sites) is then not made again.  The counts decide
  * WAH against sparse and the sparse side (gt_block.hpp:298-327): wrong counts give a wrong file, not an error -
- * XSI_CHECK_ROW_COUNTS=1 in the environment recounts and returns XSI_ERR_ARG on a difference.  d_row_counts == NULL is
+ * XSI_CHECK_ROW_COUNTS=1 in the environment (effective only under XSI_ENABLE_TUNING_ENV=1) recounts and returns XSI_ERR_ARG on a difference.  d_row_counts == NULL is
  * xsi_hip_encode_packed.  xsi_hip_count_packed_rows is that counting pass by itself (stream-ordered on the context),
  * for a producer that has no cheaper way; xsi_writer_* counts while it packs (one popcount per mask).
  */
@@ -387,7 +389,7 @@ int64_t xsi_accessor_fill_genotype_array(xsi_accessor* a, int32_t* h_gt, uint64_
  * LIFETIME: the array must stay allocated until xsi_accessor_unregister_array, the next xsi_accessor_register_array,
  * xsi_accessor_free_array of it, or xsi_accessor_close returns.  One registered array per accessor.
  * XSI_ACCESSOR_NO_REGISTER=1 makes the registration a no-op (measurement); XSI_ACCESSOR_NO_ZEROCOPY=1 keeps it but
- * fills the array with the copy engine. */
+ * fills the array with the copy engine (both effective only under XSI_ENABLE_TUNING_ENV=1). */
 int xsi_accessor_alloc_array(xsi_accessor* a, uint64_t n_values, int32_t** h_gt);
 int xsi_accessor_free_array(xsi_accessor* a, int32_t* h_gt);
 int xsi_accessor_register_array(xsi_accessor* a, int32_t* h_gt, uint64_t n_values);
@@ -411,7 +413,7 @@ int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint
 int64_t xsi_accessor_genotypes_view(xsi_accessor* a, uint32_t n_alleles, uint64_t position, const int32_t** h_gt);
 /* Decoded blocks stay resident in HBM (LRU) so that backward and random seeks do not replay a block
  * prefix the way accessor_internals_new.hpp:154-196 does.  Budget in bytes (default: half of the free
- * HBM at open, at most 64 GiB; XSI_ACCESSOR_CACHE_MB overrides); 0 keeps only the current block. */
+ * HBM at open, at most 64 GiB; XSI_ACCESSOR_CACHE_MB overrides it under XSI_ENABLE_TUNING_ENV=1); 0 keeps only the current block. */
 int xsi_accessor_set_cache_bytes(xsi_accessor* a, uint64_t bytes);
 /* Any of the outputs may be NULL. */
 int xsi_accessor_cache_stats(const xsi_accessor* a, uint64_t* blocks, uint64_t* bytes, uint64_t* hits,
@@ -421,7 +423,8 @@ int xsi_accessor_cache_stats(const xsi_accessor* a, uint64_t* blocks, uint64_t* 
  * (accessor_internals_new.hpp:154-196) - leaving the chain's ranks parked in HBM; a later query further into the block
  * continues from there (in steps that grow by half of what is decoded, so a scan through a cold block is a dozen
  * continuations).  prefix_decodes: first touches that stopped before the block's end; extensions: continuations since
- * open.  XSI_ACCESSOR_FULL_DECODE=1 decodes whole blocks on first touch (measurement, as before round 4). */
+ * open.  XSI_ACCESSOR_FULL_DECODE=1 (under XSI_ENABLE_TUNING_ENV=1) decodes whole blocks on first touch (measurement, as
+ * before round 4). */
 int xsi_accessor_prefix_stats(const xsi_accessor* a, uint64_t* prefix_decodes, uint64_t* extensions);
 /* Sample selection on decode (NewDecompressor::fill_selected_genotypes, include/gt_decompressor_new.hpp:209-238):
  * after set_sample_subset(idx, n) (indices into the file's sample list, any order, repeats allowed; n = 0

@@ -685,8 +685,10 @@ int xsi_hip_decode_packed(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_le
                 for (uint64_t b = 0; b < n_blocks64; ++b) n_wah[b] = plan.blocks_h[b].n_wah;
             }
             const uint32_t yps = (uint32_t)((((N64 + 31u) / 32u) + 1u) & ~1ull);
-            const uint64_t wgs = rank_decode_big_wgs_per_block((uint32_t)N64, yps);
-            const uint64_t quantum = wgs > 1 && 256u / wgs > 1u ? 256u / wgs : 1u;
+            // (the geometry of a launch that fills the chip - the same selection the launcher makes - on this device's CUs)
+            const uint64_t cus = rank_decode_cus();
+            const uint64_t wgs = rank_decode_big_wgs_per_block((uint32_t)N64, yps, (uint32_t)(n_blocks64 < cus ? n_blocks64 : cus));
+            const uint64_t quantum = wgs > 1 && cus / wgs > 1u ? cus / wgs : 1u;
             uint64_t b0 = 0;
             while (b0 < n_blocks64) {
                 uint64_t need = 0, nb = 0, best = 0;

@@ -64,6 +64,24 @@ struct xsi_encode_params;
 struct xsi_encode_result;
 
 namespace xsi {
+// Waits for the stream on EVERY exit of the scope it stands in until release() is called: for the stretches of a call in
+// which asynchronous copies still read host memory the call does not own beyond its return (the caller's arrays, local
+// vectors), or kernels still store into the caller's registered array.  An early error return there would otherwise hand
+// that memory back while the GPU is using it.
+struct StreamSyncGuard {
+    hipStream_t s;
+    bool armed = true;
+    explicit StreamSyncGuard(hipStream_t stream) : s(stream) {}
+    StreamSyncGuard(const StreamSyncGuard&) = delete;
+    StreamSyncGuard& operator=(const StreamSyncGuard&) = delete;
+    void release() { armed = false; }
+    ~StreamSyncGuard() {
+        if (armed) (void)hipStreamSynchronize(s);
+    }
+};
+}  // namespace xsi
+
+namespace xsi {
 
 int set_error(int code, const char* fmt, ...);
 // mark the start of `stage` on the stream (no-op unless timing is on); stage -1 ends the last one

@@ -29,7 +29,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // (optional symbol)
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // (required: the recovery of a partly posted group needs it)
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -56,7 +56,7 @@ const RcclApi& rccl() {
         XSI_SYM(GroupEnd, "ncclGroupEnd");
         XSI_SYM(GetErrorString, "ncclGetErrorString");
 #undef XSI_SYM
-        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.Send && a.Recv && a.GroupStart &&
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.CommAbort && a.AllGather && a.Send && a.Recv && a.GroupStart &&
                a.GroupEnd && a.GetErrorString;
         return a;
     }();
@@ -89,6 +89,7 @@ struct xsi_hip_comm {
     hipStream_t cs = nullptr;    // the exchange runs here, ordered behind the context's stream by ev_in, so that
     hipEvent_t ev_in = nullptr, ev_done = nullptr;  // work the caller enqueues next (the decode) overlaps with it
     bool broken = false;         // a group was launched with only part of its posts (see gather_block_streams_round): aborted, unusable
+    bool abort_failed = false;   // ... and ncclCommAbort itself failed: the operations it left on `cs` never complete
     uint64_t* d_meta = nullptr;  // [world + 1][4]: every rank's {bytes, blocks, region capacity, offsets capacity}; the last is this rank's (send buffer)
 };
 
@@ -150,10 +151,10 @@ int xsi_hip_comm_create(xsi_hip_comm** out, xsi_hip_ctx* ctx, int world, int ran
 
 void xsi_hip_comm_destroy(xsi_hip_comm* c) {
     if (!c) return;
-    if (c->cs) (void)hipStreamSynchronize(c->cs);
+    if (c->cs && !c->abort_failed) (void)hipStreamSynchronize(c->cs);  // (operations of a communicator that could not be aborted never finish)
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
-    if (c->cs) (void)hipStreamDestroy(c->cs);
+    if (c->cs && !c->abort_failed) (void)hipStreamDestroy(c->cs);  // (destroying a stream waits for its work: leaked in that case)
     if (c->d_meta) (void)hipFree(c->d_meta);
     if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
     delete c;
@@ -263,9 +264,12 @@ int xsi_hip_gather_block_streams_round(xsi_hip_comm* c, const void* d_region, ui
         // communicator: it is aborted, so that the operations already launched do not wait for ever, and every
         // later call on it fails at once.  (A first post that is refused leaves nothing behind: the communicator stays usable.)
         if (posted > 0) {
-            if (R.CommAbort) (void)R.CommAbort(c->comm);
+            // (ncclCommAbort is part of rccl().ok: a library without it never gets this far)
+            const ncclResult_t ar = R.CommAbort(c->comm);
             c->comm = nullptr;
             c->broken = true;
+            // an abort that itself failed leaves the launched operations queued on c->cs: comm_destroy must not wait for them
+            c->abort_failed = ar != ncclSuccess;
         }
         return set_error(XSI_ERR_HIP, "gather_block_streams: %s: %s%s", what, R.GetErrorString(first),
                          posted > 0 ? " (communicator aborted: part of the group had been posted)" : "");

@@ -1319,11 +1319,10 @@ int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint
     std::vector<uint32_t> order;
     int64_t total = 0;
     // an error inside a chunk leaves compose kernels of its earlier groups in flight, storing into the caller's array
-    // (direct path): they are waited for before the call returns
-    auto bail = [&](int rc) {
-        (void)hipStreamSynchronize(s);
-        return rc;
-    };
+    // (direct path): they are waited for before the call returns, whichever exit it takes - the `return rc` paths and the
+    // HIP_TRY ones alike: the guard synchronises the stream on every exit but the last
+    StreamSyncGuard in_flight(s);
+    auto bail = [&](int rc) { return rc; };
     for (uint64_t c0 = 0; c0 < n; c0 += chunk_cap) {
         const uint32_t m = (uint32_t)(n - c0 < chunk_cap ? n - c0 : chunk_cap);
         // queries of a chunk grouped by block (stable): one compose launch per block touched
@@ -1383,6 +1382,7 @@ int64_t xsi_accessor_get_genotypes_batch(xsi_accessor* a, uint64_t n, const uint
             total += ng[i];
         }
     }
+    in_flight.release();  // the last chunk's synchronisation stands above
     return total;
 }
 

@@ -255,7 +255,7 @@ static int write_variant_bcf(const char* in_bcf, const std::string& var_path, co
     int rc = XSI_OK;
     bcf_hdr_t* hdr = nullptr;
     if (bcf_hdr_set_samples(sr->readers[0].header, nullptr, 0) < 0) {
-        fprintf(stderr, "Failed to set pseudo sample in header for file %s\n", in_bcf);
+        fprintf(stderr, "xsi_compress_bcf: %s: could not drop the sample columns from the header copy\n", in_bcf);
         rc = XSI_ERR_FORMAT;
     }
     if (rc == XSI_OK && !(hdr = bcf_hdr_dup(sr->readers[0].header))) rc = XSI_ERR_IO;
@@ -265,10 +265,10 @@ static int write_variant_bcf(const char* in_bcf, const std::string& var_path, co
             bcf_hdr_append(hdr, (std::string("##XSI=") + base_name(out_xsi)).c_str()) < 0)
             rc = XSI_ERR_FORMAT;
         else if (bcf_hdr_sync(hdr) < 0)
-            fprintf(stderr, "bcf_hdr_sync() failed ... oh well\n");
+            fprintf(stderr, "xsi_compress_bcf: header of %s did not re-synchronise after the BM additions (continuing)\n", var_path.c_str());
     }
     if (rc == XSI_OK && bcf_hdr_write(fp, hdr) < 0) {
-        fprintf(stderr, "Failed to write header to file %s\n", var_path.c_str());
+        fprintf(stderr, "xsi_compress_bcf: %s: header write refused by htslib\n", var_path.c_str());
         rc = XSI_ERR_IO;
     }
     xsi_bm_state bm;

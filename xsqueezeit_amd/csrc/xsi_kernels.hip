@@ -1419,11 +1419,12 @@ hipError_t launch_chain_encode(hipStream_t s, const EncBlock* blocks, uint32_t n
     bool rank_done = false;
     if (multi_refused) *multi_refused = false;
     if (chain_rank_enc_multi_supported(L)) {
-        hipError_t e = launch_rank_encode_multi(s, blocks, n_blocks, L);
-        if (e == hipErrorInvalidValue) {
+        bool refused = false;
+        hipError_t e = launch_rank_encode_multi(s, blocks, n_blocks, L, &refused);
+        if (refused) {
             // the device (or the CU mask of this process) cannot hold a whole group of workgroups:
-            // k_chain_stream below takes the blocks (the caller counts it as a fallback)
-            (void)hipGetLastError();
+            // k_chain_stream below takes the blocks (the caller counts it as a fallback).  Only the launcher's own
+            // pre-launch checks say so; a hipErrorInvalidValue from the runtime is an error like any other
             if (multi_refused) *multi_refused = true;
         } else {
             if (e != hipSuccess || !any_haploid) return e;

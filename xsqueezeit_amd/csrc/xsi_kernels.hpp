@@ -178,7 +178,8 @@ uint64_t rank_decode_state_words(uint32_t N, uint32_t n_blocks);
 hipError_t launch_rank_decode_phase(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                                     uint32_t* out_rows, uint32_t out_stride_w, const uint32_t* ph_start,
                                     const uint32_t* ph_cnt, uint32_t* state, uint32_t active_blocks = 0);
-uint32_t rank_decode_big_wgs_per_block(uint32_t N, uint32_t yp_stride);
+uint32_t rank_decode_big_wgs_per_block(uint32_t N, uint32_t yp_stride, uint32_t active = 0);
+uint32_t rank_decode_cus();  // CUs of the current device
 // element-major decode chain (xsi_rank.hip): all blocks without fully haploid lines
 hipError_t launch_rank_decode(hipStream_t s, const DecBlock* blocks, uint32_t n_blocks, const DecLines& L,
                               uint32_t* out_rows, uint32_t out_stride_w);
@@ -210,7 +211,9 @@ constexpr uint32_t CHAIN_ITEM_BEGIN_WORDS = 132u;  // the schedule's per-group b
 constexpr uint64_t CHAIN_PARK_BYTES = (uint64_t)CHAIN_MAX_WGS * 64u * 1024u * 4u;  // per workgroup 64 x 1024 ranks
 constexpr uint64_t CHAIN_BMP_BYTES = (uint64_t)CHAIN_MAX_WGS * 8u * 8192u;  // per workgroup a bitmap of up to 8 slices
 bool chain_rank_enc_multi_supported(const EncLines& L);
-hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L);
+// *refused = true (and hipSuccess, nothing enqueued): the device or CU mask cannot hold one group of workgroups, or the grid
+// would exceed the exchange buffers - the caller takes k_chain_stream.  Every other error is a real one and is returned.
+hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L, bool* refused);
 
 // ---- synthetic data ----
 hipError_t launch_synth_packed(hipStream_t s, uint64_t seed, uint64_t first_line, uint64_t n_lines, uint32_t n_haps,

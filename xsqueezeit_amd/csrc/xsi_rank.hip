@@ -728,8 +728,49 @@ static hipError_t launch_rank(hipStream_t s, const RankGeom& g, uint32_t n_block
 }
 
 
-// Long-row decode: RP by the row length, E by how many workgroups it takes to fill the chip
-// (and by what still fits 128 VGPRs next to the RP prefetch registers).
+// CUs of the current device (one chain workgroup per CU); 256 when the attribute cannot be read
+uint32_t rank_decode_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        return (uint32_t)cus;
+    return 256u;
+}
+
+static uint32_t rank_big_rp(uint32_t yp_stride) { return yp_stride <= 8u * 1024u ? 8u : (yp_stride <= 16u * 1024u ? 16u : 20u); }
+
+// Chunks per wave of the long-row kernel for a launch with `active` blocks on a chip of `cus` CUs - ONE selection, used by
+// the launcher and by rank_decode_big_wgs_per_block (the batch quantum of xsi_hip_decode_packed), so that the quantum and
+// the geometry actually launched agree.  Every workgroup of a block stages the whole rank-select row of each
+// line: the fewer workgroups per block (the more chunks per wave) the less of that, as long as the launch still fills the
+// chip.  Cost = rounds of the chip the launch takes x what a round costs: a workgroup with half the chunks per wave does a
+// little more than half the work (it stages the same row: 0.59 of the time at 500 000 haplotypes,
+// profiles/r05_config3_kernel_stats.csv) - 25 blocks: one round of <64> at 25 / 32 of the chip (1.0) beats two of <32>
+// (1.18); 12 blocks: <32> in one round.
+static uint32_t rank_big_pick_e(uint32_t N, uint32_t yp_stride, uint32_t active, uint32_t cus) {
+    const uint32_t nch = (N + 63u) / 64u;
+    const uint32_t RP = rank_big_rp(yp_stride);
+    const uint32_t e_max = RP == 20u ? 16u : 64u;  // <64, 16> fits since the row travels as 16-byte pieces (it spilled 60 VGPRs)
+    if (const char* ev = tuning_env("XSI_DEC_BIG_E")) {
+        const uint32_t v = (uint32_t)atoi(ev);
+        if ((v == 8u || v == 16u || v == 32u || v == 64u) && v <= e_max) return v;
+    }
+    if (!cus) cus = 256u;
+    if (!active) active = cus;  // "enough blocks to fill the chip"
+    uint32_t E = 8;
+    double best_cost = 1e30;
+    for (uint32_t e : {64u, 32u, 16u, 8u}) {
+        if (e > e_max) continue;
+        const uint64_t splits = (nch + 16u * e - 1u) / (16u * e);
+        const double rounds = (double)(((uint64_t)active * splits + cus - 1u) / cus);
+        const double cost = rounds * (e == 64u ? 1.0 : e == 32u ? 0.59 : e == 16u ? 0.36 : 0.23);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            E = e;
+        }
+    }
+    return E;
+}
+
 // `active`: blocks that have lines in this launch (a batch's launches all pass the same figure - the parked ranks' layout
 // depends on the geometry chosen from it)
 static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A, uint32_t active = 0) {
@@ -737,29 +778,8 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A, 
     const uint32_t nch = (A.N + 63u) / 64u;
     const uint32_t lds = ((A.yp_stride / 2u + 1023u) / 1024u) * 16384u;  // whole 1024-unit pieces (see the kernel's store_row)
     auto splits_of = [&](uint32_t e) { return (nch + 16u * e - 1u) / (16u * e); };
-    static const int env_e = [] {
-        const char* e = tuning_env("XSI_DEC_BIG_E");
-        return e ? atoi(e) : 0;
-    }();
-    const uint32_t RP = A.yp_stride <= 8u * 1024u ? 8u : (A.yp_stride <= 16u * 1024u ? 16u : 20u);
-    // every workgroup of a block stages the whole rank-select row of each line: the fewer workgroups per block
-    // (the more chunks per wave) the less of that, as long as the launch still fills the chip
-    const uint32_t e_max = RP == 20u ? 16u : 64u;  // <64, 16> fits since the row travels as 16-byte pieces (it spilled 60 VGPRs)
-    // rounds of the chip the launch takes x what a round costs: a workgroup with half the chunks per wave does a little more
-    // than half the work (it stages the same row: 0.59 of the time at 500 000 haplotypes, profiles/r05_config3_kernel_stats.csv)
-    // - 25 blocks: one round of <64> at 25 / 32 of the chip (1.0) beats two of <32> (1.18); 12 blocks: <32> in one round
-    uint32_t E = 8;
-    double best_cost = 1e30;
-    for (uint32_t e : {64u, 32u, 16u, 8u}) {
-        if (e > e_max) continue;
-        const double rounds = (double)(((uint64_t)active * splits_of(e) + 255u) / 256u);
-        const double cost = rounds * (e == 64u ? 1.0 : e == 32u ? 0.59 : e == 16u ? 0.36 : 0.23);
-        if (cost < best_cost - 1e-9) {
-            best_cost = cost;
-            E = e;
-        }
-    }
-    if ((env_e == 8 || env_e == 16 || env_e == 32 || env_e == 64) && (uint32_t)env_e <= e_max) E = (uint32_t)env_e;
+    const uint32_t RP = rank_big_rp(A.yp_stride);
+    const uint32_t E = rank_big_pick_e(A.N, A.yp_stride, active, rank_decode_cus());
 #define XSI_BIG_CASE(EE, RR)                                                                                 \
     if (E == EE && RP == RR && A.yp_rev) {                                                                   \
         auto kern = &k_chain_decode_rank_big<EE, RR, false, true>;                                           \
@@ -807,18 +827,13 @@ static hipError_t launch_rank_big(hipStream_t s, uint32_t n_blocks, RankArgs A, 
     return hipErrorInvalidValue;
 }
 
-// workgroups per block of the long-row kernel at its usual geometry (enough blocks to fill the chip): what a caller
-// that cuts a job into batches of blocks rounds the batches to, so that the last round of a launch is a full one
-uint32_t rank_decode_big_wgs_per_block(uint32_t N, uint32_t yp_stride) {
+// workgroups per block of the long-row kernel for a launch with `active` blocks (0: enough blocks to fill the chip): what a
+// caller that cuts a job into batches of blocks rounds the batches to, so that the last round of a launch is a full one
+uint32_t rank_decode_big_wgs_per_block(uint32_t N, uint32_t yp_stride, uint32_t active) {
     if (N <= 65536u) return 1u;
     const uint32_t nch = (N + 63u) / 64u;
-    const uint32_t RP = yp_stride <= 8u * 1024u ? 8u : (yp_stride <= 16u * 1024u ? 16u : 20u);
-    uint32_t e_max = RP == 20u ? 16u : 64u;
-    if (const char* e = tuning_env("XSI_DEC_BIG_E")) {
-        const uint32_t v = (uint32_t)atoi(e);
-        if ((v == 8u || v == 16u || v == 32u || v == 64u) && v <= e_max) e_max = v;
-    }
-    return (nch + 16u * e_max - 1u) / (16u * e_max);
+    const uint32_t e = rank_big_pick_e(N, yp_stride, active, rank_decode_cus());
+    return (nch + 16u * e - 1u) / (16u * e);
 }
 
 // one workgroup per block: batches with about as many blocks as CUs, rows that fit a 16 KiB LDS slot

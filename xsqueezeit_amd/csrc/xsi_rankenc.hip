@@ -1053,7 +1053,10 @@ bool chain_rank_enc_multi_supported(const EncLines& L) {
            (L.y_stride64 % 2u) == 0u;
 }
 
-static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L, int cus) {
+static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L, int cus, bool* refused) {
+    // `refused` is raised by the checks that stand in FRONT of the first enqueue only: an error of
+    // hipFuncSetAttribute or of the launch itself is a bug or a broken device and travels up as what it is
+    *refused = false;
     RankEncMultiArgs A{};
     A.wah_lines = L.wah_lines;
     A.src = L.planes;
@@ -1065,9 +1068,15 @@ static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* b
     A.n_blocks = n_blocks;
     A.S = (L.N + 65535u) / 65536u;
     A.gpx = (uint32_t)cus / 8u / A.S;
-    if (A.gpx < 1u) return hipErrorInvalidValue;
+    if (A.gpx < 1u) {
+        *refused = true;
+        return hipSuccess;
+    }
     while (A.gpx > 1u && 8u * (A.gpx - 1u) >= n_blocks) --A.gpx;  // no more groups than blocks need
-    if (8u * A.gpx * A.S > CHAIN_MAX_WGS) return hipErrorInvalidValue;
+    if (8u * A.gpx * A.S > CHAIN_MAX_WGS || 8u * A.gpx + 1u > CHAIN_ITEM_BEGIN_WORDS || !L.chain_items || !L.chain_park) {
+        *refused = true;
+        return hipSuccess;
+    }
     static_assert(CHAIN_SLICEFLAG_WORDS >= (CHAIN_MAX_WGS / 2u) * 32u, "16 flags of 8 bytes per group");
     const char* thr = tuning_env("XSI_MULTI_LIST_THR");
     A.thr = thr ? (uint32_t)atoi(thr) : 49152u;
@@ -1092,7 +1101,6 @@ static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* b
     A.items = reinterpret_cast<const MultiItem*>(L.chain_items + CHAIN_ITEM_BEGIN_WORDS);
     A.park = L.chain_park;
     A.park_flags = L.chain_sync + 16u;
-    if (n_groups + 1u > CHAIN_ITEM_BEGIN_WORDS || !L.chain_items || !L.chain_park) return hipErrorInvalidValue;
     k_multi_schedule<<<dim3(1), dim3(64), 0, s>>>(blocks, n_blocks, n_groups, L.chain_items, reinterpret_cast<MultiItem*>(L.chain_items + CHAIN_ITEM_BEGIN_WORDS),
                                                   tuning_env("XSI_MULTI_ROUND_ROBIN") ? 1u : 0u);
     e = hipGetLastError();
@@ -1131,14 +1139,15 @@ static hipError_t launch_rank_encode_multi_grid(hipStream_t s, const EncBlock* b
     return e;
 }
 
-hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L) {
+hipError_t launch_rank_encode_multi(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L, bool* refused) {
+    *refused = false;
     if (!n_blocks) return hipSuccess;
     int dev = 0, cus = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
-    return launch_rank_encode_multi_grid(s, blocks, n_blocks, L, cus);
+    return launch_rank_encode_multi_grid(s, blocks, n_blocks, L, cus, refused);
 }
 
 }  // namespace xsi
