@@ -190,3 +190,15 @@ def test_bench_attaches_the_north_star_job_on_the_multi_rank_path():
     assert sub["scaling"] == "strong" and sub["roundtrip_equal"] and sub["gather_ms"] > 0
     assert sub["config"]["haps"] == 500000 and sub["gathered"]["own_part_equals_encode_output"]
     assert sub["config"]["memory_plan_bytes"]["fits"]
+    # ... and a second time as flat scalars at the END of the line: a record that keeps only the tail of
+    # stdout, or only the top-level scalars of the line, still carries the job's result
+    ns = out["north_star"]
+    assert list(out)[-len(ns) - 1] == "north_star" and lines[0].rstrip().endswith("}")
+    assert ns["value"] == sub["value"] and ns["ms_per_step"] == sub["ms_per_step"] and ns["gather_ms"] == sub["gather_ms"]
+    assert ns["n_gpus"] == 1 and ns["scaling"] == "strong" and ns["roundtrip_equal"] is True and ns["error"] is None
+    assert ns["frac"] == sub["roofline"]["frac"] and ns["bit_exact_vs_oracle"] == sub["bit_exact_vs_oracle"]
+    assert ns["max_rank_ms"] >= ns["min_rank_ms"] > 0
+    for k, v in ns.items():
+        assert out["north_star_" + k] == v and not isinstance(v, (dict, list))
+    tail = lines[0][-1500:]  # what a cut record keeps
+    assert '"north_star_value"' in tail and '"north_star_gather_ms"' in tail and '"north_star_roundtrip_equal"' in tail

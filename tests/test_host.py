@@ -510,3 +510,23 @@ def test_generated_wah_classification_is_in_sync():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_wah_classify.py"), "--check"])
     assert r.returncode == 0
+
+
+def test_north_star_summary_is_flat_scalars():
+    """The N > 1 line repeats the north_star job as flat scalars: the summary is made of the sub-run's
+    own fields, every value a scalar, an error text carried when the sub-run failed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("xsi_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    o3 = {"metric": "GT cells/sec", "value": 1.0e13, "unit": "GT cells/s", "ms_per_step": 500.0, "gather_ms": 12.5,
+          "ms_per_step_per_rank": [480.0, 500.0, 470.0, 490.0], "roundtrip_equal": True, "bit_exact_vs_oracle": True,
+          "config": {"workload": "BASELINE configs[3]", "haps": 500000},
+          "roofline": {"frac": 0.05, "chain_encode_ms": 240.0, "chain_decode_ms": 139.0, "stage_ms": {"x": 1}}}
+    ns = bench.north_star_summary(o3, 4)
+    assert ns["value"] == 1.0e13 and ns["ms_per_step"] == 500.0 and ns["frac"] == 0.05 and ns["gather_ms"] == 12.5
+    assert ns["n_gpus"] == 4 and ns["scaling"] == "strong" and ns["max_rank_ms"] == 500.0 and ns["min_rank_ms"] == 470.0
+    assert ns["roundtrip_equal"] is True and ns["bit_exact_vs_oracle"] is True and ns["error"] is None
+    assert all(not isinstance(v, (dict, list)) for v in ns.values())
+    bad = bench.north_star_summary({"error": "RuntimeError: x"}, 8)
+    assert bad["error"] == "RuntimeError: x" and bad["value"] is None and bad["max_rank_ms"] is None and bad["n_gpus"] == 8
