@@ -64,6 +64,13 @@ uint64_t xsi_hip_ctx_workspace_bytes(const xsi_hip_ctx* ctx);
  * batch was run a second time, or it could not be launched at all (a device too small for one group).
  * The bytes written are the same either way (pbwt_sort, include/internal_gt_record.hpp:32-59). */
 uint64_t xsi_hip_ctx_chain_fallbacks(const xsi_hip_ctx* ctx);
+/* Optional side output of the encode entry points (xsi_hip_encode_packed[_counted], xsi_hip_encode_gt, xsi_hip_reencode):
+ * d_sizes[b] (in HBM, stream-ordered like the call's other outputs) = bytes of block b of the call BEFORE its pad to 4 -
+ * the block as the reference streams it into its zstd layer (compress_and_write, interfaces.hpp:291-314), which
+ * xsi_encode_result.last_block_bytes gives for the last block only.  With it a caller (xsi_writer_* does) can wrap every
+ * block of a multi-block call in its own zstd frame.  capacity_blocks: blocks d_sizes can hold - a call with more fails with
+ * XSI_ERR_CAPACITY before it writes anything; d_sizes == NULL switches the output off.  The setting stays until changed. */
+int xsi_hip_ctx_set_block_sizes_out(xsi_hip_ctx* ctx, uint32_t* d_sizes, uint64_t capacity_blocks);
 uint32_t xsi_hip_ctx_reencode_ranges(const xsi_hip_ctx* ctx);
 
 /* Bytes of per-line device workspace one block-level call may hold.  A job that needs more (e.g. 153 blocks

@@ -546,6 +546,91 @@ def test_zstd_layer_roundtrip(tmp_path):
 
 
 @pytest.mark.gpu
+def test_zstd_writer_pool_equals_one_thread_writer_and_oracle_blocks(tmp_path, monkeypatch):
+    """--zstd at block-parallel speed: batches of several blocks, every block compressed by one of a pool
+    of host threads, frames written in block order.  ZSTD_compress is one-shot per block and deterministic, so the file
+    must be, byte for byte, (a) the file of the one-thread / one-block-per-batch writer of rounds 1 - 5 and (b) the
+    oracle's plain blocks, each cut at its unpadded length and wrapped by this box's libzstd at the same level
+    (compress_and_write, interfaces.hpp:291-314)."""
+    import struct
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    try:
+        Z = ctypes.CDLL("libzstd.so.1")
+    except OSError:
+        pytest.skip("no libzstd.so.1 on this box")
+    Z.ZSTD_compress.restype = ctypes.c_size_t
+    Z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    rng = np.random.default_rng(4242)
+    n, block_len, n_blocks = 400, 48, 37
+    n_lines = block_len * n_blocks - 11  # a short last block
+    lines = _random_lines(rng, n, n_lines, multi=True, missing=True, eov=True)
+    dp = oracle.default_phased_of(lines, n)
+    names = ["s%d" % i for i in range(n)]
+    plain = oracle.encode_file(lines, n, block_len=block_len, mac_thr=3, default_phased=dp, sample_names=names)
+
+    def write(tag, env):
+        for k in ("XSI_WRITER_ZSTD_THREADS", "XSI_WRITER_BATCH_BLOCKS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        path = str(tmp_path / ("z_%s.xsi" % tag)).encode()
+        p = G.params(n, block_len, 3, dp)
+        p.zstd_level = 7
+        w = ctypes.c_void_p()
+        arr = (ctypes.c_char_p * n)(*[s.encode() for s in names])
+        binding.check(L.xsi_writer_open(ctypes.byref(w), G.ctx().handle, path, ctypes.byref(p), arr))
+        for gt, na in lines:
+            gt = np.ascontiguousarray(gt, dtype=np.int32)
+            binding.check(L.xsi_writer_append(w, gt.ctypes.data, gt.size, na))
+        binding.check(L.xsi_writer_finalize(w, 0))
+        L.xsi_writer_close(w)
+        return open(path, "rb").read()
+
+    pooled = write("pool", {})                                                            # default pool, default batches
+    one = write("one", {"XSI_WRITER_ZSTD_THREADS": "1", "XSI_WRITER_BATCH_BLOCKS": "1"})  # rounds 1 - 5
+    odd = write("odd", {"XSI_WRITER_ZSTD_THREADS": "3", "XSI_WRITER_BATCH_BLOCKS": "7"})  # batches that do not divide the file
+    assert pooled == one, "pooled writer differs from the one-thread writer"
+    assert odd == one
+    # (b) the oracle's blocks wrapped by libzstd
+    zio, zso = struct.unpack_from("<QQ", pooled, 72)
+    pio, pso = struct.unpack_from("<QQ", plain, 72)
+    zoffs = np.frombuffer(pooled, "<u8", (zso - zio) // 8, zio)
+    poffs = list(np.frombuffer(plain, "<u8", (pso - pio) // 8, pio)) + [pio]
+    assert len(zoffs) == n_blocks == len(poffs) - 1
+    pos = 256
+    for b in range(n_blocks):
+        assert int(zoffs[b]) == pos, "block %d starts where the one before ended (padded to 4)" % b
+        csize, usize = struct.unpack_from("<QQ", pooled, pos)
+        padded = int(poffs[b + 1]) - int(poffs[b]) if b + 1 < n_blocks else None
+        if padded is not None:
+            assert 0 <= padded - usize < 4 and plain[int(poffs[b]) + usize:int(poffs[b]) + padded] == b"\0" * (padded - usize)
+        raw = plain[int(poffs[b]):int(poffs[b]) + usize]
+        dst = ctypes.create_string_buffer(2 * usize + 64)
+        cs = Z.ZSTD_compress(dst, len(dst), raw, usize, 7)
+        assert cs == csize and dst.raw[:cs] == pooled[pos + 16:pos + 16 + csize], "frame of block %d" % b
+        pos += 16 + csize
+        pos += (-pos) % 4
+    # and it reads back
+    a = ctypes.c_void_p()
+    path = str(tmp_path / "z_pool.xsi").encode()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, path))
+    buf = np.zeros(2 * n, dtype=np.int32)
+    block = off = 0
+    for i, (gt, na) in enumerate(lines):
+        if i and i % block_len == 0:
+            block += 1
+            off = 0
+        if i % 7 == 0:
+            r = L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, na, (block << 15) | off)
+            assert r == len(gt) and np.array_equal(buf[:r], gt), "line %d" % i
+        off += na - 1
+    L.xsi_accessor_close(a)
+
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("budget", [None, "two_blocks", 0])
 def test_accessor_random_access_block_cache(tmp_path, budget):
     """Config-5 style use: uniformly random BM positions over many blocks (mixed ploidy, multi-allelic,

@@ -117,6 +117,13 @@ uint64_t xsi_hip_ctx_workspace_bytes(const xsi_hip_ctx* c) {
 }
 
 uint64_t xsi_hip_ctx_chain_fallbacks(const xsi_hip_ctx* c) { return c ? c->chain_fallbacks : 0; }
+int xsi_hip_ctx_set_block_sizes_out(xsi_hip_ctx* c, uint32_t* d_sizes, uint64_t capacity_blocks) {
+    if (!c || (d_sizes && !capacity_blocks)) return set_error(XSI_ERR_ARG, "set_block_sizes_out: null context or zero capacity");
+    c->block_sizes_out = d_sizes;
+    c->block_sizes_cap = d_sizes ? capacity_blocks : 0;
+    c->block_sizes_pos = 0;
+    return XSI_OK;
+}
 
 int xsi_hip_ctx_set_workspace_budget(xsi_hip_ctx* c, uint64_t bytes) {
     if (!c) return set_error(XSI_ERR_ARG, "null context");
@@ -393,7 +400,14 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
         if (int rc = fork_sparse()) return rc;
     stage_mark(ctx, XSI_ST_LAYOUT);
     HIP_TRY(launch_block_layout(s, d_blocks, n_blocks, L, S, p->default_phased));
-    HIP_TRY(launch_scan_blocks_out(s, d_blocks, n_blocks, out_capacity, d_block_offsets, d_result, 256u + region_offset));
+    uint32_t* d_block_sizes = nullptr;
+    if (ctx->block_sizes_out) {
+        if (ctx->block_sizes_pos + n_blocks > ctx->block_sizes_cap)
+            return set_error(XSI_ERR_CAPACITY, "encode: the block-sizes side output holds %llu blocks, the call has more",
+                             (unsigned long long)ctx->block_sizes_cap);
+        d_block_sizes = ctx->block_sizes_out + ctx->block_sizes_pos;
+    }
+    HIP_TRY(launch_scan_blocks_out(s, d_blocks, n_blocks, out_capacity, d_block_offsets, d_result, 256u + region_offset, d_block_sizes));
     const uint32_t strategy = p->wah_encode_missing ? WS_WAH : WS_SPARSE;
     stage_mark(ctx, XSI_ST_WRITE);
     HIP_TRY(launch_write_headers(s, d_blocks, n_blocks, L, p->default_phased, strategy, (uint8_t*)d_out, d_result));
@@ -427,6 +441,7 @@ int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide
     }
     if (res[3]) return set_error(XSI_ERR_CAPACITY, "encode: output needs %llu bytes, capacity is %llu",
                                  (unsigned long long)res[0], (unsigned long long)out_capacity);
+    if (ctx->block_sizes_out) ctx->block_sizes_pos += n_blocks;  // (the next batch of the same call goes behind these)
     if (h_result) {
         h_result->n_blocks = n_blocks;
         h_result->blocks_bytes = res[0];
@@ -465,6 +480,7 @@ int xsi_hip_encode_packed_counted(xsi_hip_ctx* ctx, const xsi_encode_params* p, 
                                   uint32_t row_stride_bytes, const uint32_t* d_row_counts, void* d_out, uint64_t out_capacity,
                                   uint64_t* d_block_offsets, xsi_encode_result* h_result) {
     if (!ctx || !p || !d_bits || !d_out) return set_error(XSI_ERR_ARG, "encode_packed: null argument");
+    ctx->block_sizes_pos = 0;
     if (!p->n_samples || !p->block_len) return set_error(XSI_ERR_ARG, "encode_packed: n_samples and block_len must be > 0");
     if (p->block_len > MAX_BIN_PER_BLOCK)
         return set_error(XSI_ERR_ARG, "block_len %u exceeds the BM offset range (%u binary lines per block)", p->block_len,

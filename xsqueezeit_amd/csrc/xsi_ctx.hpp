@@ -58,6 +58,10 @@ struct xsi_hip_ctx {
     uint64_t stage_n[XSI_STAGE_COUNT] = {0};
     uint64_t chain_fallbacks = 0;     // encode batches run again with the streaming chain after an aborted launch
     uint32_t reencode_ranges = 0;     // block ranges the last xsi_hip_reencode walked the file in
+    // optional side output of the encode entry points (xsi_hip_ctx_set_block_sizes_out): bytes of every block of the call
+    // before its pad to 4; `pos` = blocks of the running call already encoded (a call may run as several batches)
+    uint32_t* block_sizes_out = nullptr;
+    uint64_t block_sizes_cap = 0, block_sizes_pos = 0;
 };
 
 struct xsi_encode_params;

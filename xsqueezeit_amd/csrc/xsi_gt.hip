@@ -1239,6 +1239,7 @@ static int encode_gt_impl(xsi_hip_ctx* ctx, const xsi_encode_params* p, const in
                           uint64_t n_lines, const uint32_t* h_ngt, const uint32_t* h_n_allele, void* d_out,
                           uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result, uint64_t region_offset) {
     if (!ctx || !p || !d_gt || !h_ngt || !h_n_allele || !d_out) return set_error(XSI_ERR_ARG, "encode_gt: null argument");
+    if (!region_offset) ctx->block_sizes_pos = 0;  // (xsi_hip_reencode's later ranges continue the same call)
     if (!p->n_samples || !p->block_len) return set_error(XSI_ERR_ARG, "encode_gt: n_samples and block_len must be > 0");
     if (at_mismatch_window(p->n_samples))
         return set_error(XSI_ERR_UNSUPPORTED, "%s: %u samples fall in the reference's A_T mismatch window (32768..65535: 16-bit "

@@ -39,8 +39,15 @@ using namespace xsi;
 // time (no zstd headers in the build image); without it --zstd files are refused.
 // ------------------------------------------------------------------------------------------
 #include <dlfcn.h>
+#include <condition_variable>
+#include <deque>
 #include <exception>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <string>
+#include <thread>
+#include <vector>
 namespace {
 struct ZstdApi {
     size_t (*compress)(void*, size_t, const void*, size_t, int) = nullptr;
@@ -64,6 +71,99 @@ const ZstdApi& zstd_api() {
     }();
     return z;
 }
+
+// The zstd layer at block-parallel speed.  ZSTD_compress is one-shot per block and deterministic, every call
+// with a context of its own: blocks are compressed side by side on a small pool while the GPU encodes the next batch and the
+// caller fills the one after, and the frames reach the file in block order - byte for byte the file of the one-thread
+// writer (and of the reference, for the libzstd in use).
+struct ZstdJob {
+    std::vector<uint8_t> raw;    // the block as streamed, before its pad
+    std::vector<uint8_t> frame;  // compressed
+    size_t csize = 0;
+    uint64_t usize = 0;          // raw.size() (raw is released once compressed)
+    bool done = false, failed = false;
+    std::string err;
+};
+struct ZstdPool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::deque<std::shared_ptr<ZstdJob>> todo;   // not yet taken by a thread
+    std::deque<std::shared_ptr<ZstdJob>> order;  // in file order, not yet written
+    bool stop = false;
+    int level = 0;
+    void run() {
+        const ZstdApi& z = zstd_api();
+        for (;;) {
+            std::shared_ptr<ZstdJob> j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return stop || !todo.empty(); });
+                if (todo.empty()) return;  // (stop, nothing left)
+                j = todo.front();
+                todo.pop_front();
+            }
+            bool failed = false;
+            std::string err;
+            size_t cs = 0;
+            try {
+                j->frame.resize(j->raw.size() * 2 + 64);  // (the bound the one-thread writer has always used: above ZSTD_compressBound)
+                cs = z.compress(j->frame.data(), j->frame.size(), j->raw.data(), j->raw.size(), level);
+                if (z.is_error(cs)) {
+                    failed = true;
+                    err = z.error_name ? z.error_name(cs) : "zstd";
+                }
+                std::vector<uint8_t>().swap(j->raw);
+            } catch (const std::exception& e) {
+                failed = true;
+                err = e.what();
+            }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                j->csize = cs;
+                j->failed = failed;
+                j->err = err;
+                j->done = true;
+            }
+            cv_done.notify_all();
+        }
+    }
+    void start(unsigned n, int lvl) {
+        level = lvl;
+        for (unsigned i = 0; i < n; ++i) threads.emplace_back([this] { run(); });
+    }
+    void submit(std::shared_ptr<ZstdJob> j) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            todo.push_back(j);
+            order.push_back(j);
+        }
+        cv_work.notify_one();
+    }
+    // the oldest job once it is done (waits for it when `wait`), removed from the order; nullptr: none / not yet
+    std::shared_ptr<ZstdJob> pop_done(bool wait) {
+        std::unique_lock<std::mutex> lk(m);
+        if (order.empty()) return nullptr;
+        if (wait) cv_done.wait(lk, [&] { return order.front()->done; });
+        if (!order.front()->done) return nullptr;
+        std::shared_ptr<ZstdJob> j = order.front();
+        order.pop_front();
+        return j;
+    }
+    size_t pending() {
+        std::lock_guard<std::mutex> lk(m);
+        return order.size();
+    }
+    ~ZstdPool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+            todo.clear();
+        }
+        cv_work.notify_all();
+        for (auto& t : threads) t.join();
+    }
+};
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -129,6 +229,12 @@ struct xsi_writer {
     uint64_t entry_counter = 0, variant_counter = 0;
     uint32_t max_ploidy_seen = 0;
     uint64_t file_pos = 0;
+    // --zstd: blocks of a batch are compressed on a pool and written in order (ZstdPool above); d_sizes takes every block's
+    // length before its pad (xsi_hip_ctx_set_block_sizes_out)
+    ZstdPool* zpool = nullptr;
+    uint32_t* d_sizes = nullptr;
+    std::vector<uint32_t> h_sizes;
+    size_t zstd_max_pending = 0;
 };
 
 
@@ -150,6 +256,27 @@ static int writer_ship_chunk(xsi_writer* w) {
     w->h_bits_chunk = w->h_bits_chunks[w->cur_chunk];
     HIP_TRY(hipEventSynchronize(w->chunk_done[w->cur_chunk]));
     return XSI_OK;
+}
+
+// Frames of finished blocks -> file, in block order.  all: every block submitted so far (finalize); else only while the
+// queue is longer than what keeps the pool busy (or the front happens to be ready).
+static int writer_drain_zstd(xsi_writer* w, bool all) {
+    if (!w->zpool) return XSI_OK;
+    for (;;) {
+        const bool must = all || w->zpool->pending() > w->zstd_max_pending;
+        std::shared_ptr<ZstdJob> j = w->zpool->pop_done(must);
+        if (!j) return XSI_OK;
+        if (j->failed) return set_error(XSI_ERR_IO, "Failed to compress block: %s", j->err.c_str());
+        w->indices.push_back(w->file_pos);
+        const uint64_t c64 = j->csize, u64 = j->usize;
+        if (fwrite(&c64, 8, 1, w->f) != 1 || fwrite(&u64, 8, 1, w->f) != 1 || fwrite(j->frame.data(), 1, j->csize, w->f) != j->csize)
+            return set_error(XSI_ERR_IO, "short write");
+        w->file_pos += 16 + j->csize;
+        while (w->file_pos % 4) {
+            if (fputc(0, w->f) == EOF) return set_error(XSI_ERR_IO, "short write");
+            w->file_pos++;
+        }
+    }
 }
 
 // Worker: encode batch `b` (its rows are on the device once batch_copied has fired) and append the
@@ -177,6 +304,16 @@ static int writer_encode_batch(xsi_writer* w, int b, uint64_t n_lines) {
     int rc;
     uint64_t n_general = 0;
     for (uint8_t f : w->fast[b]) n_general += f ? 0u : 1u;
+    // (the context is the caller's: the side output is on for this call only)
+    struct SizesOut {
+        xsi_hip_ctx* c;
+        SizesOut(xsi_hip_ctx* ctx, uint32_t* d, uint64_t cap) : c(d ? ctx : nullptr) {
+            if (c) (void)xsi_hip_ctx_set_block_sizes_out(c, d, cap);
+        }
+        ~SizesOut() {
+            if (c) (void)xsi_hip_ctx_set_block_sizes_out(c, nullptr, 0);
+        }
+    } sizes_out(w->ctx, w->p.zstd_level ? w->d_sizes : nullptr, w->batch_blocks);
     if (n_general == 0) {
         HIP_TRY(hipMemcpyAsync(w->d_ones[b], w->ones[b].data(), 4ull * n_lines, hipMemcpyHostToDevice, w->ctx->stream));
         rc = xsi_hip_encode_packed_counted(w->ctx, &w->p, w->d_bits[b], n_lines, w->bit_stride, w->d_ones[b], w->d_out, w->out_cap,
@@ -203,24 +340,20 @@ static int writer_encode_batch(xsi_writer* w, int b, uint64_t n_lines) {
         return XSI_OK;
     }
     // compress_and_write, interfaces.hpp:291-314: u64 compressed size, u64 original size, frame; pad to 4.
-    // The reference compresses the block as streamed, before its pad; only the last block of a call comes
-    // with that length, so --zstd batches hold one block (the host-side compression is the bound anyway).
-    if (n_blocks != 1) return set_error(XSI_ERR_ARG, "zstd batches hold one block");
-    const ZstdApi& z = zstd_api();
-    const uint64_t usize = res.last_block_bytes;
-    std::vector<uint8_t> frame((size_t)usize * 2 + 64);
-    const size_t csize = z.compress(frame.data(), frame.size(), w->h_out.data(), (size_t)usize, (int)w->p.zstd_level);
-    if (z.is_error(csize)) return set_error(XSI_ERR_IO, "Failed to compress block: %s", z.error_name ? z.error_name(csize) : "zstd");
-    w->indices.push_back(w->file_pos);
-    const uint64_t c64 = csize;
-    if (fwrite(&c64, 8, 1, w->f) != 1 || fwrite(&usize, 8, 1, w->f) != 1 || fwrite(frame.data(), 1, csize, w->f) != csize)
-        return set_error(XSI_ERR_IO, "short write");
-    w->file_pos += 16 + csize;
-    while (w->file_pos % 4) {
-        if (fputc(0, w->f) == EOF) return set_error(XSI_ERR_IO, "short write");
-        w->file_pos++;
+    // The reference compresses the block as streamed, before its pad: every block's own length comes from the encode
+    // call's side output (xsi_hip_ctx_set_block_sizes_out).  The blocks go to the pool; frames that are ready are written,
+    // in order, here and at finalize - this thread returns as soon as the queue is short enough, so that the GPU encodes
+    // the next batch while the pool is still busy with this one.
+    HIP_TRY(hipMemcpy(w->h_sizes.data(), w->d_sizes, 4ull * n_blocks, hipMemcpyDeviceToHost));
+    for (uint64_t k = 0; k < n_blocks; ++k) {
+        const uint64_t off = w->h_offs[k] - 256, usize = w->h_sizes[k];
+        if (off + usize > w->h_out.size() || usize < 16) return set_error(XSI_ERR_FORMAT, "writer: block %llu of the batch has no sane length", (unsigned long long)k);
+        auto j = std::make_shared<ZstdJob>();
+        j->raw.assign(w->h_out.data() + off, w->h_out.data() + off + usize);
+        j->usize = usize;
+        w->zpool->submit(j);
     }
-    return XSI_OK;
+    return writer_drain_zstd(w, /*all=*/false);
 }
 
 static int writer_join(xsi_writer* w) {
@@ -277,6 +410,8 @@ static void writer_free(xsi_writer* w) {
         if (w->h_chunks[i]) (void)hipHostFree(w->h_chunks[i]);
         if (w->chunk_done[i]) (void)hipEventDestroy(w->chunk_done[i]);
     }
+    delete w->zpool;  // (joins its threads; jobs not yet taken are dropped)
+    if (w->d_sizes) (void)hipFree(w->d_sizes);
     if (w->d_out) (void)hipFree(w->d_out);
     if (w->d_offs) (void)hipFree(w->d_offs);
     if (w->batch_copied) (void)hipEventDestroy(w->batch_copied);
@@ -346,8 +481,21 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
         if (k > 64) k = 64;
         if (k > fit) k = fit;
         if (const char* e = tuning_env("XSI_WRITER_BATCH_BLOCKS")) k = strtoull(e, nullptr, 10);
-        if (k < 1 || p->zstd_level) k = 1;
+        if (k < 1) k = 1;
         w->batch_blocks = (uint32_t)k;
+    }
+    if (p->zstd_level) {
+        // pool: the host's cores less the caller's and the worker's, at most 16 (XSI_WRITER_ZSTD_THREADS overrides, 1 = the
+        // one-thread writer of rounds 1 - 5 for A/B runs); the queue may hold two batches' blocks before the worker waits
+        unsigned hc = std::thread::hardware_concurrency();
+        unsigned nt = hc > 3 ? hc - 2 : 2;
+        if (nt > 16) nt = 16;
+        if (const char* e = tuning_env("XSI_WRITER_ZSTD_THREADS")) nt = (unsigned)atoi(e);
+        if (nt < 1) nt = 1;
+        w->zpool = new ZstdPool();
+        w->zpool->start(nt, (int)p->zstd_level);
+        w->zstd_max_pending = nt > 1 ? (size_t)2 * w->batch_blocks : 0;
+        w->h_sizes.resize(w->batch_blocks);
     }
     hipError_t e = hipSuccess;
     w->bit_stride = (uint32_t)(((w->N + 1023u) / 1024u) * 128u);
@@ -355,6 +503,7 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&w->d_bits[i], (size_t)w->bit_stride * p->block_len * w->batch_blocks);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&w->d_fast[i], (size_t)p->block_len * w->batch_blocks);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&w->d_ones[i], 4ull * p->block_len * w->batch_blocks);
+    if (e == hipSuccess && p->zstd_level) e = hipMalloc((void**)&w->d_sizes, 4ull * w->batch_blocks);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&w->batch_copied, hipEventDisableTiming);
     size_t chunk_bytes = 64ull << 20;
@@ -455,6 +604,8 @@ int xsi_writer_finalize(xsi_writer* w, uint32_t max_ploidy) {
     int rc = writer_flush_batch(w);
     if (rc) return rc;
     rc = writer_join(w);
+    if (rc) return rc;
+    rc = writer_drain_zstd(w, /*all=*/true);  // (--zstd: the frames still with the pool)
     if (rc) return rc;
     // xsi_factory.hpp:558-605
     while (w->file_pos % 8) {

@@ -2250,7 +2250,8 @@ hipError_t launch_block_layout(hipStream_t s, EncBlock* blocks, uint32_t n_block
 // d_result: [0] total bytes, [1] n_blocks, [2] total WAH lines, [3] error (1 = capacity)
 __global__ void __launch_bounds__(1024) k_scan_blocks_out(EncBlock* __restrict__ blocks, uint32_t n_blocks,
                                                           uint64_t capacity, uint64_t* __restrict__ d_block_offsets,
-                                                          uint64_t* __restrict__ d_result, uint64_t file_base) {
+                                                          uint64_t* __restrict__ d_result, uint64_t file_base,
+                                                          uint32_t* __restrict__ d_block_sizes) {
     __shared__ uint64_t s_scan[20];
     uint64_t base = 0;
     uint32_t wah = 0;
@@ -2262,6 +2263,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocks_out(EncBlock* __restrict__
         if (i < n_blocks) {
             blocks[i].out_off = base + ex;
             if (d_block_offsets) d_block_offsets[i] = file_base + base + ex;  // 256 + bytes of earlier blocks
+            if (d_block_sizes) d_block_sizes[i] = 16u + blocks[i].gt_bytes;   // the block as streamed, before its pad (what the zstd layer compresses)
         }
         base += tot;
     }
@@ -2276,8 +2278,8 @@ __global__ void __launch_bounds__(1024) k_scan_blocks_out(EncBlock* __restrict__
 }
 
 hipError_t launch_scan_blocks_out(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, uint64_t capacity,
-                                  uint64_t* d_block_offsets, uint64_t* d_result, uint64_t file_base) {
-    k_scan_blocks_out<<<dim3(1), dim3(1024), 0, s>>>(blocks, n_blocks, capacity, d_block_offsets, d_result, file_base);
+                                  uint64_t* d_block_offsets, uint64_t* d_result, uint64_t file_base, uint32_t* d_block_sizes) {
+    k_scan_blocks_out<<<dim3(1), dim3(1024), 0, s>>>(blocks, n_blocks, capacity, d_block_offsets, d_result, file_base, d_block_sizes);
     return hipGetLastError();
 }
 

@@ -95,7 +95,7 @@ bool wah_units_any(uint32_t y_stride64);
 hipError_t launch_block_layout(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
                                const EncSide& S, int32_t default_phased);
 hipError_t launch_scan_blocks_out(hipStream_t s, EncBlock* blocks, uint32_t n_blocks, uint64_t capacity,
-                                  uint64_t* d_block_offsets, uint64_t* d_result /*[5]*/, uint64_t file_base);
+                                  uint64_t* d_block_offsets, uint64_t* d_result /*[5]*/, uint64_t file_base, uint32_t* d_block_sizes = nullptr);
 hipError_t launch_write_headers(hipStream_t s, const EncBlock* blocks, uint32_t n_blocks, const EncLines& L,
                                 int32_t default_phased, uint32_t strategy, uint8_t* out, const uint64_t* d_result);
 hipError_t launch_wah_write(hipStream_t s, const EncBlock* blocks, const EncLines& L, uint32_t max_wah,
