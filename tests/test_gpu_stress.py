@@ -114,6 +114,7 @@ def test_haploid_flags_misaligned_by_multiallelic_lines(order, n):
     for i, (gt_o, cnt_o) in enumerate(want):
         assert len(rows[i]) == len(gt_o), "line %d: %d values, the oracle's reader has %d" % (i, len(rows[i]), len(gt_o))
         assert np.array_equal(rows[i], gt_o), "line %d differs from the oracle reader's row" % i
+        assert [int(x) for x in counts[i][:nal[i]]] == [int(x) for x in cnt_o], "allele counts of line %d" % i
     same_as_input = all(len(rows[i]) == len(lines[i][0]) and np.array_equal(rows[i], lines[i][0]) for i in range(len(lines)))
     if order == "haploid_first":
         assert same_as_input

@@ -92,8 +92,10 @@ struct ZstdPool {
     std::deque<std::shared_ptr<ZstdJob>> order;  // in file order, not yet written
     bool stop = false;
     int level = 0;
+    bool prof = false;
     void run() {
         const ZstdApi& z = zstd_api();
+        std::vector<uint8_t> scratch;
         for (;;) {
             std::shared_ptr<ZstdJob> j;
             {
@@ -106,18 +108,27 @@ struct ZstdPool {
             bool failed = false;
             std::string err;
             size_t cs = 0;
+            const auto t0 = std::chrono::steady_clock::now();
             try {
-                j->frame.resize(j->raw.size() * 2 + 64);  // (the bound the one-thread writer has always used: above ZSTD_compressBound)
-                cs = z.compress(j->frame.data(), j->frame.size(), j->raw.data(), j->raw.size(), level);
+                // the destination is this thread's own, kept across jobs (a fresh 2 x block-size vector per job was a page
+                // fault per 4 KiB in sixteen threads at once); only the frame's bytes are copied into the job
+                const size_t bound = j->raw.size() + j->raw.size() / 128u + 1024u;  // (above ZSTD_compressBound: size + size / 256 + 64 KiB-block margins)
+                if (scratch.size() < bound) scratch.resize(bound + bound / 4u);
+                cs = z.compress(scratch.data(), scratch.size(), j->raw.data(), j->raw.size(), level);
                 if (z.is_error(cs)) {
                     failed = true;
                     err = z.error_name ? z.error_name(cs) : "zstd";
+                } else {
+                    j->frame.assign(scratch.data(), scratch.data() + cs);
                 }
                 std::vector<uint8_t>().swap(j->raw);
             } catch (const std::exception& e) {
                 failed = true;
                 err = e.what();
             }
+            if (prof)
+                fprintf(stderr, "[xsi writer prof] zstd job: %llu -> %zu bytes in %.1f ms\n", (unsigned long long)j->usize, cs,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
             {
                 std::lock_guard<std::mutex> lk(m);
                 j->csize = cs;
@@ -328,6 +339,11 @@ static int writer_encode_batch(xsi_writer* w, int b, uint64_t n_lines) {
                                w->out_cap, w->d_offs, &res);
     }
     if (rc) return rc;
+    if (w->zpool && w->zpool->prof) {
+        (void)hipStreamSynchronize(w->ctx->stream);
+        fprintf(stderr, "[xsi writer prof] batch of %llu blocks encoded (%llu bytes), %zu frames pending\n", (unsigned long long)n_blocks,
+                (unsigned long long)res.blocks_bytes, w->zpool->pending());
+    }
     w->h_out.resize(res.blocks_bytes);
     w->h_offs.resize(n_blocks + 1);
     HIP_TRY(hipMemcpy(w->h_out.data(), w->d_out, res.blocks_bytes, hipMemcpyDeviceToHost));
@@ -481,6 +497,9 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
         if (k > 64) k = 64;
         if (k > fit) k = fit;
         if (const char* e = tuning_env("XSI_WRITER_BATCH_BLOCKS")) k = strtoull(e, nullptr, 10);
+        // --zstd: a block's compression (tens of milliseconds on one core) starts when its batch has been encoded, so small
+        // batches put the pool to work early and shorten the tail behind the last append
+        if (p->zstd_level && k > 4 && !tuning_env("XSI_WRITER_BATCH_BLOCKS")) k = 4;
         if (k < 1) k = 1;
         w->batch_blocks = (uint32_t)k;
     }
@@ -493,6 +512,7 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
         if (const char* e = tuning_env("XSI_WRITER_ZSTD_THREADS")) nt = (unsigned)atoi(e);
         if (nt < 1) nt = 1;
         w->zpool = new ZstdPool();
+        w->zpool->prof = tuning_env("XSI_WRITER_PROF") != nullptr;
         w->zpool->start(nt, (int)p->zstd_level);
         w->zstd_max_pending = nt > 1 ? (size_t)2 * w->batch_blocks : 0;
         w->h_sizes.resize(w->batch_blocks);

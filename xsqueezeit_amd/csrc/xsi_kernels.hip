@@ -3385,7 +3385,11 @@ __global__ void __launch_bounds__(T) k_sparse_fill(const uint8_t* __restrict__ f
     }
     for (uint32_t i = lane; i < num; i += (uint32_t)T) {
         const uint32_t idx = rd_at(p + (size_t)(1u + i) * L.aet, L.aet);
-        if (idx < nbits) atomicOr(&row[idx >> 5], 1u << (idx & 31u));
+        // Raw lists (no complement here: the composer reads them) keep EVERY listed position of the row: the reference
+        // applies a sparse list entry by entry whatever the line's haploid flag (accessor_internals_new.hpp:208-256), and
+        // that flag can belong to another line (KEY_LINE_HAPLOID is written per BCF line and read per binary line, SURVEY
+        // 9.6.2) - a diploid line's second ALT read as "haploid" still lists haplotypes up to N.
+        if (idx < (apply_negation ? nbits : L.N)) atomicOr(&row[idx >> 5], 1u << (idx & 31u));
     }
     __syncthreads();
     uint32_t* dst = out_rows + (size_t)l * out_stride_w;
@@ -3444,14 +3448,17 @@ __global__ void __launch_bounds__(256) k_sparse_fill_direct(const uint8_t* __res
         const uint32_t idx = rd_at(p + (size_t)(1u + i) * L.aet, L.aet);
         const uint32_t w = idx >> 5;
         if (i && (rd_at(p + (size_t)i * L.aet, L.aet) >> 5) == w) continue;  // not the first entry of its word
-        if (w >= nw) continue;  // corrupt image: positions at or beyond nbits are dropped
+        // raw lists keep every listed position of the row (see k_sparse_fill); only a complemented row ends at nbits
+        const uint32_t lim = apply_negation ? nbits : L.N;
+        const uint32_t nwl = (lim + 31u) >> 5;
+        if (w >= nwl) continue;  // corrupt image: positions beyond the row are dropped
         uint32_t v = 1u << (idx & 31u);
         for (uint32_t j = i + 1u; j < num; ++j) {
             const uint32_t nx = rd_at(p + (size_t)(1u + j) * L.aet, L.aet);
             if ((nx >> 5) != w) break;
             v |= 1u << (nx & 31u);
         }
-        if (w == nw - 1u) v &= last_mask;
+        if (w == nwl - 1u && (lim & 31u)) v &= (1u << (lim & 31u)) - 1u;
         dst[w] = ones_bg ? (background(w) & ~v) : v;
     }
     if (tid == 0) {
