@@ -364,6 +364,50 @@ def run_config4(args, real_stdout, emit=True):
                 raise SystemExit("cold query at line %d (%s) failed: %s" % (li, mode, L.xsi_hip_last_error()))
         cold_iso.append(rec)
     cold_iso = cold_iso[1:]
+
+    # ---- cold sequential scan (the reference's own benchmark loads every line in order,
+    # loading_time/gt_loader_new.hpp:112-172): nothing in HBM, then every line of the first blocks in file order, one
+    # get_genotypes call per line.  "stalls" = calls that took more than a millisecond (first touches and continuations of a
+    # prefix decode).  Measured twice: with the accessor's sequential policy (one continuation per prefix-decoded block,
+    # whole-block first touches, block b + 1 decoded by a second thread while b is served) and with
+    # XSI_ACCESSOR_NO_READAHEAD=1, which is the accessor of rounds 4 - 5.
+    def seq_scan(readahead):
+        had_switch = os.environ.get("XSI_ENABLE_TUNING_ENV")
+        if not readahead:
+            os.environ["XSI_ENABLE_TUNING_ENV"] = "1"
+            os.environ["XSI_ACCESSOR_NO_READAHEAD"] = "1"
+        binding.check(L.xsi_accessor_set_cache_bytes(a, 0))       # evict everything
+        binding.check(L.xsi_accessor_set_cache_bytes(a, budget_before))
+        torch.cuda.synchronize()
+        n_scan = min(4, n_blocks) * bl
+        lat = np.empty(n_scan)
+        ok = True
+        ra0, rh0 = u64(0), u64(0)
+        binding.check(L.xsi_accessor_readahead_stats(a, ctypes.byref(ra0), ctypes.byref(rh0)))
+        t_scan = 0.0
+        for li in range(n_scan):
+            tq = time.perf_counter()
+            r = get(a, int(nal[li]), int(bm[li]), ctypes.byref(pbuf), ctypes.byref(nout))
+            lat[li] = time.perf_counter() - tq
+            t_scan += lat[li]
+            if r != N:
+                raise SystemExit("sequential scan failed at line %d: %s" % (li, L.xsi_hip_last_error()))
+            if li % 509 == 0:
+                ok = ok and bool(np.array_equal(buf, rows[li].cpu().numpy()))
+        os.environ.pop("XSI_ACCESSOR_NO_READAHEAD", None)
+        if had_switch is None:
+            os.environ.pop("XSI_ENABLE_TUNING_ENV", None)
+        ra1, rh1 = u64(0), u64(0)
+        binding.check(L.xsi_accessor_readahead_stats(a, ctypes.byref(ra1), ctypes.byref(rh1)))
+        return {"lines": n_scan, "seconds": t_scan, "lines_per_s": n_scan / t_scan, "cells_per_s": float(N) * n_scan / t_scan,
+                "stalls_over_1ms": int((lat > 1e-3).sum()), "stall_ms_total": float(lat[lat > 1e-3].sum() * 1e3),
+                "max_call_ms": float(lat.max() * 1e3), "median_call_us": float(np.median(lat) * 1e6),
+                "readaheads_started": int(ra1.value - ra0.value), "first_touches_served_by_readahead": int(rh1.value - rh0.value),
+                "rows_match_source": ok}
+
+    seq_scan(True)  # (warms the second context up: its workspace is allocated on first use)
+    seq_new = seq_scan(True)
+    seq_old = seq_scan(False)
     binding.check(L.xsi_accessor_unregister_array(a))
     binding.check(L.xsi_accessor_register_array(a, bat_np.ctypes.data, bat_np.size))
     batched_pass(False)
@@ -422,7 +466,11 @@ def run_config4(args, real_stdout, emit=True):
             "cold_isolated_queries": {"what": "one line asked of a block that is not in HBM, at rising offsets into the block: "
                                               "prefix_ms = first touch decodes the lines in front of it only, full_ms = the whole block",
                                       "block_lines": int(min(bl, S)), "queries": cold_iso},
-            "rows_match_source": bool(ok_cold and ok_warm and ok_chk and ok_batched),
+            "cold_sequential_scan": dict(seq_new, what="every line of %d cold blocks in file order, one xsi_accessor_get_genotypes "
+                                                       "call per line (int32 rows into a registered page-locked array)" % min(4, n_blocks),
+                                         without_sequential_policy=seq_old,
+                                         speedup=seq_new["lines_per_s"] / seq_old["lines_per_s"]),
+            "rows_match_source": bool(ok_cold and ok_warm and ok_chk and ok_batched and seq_new["rows_match_source"] and seq_old["rows_match_source"]),
         }
         if not args.no_cpu_baseline:
             from oracle import oracle

@@ -433,6 +433,13 @@ int xsi_accessor_cache_stats(const xsi_accessor* a, uint64_t* blocks, uint64_t* 
  * open.  XSI_ACCESSOR_FULL_DECODE=1 (under XSI_ENABLE_TUNING_ENV=1) decodes whole blocks on first touch (measurement, as
  * before round 4). */
 int xsi_accessor_prefix_stats(const xsi_accessor* a, uint64_t* prefix_decodes, uint64_t* extensions);
+/* Sequential scans (the reference's published benchmark loads every line in order, loading_time/gt_loader_new.hpp:112-172):
+ * once a handful of single-line queries have followed one another line by line, a prefix-decoded block is finished in one
+ * continuation, a cold block is decoded whole, and block b + 1 is decoded by a second thread (own stream and workspace)
+ * while block b is served, provided the cache can hold both.  started: read-aheads begun; hits: blocks whose first touch
+ * found them in HBM because of one.  Plain files only (a zstd block is inflated on the host first).
+ * XSI_ACCESSOR_NO_READAHEAD=1 (under XSI_ENABLE_TUNING_ENV=1) switches the whole policy off (measurement). */
+int xsi_accessor_readahead_stats(const xsi_accessor* a, uint64_t* started, uint64_t* hits);
 /* Sample selection on decode (NewDecompressor::fill_selected_genotypes, include/gt_decompressor_new.hpp:209-238):
  * after set_sample_subset(idx, n) (indices into the file's sample list, any order, repeats allowed; n = 0
  * clears), fill_selected_genotypes composes the line on the device, gathers the listed samples there and

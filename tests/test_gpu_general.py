@@ -384,6 +384,91 @@ def test_allele_counts_without_expansion(tmp_path):
     L.xsi_accessor_close(a)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["readahead", "no_readahead", "reparse", "small_cache"])
+def test_sequential_scan_readahead_in_the_accessor(tmp_path, monkeypatch, mode):
+    """Round 6.  A scan that asks for every line in file order: after a few consecutive queries the
+    accessor finishes a prefix-decoded block in ONE continuation (from the plan it kept: no second parse, no second
+    boundary scan), decodes cold blocks whole, and has block b + 1 decoded by a second thread while b is served
+    (accessor_internals_new.hpp:154-196 replays; loading_time/gt_loader_new.hpp:112-172 is the sequential consumer).
+    Every row and allele count equals the source / the oracle's reader in every mode: the policy on, off
+    (XSI_ACCESSOR_NO_READAHEAD: rounds 4 - 5), continuations that parse again (XSI_ACCESSOR_REPARSE), and a cache too
+    small for two blocks (no read-ahead may throw out the block being served).  A jump away in the middle of the scan
+    and back must not disturb it."""
+    import gpu_util as G
+    from oracle import oracle
+    L = binding.lib()
+    for k in ("XSI_ACCESSOR_NO_READAHEAD", "XSI_ACCESSOR_REPARSE"):
+        monkeypatch.delenv(k, raising=False)
+    if mode == "no_readahead":
+        monkeypatch.setenv("XSI_ACCESSOR_NO_READAHEAD", "1")
+    if mode == "reparse":
+        monkeypatch.setenv("XSI_ACCESSOR_REPARSE", "1")
+    rng = np.random.default_rng(6100)
+    n, block_len, n_blocks = 25000, 150, 5
+    n_lines = block_len * n_blocks - 20
+    lines = _random_lines(rng, n, n_lines, multi=True, missing=True, eov=True)
+    dp = oracle.default_phased_of(lines, n)
+    names = ["s%d" % i for i in range(n)]
+    plain = oracle.encode_file(lines, n, block_len=block_len, mac_thr=50, default_phased=dp, sample_names=names)
+    path = tmp_path / "seq.xsi"
+    path.write_bytes(plain)
+    rd = oracle.Reader(plain)
+    bms, block, off = [], 0, 0
+    for i, (_, na) in enumerate(lines):
+        if i and i % block_len == 0:
+            block, off = block + 1, 0
+        bms.append((block << 15) | off)
+        off += na - 1
+    a = ctypes.c_void_p()
+    binding.check(L.xsi_accessor_open(ctypes.byref(a), G.ctx().handle, str(path).encode()))
+    if mode == "small_cache":
+        # room for one decoded block and a half
+        buf0 = np.zeros(2 * n, dtype=np.int32)
+        assert L.xsi_accessor_fill_genotype_array(a, buf0.ctypes.data, buf0.size, lines[block_len][1], bms[block_len]) > 0
+        nb, by = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        binding.check(L.xsi_accessor_cache_stats(a, ctypes.byref(nb), ctypes.byref(by), None, None))
+        assert nb.value == 1
+        binding.check(L.xsi_accessor_set_cache_bytes(a, 0))
+        binding.check(L.xsi_accessor_set_cache_bytes(a, int(by.value * 1.5)))
+    buf = np.zeros(2 * n, dtype=np.int32)
+    cnt = np.zeros(8, dtype=np.uint64)
+
+    def check(i, full=False):
+        na = lines[i][1]
+        r = L.xsi_accessor_fill_genotype_array(a, buf.ctypes.data, buf.size, na, bms[i])
+        assert r == len(lines[i][0]), L.xsi_hip_last_error()
+        assert np.array_equal(buf[:r], lines[i][0]), "line %d vs source" % i
+        if full:
+            egt, ecnt = rd.fill_genotype_array(na, bms[i])
+            assert np.array_equal(buf[:r], egt), "line %d vs oracle reader" % i
+            binding.check(L.xsi_accessor_allele_counts(a, cnt.ctypes.data, na))
+            assert np.array_equal(cnt[:na], ecnt), "allele counts of line %d" % i
+
+    for i in range(n_lines):
+        check(i, full=(i % 23 == 0))
+        if i == 2 * block_len + 40:  # a jump into a block far away and back: the scan's count starts again
+            check(n_lines - 3, full=True)
+            check(5, full=True)
+    st, hits = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    binding.check(L.xsi_accessor_readahead_stats(a, ctypes.byref(st), ctypes.byref(hits)))
+    pd, ext = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    binding.check(L.xsi_accessor_prefix_stats(a, ctypes.byref(pd), ctypes.byref(ext)))
+    if mode in ("readahead", "reparse"):
+        assert st.value >= 2 and hits.value >= 2, (st.value, hits.value)
+        assert ext.value <= 4, "a prefix-decoded block of a sequential scan is finished in one continuation (%d)" % ext.value
+    elif mode == "no_readahead":
+        assert st.value == 0 and hits.value == 0
+        assert ext.value >= 5  # the growing continuations of rounds 4 - 5
+    else:
+        assert st.value == 0  # the cache cannot hold two blocks: nothing is read ahead
+    # a second scan, everything in HBM or evicted: same rows
+    for i in range(0, n_lines, 7):
+        check(i)
+    L.xsi_accessor_close(a)
+
+
+
 @pytest.mark.parametrize("zstd", [False, True])
 def test_prefix_decode_in_the_accessor(tmp_path, zstd):
     """Round 4: a cold query decodes its block only up to the requested line (the chain over the WAH lines in front of

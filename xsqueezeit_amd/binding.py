@@ -52,7 +52,7 @@ SYMBOLS = [
     "xsi_accessor_set_cache_bytes", "xsi_accessor_cache_stats", "xsi_file_num_samples", "xsi_hip_decode_dot", "xsi_hip_decode_dot_gt",
     "xsi_hip_ctx_set_workspace_budget", "xsi_hip_chain_kernel", "xsi_mac_threshold", "xsi_default_phased",
     "xsi_bm_init", "xsi_bm_next", "xsi_accessor_set_sample_subset", "xsi_accessor_fill_selected_genotypes",
-    "xsi_hip_reencode", "xsi_hip_ctx_chain_fallbacks", "xsi_hip_ctx_set_block_sizes_out",
+    "xsi_hip_reencode", "xsi_hip_ctx_chain_fallbacks", "xsi_hip_ctx_set_block_sizes_out", "xsi_accessor_readahead_stats",
     "xsi_hip_shard_blocks", "xsi_hip_shard_of_block", "xsi_hip_comm_unique_id", "xsi_hip_comm_create", "xsi_hip_comm_destroy",
     "xsi_hip_comm_world", "xsi_hip_comm_rank", "xsi_hip_gather_block_streams", "xsi_hip_comm_wait", "xsi_htslib_shim_available", "xsi_debug_pack_bit_row",
     "xsi_hip_encode_packed_counted", "xsi_hip_count_packed_rows",
@@ -230,6 +230,8 @@ def lib():
     L.xsi_accessor_set_cache_bytes.argtypes = [vp, u64]
     L.xsi_accessor_prefix_stats.restype = c.c_int
     L.xsi_accessor_prefix_stats.argtypes = [vp, c.POINTER(u64), c.POINTER(u64)]
+    L.xsi_accessor_readahead_stats.restype = c.c_int
+    L.xsi_accessor_readahead_stats.argtypes = [vp, c.POINTER(u64), c.POINTER(u64)]
     L.xsi_accessor_cache_stats.restype = c.c_int
     L.xsi_accessor_cache_stats.argtypes = [vp, c.POINTER(u64), c.POINTER(u64), c.POINTER(u64), c.POINTER(u64)]
     L.xsi_hip_decode_dot.restype = c.c_int

@@ -915,6 +915,15 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
     L.y_stride64 = (L.N + 63u) / 64u;
     L.yp_stride = L.y_stride64 * 2u;
     if (counts_only) return XSI_OK;  // the caller only wants blocks_h: nothing sized by the WAH lines is allocated
+    return decode_plan_scratch(ctx, P);
+}
+
+// The part of a plan that is scratch of the context (sized by the plan's WAH lines, overwritten by the next decode on the
+// context): expanded rows, zeros per WAH line, the boundary scan's tiles - and, for a plan whose parsed part lives somewhere
+// else (a cache entry of the accessor: the continuation of a prefix decode), the totals the kernels read.
+int decode_plan_scratch(xsi_hip_ctx* ctx, DecodePlan* P, bool restore_totals) {
+    DecLines& L = P->L;
+    const uint32_t n_blocks = P->n_blocks;
     // shared with the encode's permuted rows; 16 KiB of slack: the long-row chain reads a row in whole 1024-unit pieces
     WS(L.yp, "ws.rows", 8ull * L.yp_stride * (size_t)(P->n_wah ? P->n_wah : 1) + 16384ull);
     WS(L.wah_z, "dec.wah_z", 4ull * (P->n_wah ? P->n_wah : 1) + 64);
@@ -927,6 +936,17 @@ int decode_prepare(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, uint
         const size_t cells = (size_t)(L.max_tiles ? L.max_tiles : 1) * n_blocks;
         WS(L.tile_sum, "dec.tile_sum", 4ull * cells);
         WS(L.tile_base, "dec.tile_base", 8ull * cells);
+    }
+    if (restore_totals) {
+        // [0] binary lines, [1] WAH lines, [2] sparse lines, [3] error, [4] BCF lines (k_scan_dec_blocks)
+        WS(P->d_totals, "dec.totals", 64);
+        uint32_t h[16] = {0};
+        h[0] = P->n_bin;
+        h[1] = P->n_wah;
+        h[2] = P->n_sparse;
+        h[4] = P->n_bcf;
+        HIP_TRY(hipMemcpyAsync(P->d_totals, h, 64, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));  // (h is a local)
     }
     return XSI_OK;
 }
@@ -1042,7 +1062,8 @@ bool decode_partial_supported(const DecodePlan& P) {
 // a block replays the o lines in front of it like the reference's seek (accessor_internals_new.hpp:154-196), not all
 // 8192, and a later query further into the block continues where this one stopped.
 int decode_planes_partial(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t* out, uint32_t stride_w,
-                          uint32_t wah_lo, uint32_t wah_hi, uint32_t* d_state, uint32_t sp_lo, uint32_t sp_hi, uint64_t* d_sp_state) {
+                          uint32_t wah_lo, uint32_t wah_hi, uint32_t* d_state, uint32_t sp_lo, uint32_t sp_hi, uint64_t* d_sp_state,
+                          bool skip_boundaries) {
     hipStream_t s = ctx->stream;
     const uint8_t* f = (const uint8_t*)d_file;
     DecLines& L = P.L;
@@ -1063,7 +1084,8 @@ int decode_planes_partial(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, u
     L.yp_compact = rank_decode_takes_compact(L.N, L.yp_stride, P.n_blocks) ? 1u : 0u;
     L.yp_rev = (wah_expand_wide(L) && rank_decode_takes_reversed(L.N, L.yp_stride, P.n_blocks)) ? 1u : 0u;
     stage_mark(ctx, XSI_ST_DEC_BOUND);
-    HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
+    // (a continuation whose plan kept the line starts of the first decode does not scan the block's WAH words again)
+    if (!skip_boundaries) HIP_TRY(launch_wah_boundaries(s, f, P.d_blocks, P.n_blocks, L));
     if (wah_hi > wah_lo) {
         const uint32_t n = wah_hi - wah_lo;
         const uint32_t K = n >= 2048u ? 8u : (n >= 512u ? 4u : (n >= 128u ? 2u : 1u));

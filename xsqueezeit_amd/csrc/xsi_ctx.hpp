@@ -128,6 +128,9 @@ struct PartialDecode {
     // carried in d_walk[0..3)
     uint32_t bin_lo, bin_hi;
     uint64_t* d_walk;  // [0..3) side-matrix cursors, [3] the sparse matrix cursor
+    // the plan still holds the WAH line starts of the block (kept by the accessor's cache entry since the first decode):
+    // the boundary scan is not run again
+    bool skip_boundaries = false;
 };
 int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, DecodedPlanes* out, const PartialDecode* part = nullptr);
 int dot_planes(xsi_hip_ctx* ctx, const DecodePlan& P, const uint32_t* planes, uint32_t stride_w, const double* d_y,
@@ -148,7 +151,10 @@ int decode_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t*
                   int apply_negation);
 bool decode_partial_supported(const DecodePlan& P);
 int decode_planes_partial(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, uint32_t* out, uint32_t stride_w,
-                          uint32_t wah_lo, uint32_t wah_hi, uint32_t* d_state, uint32_t sp_lo, uint32_t sp_hi, uint64_t* d_sp_state);
+                          uint32_t wah_lo, uint32_t wah_hi, uint32_t* d_state, uint32_t sp_lo, uint32_t sp_hi, uint64_t* d_sp_state,
+                          bool skip_boundaries = false);
+// (re)assigns the context-owned scratch of a plan; restore_totals: also the device totals, from the plan's host fields
+int decode_plan_scratch(xsi_hip_ctx* ctx, DecodePlan* P, bool restore_totals = false);
 // region_offset: bytes of the blocks region that earlier batches of the same job already wrote before d_out
 int encode_run(xsi_hip_ctx* ctx, const xsi_encode_params* p, EncLines L, EncSide S, std::vector<EncBlock>& blocks_h,
                void* d_out, uint64_t out_capacity, uint64_t* d_block_offsets, xsi_encode_result* h_result,

@@ -1032,7 +1032,8 @@ int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, Decod
     }
     // binary lines [bin_lo, bin_hi) are WAH lines [wah_lo, wah_hi) and sparse lines [bin_lo - wah_lo, bin_hi - wah_hi)
     int rc = part ? decode_planes_partial(ctx, d_file, P, out->planes, stride_w, part->wah_lo, part->wah_hi, part->d_state,
-                                          part->bin_lo - part->wah_lo, part->bin_hi - part->wah_hi, part->d_walk + 3)
+                                          part->bin_lo - part->wah_lo, part->bin_hi - part->wah_hi, part->d_walk + 3,
+                                          part->skip_boundaries)
                   : decode_planes(ctx, d_file, P, out->planes, stride_w, /*apply_negation=*/0);
     P.L.sp_state = nullptr;  // the plan outlives this call (cache entries keep a copy): no dangling range in it
     P.L.sp_lo = P.L.sp_hi = 0u;

@@ -14,6 +14,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <list>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -700,11 +703,27 @@ struct xsi_accessor {
         uint32_t* d_state = nullptr;           // inside mem: the chain's parked ranks, then 64 bytes of side-matrix cursors
         uint64_t* d_walk = nullptr;
         std::vector<uint32_t> wah_before;      // [n_bin + 1]: WAH lines among the binary lines in front of line i
+        // the parsed part of the plan (line lists, ranks, WAH line starts: P.L.* point into mem) is kept with a prefix-decoded
+        // block, so that a continuation neither parses the dictionaries nor scans the WAH words again
+        bool has_plan = false;
     };
-    std::vector<CachedBlock> cache;
+    // (a list: entries keep their address while the read-ahead thread inserts others)
+    std::list<CachedBlock> cache;
+    std::mutex cache_m;  // guards cache, cache_bytes, tick: the read-ahead thread inserts what it has decoded
     uint64_t prefix_decodes = 0, prefix_extensions = 0;
     size_t cache_bytes = 0, cache_budget = 0;
     uint64_t tick = 0, cache_hits = 0, cache_misses = 0;
+    // Sequential scans (the reference's only published benchmark loads every line in order, loading_time/gt_loader_new.hpp:
+    // 112-172): queries that follow one another line by line are counted; from SEQ_MIN of them on, a prefix-decoded block
+    // is finished in one continuation instead of a dozen growing ones, and block b + 1 is decoded by a second thread with
+    // a context (stream + workspace) of its own while block b is being served, so that its first touch finds it in HBM.
+    int64_t seq_block = -1;
+    uint32_t seq_next = 0, seq_run = 0;
+    std::thread pf_thread;
+    bool pf_started = false;       // pf_thread is joinable
+    int64_t pf_block = -1;         // the block it decodes / decoded last
+    xsi_hip_ctx* pf_ctx = nullptr;
+    uint64_t readahead_started = 0, readahead_hits = 0;
     // zstd files: every block is inflated on the host into a one-block image (header + block + index)
     bool zstd = false;
     std::vector<uint8_t> mini;
@@ -804,14 +823,32 @@ static int accessor_block_image(xsi_accessor* a, uint64_t block, const uint8_t**
     return XSI_OK;
 }
 
-static void accessor_evict(xsi_accessor* a, size_t idx) {
-    (void)hipFree(a->cache[idx].mem);
-    a->cache_bytes -= a->cache[idx].bytes;
-    a->cache.erase(a->cache.begin() + (long)idx);
+using CacheIt = std::list<xsi_accessor::CachedBlock>::iterator;
+
+static void accessor_evict(xsi_accessor* a, CacheIt it) {  // (cache_m held)
+    (void)hipFree(it->mem);
+    a->cache_bytes -= it->bytes;
+    a->cache.erase(it);
 }
 
-// Copy the decoded state of the block that sits in the context workspace into a private
-// allocation and repoint (P, D) at it.  Returns false when the budget / HBM cannot take it.
+// least recently used entry other than block `protect` (< 0: any); end() when there is none  (cache_m held)
+static CacheIt accessor_lru(xsi_accessor* a, int64_t protect) {
+    CacheIt lru = a->cache.end();
+    for (CacheIt it = a->cache.begin(); it != a->cache.end(); ++it) {
+        if (protect >= 0 && it->block == (uint64_t)protect) continue;
+        if (lru == a->cache.end() || it->last_use < lru->last_use) lru = it;
+    }
+    return lru;
+}
+
+static xsi_accessor::CachedBlock* accessor_find(xsi_accessor* a, uint64_t block) {  // (cache_m held)
+    for (auto& e : a->cache)
+        if (e.block == block) return &e;
+    return nullptr;
+}
+
+// Copy the decoded state of a block that sits in a context's workspace into a private allocation: `e` receives plan and
+// planes repointed at it.  Returns false when the budget / HBM cannot take it.
 struct PartialInfo {
     uint32_t wah_done = 0;
     const uint32_t* ws_state = nullptr;  // the chain's parked ranks in the context workspace
@@ -819,30 +856,35 @@ struct PartialInfo {
     std::vector<uint32_t>* wah_before = nullptr;
 };
 
-static bool accessor_cache_store(xsi_accessor* a, uint64_t block, const PartialInfo* part = nullptr) {
-    const size_t n_bin = a->P.n_bin ? a->P.n_bin : 1;
-    const size_t plane_b = 4ull * a->D.stride_w * n_bin;
+// protect_current: the block the main thread is serving must stay (the read-ahead thread is making room: cur_block is read
+// under the lock, where the main thread sets it on a cache hit)
+static bool accessor_cache_build(xsi_accessor* a, xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D, bool biallelic,
+                                 uint64_t block, const PartialInfo* part, bool protect_current, xsi_accessor::CachedBlock* out) {
+    const size_t n_bin = P.n_bin ? P.n_bin : 1;
+    const size_t plane_b = 4ull * D.stride_w * n_bin;
     auto al = [](size_t v) { return (v + 255u) & ~(size_t)255u; };
-    const bool side = a->D.has_side;
+    const bool side = D.has_side;
     const size_t need = al(plane_b) * (side ? 4u : 1u) + al(n_bin) * (side ? 2u : 1u) + al(4 * n_bin + 64) * 4u +
-                        al(sizeof(DecBlock)) + (part ? al(part->state_bytes) : 0u);
-    if (need > a->cache_budget) return false;
-    while (a->cache_bytes + need > a->cache_budget && !a->cache.empty()) {
-        size_t lru = 0;
-        for (size_t i = 1; i < a->cache.size(); ++i)
-            if (a->cache[i].last_use < a->cache[lru].last_use) lru = i;
-        accessor_evict(a, lru);
-    }
+                        al(sizeof(DecBlock)) + (part ? al(part->state_bytes) + 6u * al(4 * n_bin + 64) : 0u);
     uint8_t* mem = nullptr;
-    while (hipMalloc((void**)&mem, need) != hipSuccess) {
-        (void)hipGetLastError();
-        if (a->cache.empty()) return false;
-        size_t lru = 0;
-        for (size_t i = 1; i < a->cache.size(); ++i)
-            if (a->cache[i].last_use < a->cache[lru].last_use) lru = i;
-        accessor_evict(a, lru);
+    {
+        std::lock_guard<std::mutex> lk(a->cache_m);
+        const int64_t protect = protect_current && !a->cur_in_workspace ? a->cur_block : -1;
+        if (need > a->cache_budget) return false;
+        while (a->cache_bytes + need > a->cache_budget) {
+            CacheIt lru = accessor_lru(a, protect);
+            if (lru == a->cache.end()) return false;
+            accessor_evict(a, lru);
+        }
+        while (hipMalloc((void**)&mem, need) != hipSuccess) {
+            (void)hipGetLastError();
+            CacheIt lru = accessor_lru(a, protect);
+            if (lru == a->cache.end()) return false;
+            accessor_evict(a, lru);
+        }
+        a->cache_bytes += need;  // reserved; given back below if the copy fails
     }
-    hipStream_t s = a->ctx->stream;
+    hipStream_t s = ctx->stream;
     size_t off = 0;
     bool ok = true;
     auto take = [&](const void* src, size_t bytes) -> void* {
@@ -851,21 +893,21 @@ static bool accessor_cache_store(xsi_accessor* a, uint64_t block, const PartialI
         off += al(bytes);
         return dst;
     };
-    xsi_accessor::CachedBlock e;
-    e.P = a->P;
-    e.D = a->D;
-    e.D.planes = (uint32_t*)take(a->D.planes, plane_b);
-    e.P.L.kind = (uint8_t*)take(a->P.L.kind, n_bin);
-    e.P.L.ones = (uint32_t*)take(a->P.L.ones, 4 * n_bin);
-    e.P.L.line_block = (uint32_t*)take(a->P.L.line_block, 4 * n_bin);
-    e.D.n_miss = (uint32_t*)take(a->D.n_miss, 4 * n_bin + 64);
-    e.D.n_eov = (uint32_t*)take(a->D.n_eov, 4 * n_bin + 64);
-    e.P.d_blocks = (DecBlock*)take(a->P.d_blocks, sizeof(DecBlock));
+    xsi_accessor::CachedBlock& e = *out;
+    e.P = P;
+    e.D = D;
+    e.D.planes = (uint32_t*)take(D.planes, plane_b);
+    e.P.L.kind = (uint8_t*)take(P.L.kind, n_bin);
+    e.P.L.ones = (uint32_t*)take(P.L.ones, 4 * n_bin);
+    e.P.L.line_block = (uint32_t*)take(P.L.line_block, 4 * n_bin);
+    e.D.n_miss = (uint32_t*)take(D.n_miss, 4 * n_bin + 64);
+    e.D.n_eov = (uint32_t*)take(D.n_eov, 4 * n_bin + 64);
+    e.P.d_blocks = (DecBlock*)take(P.d_blocks, sizeof(DecBlock));
     if (side) {
-        e.D.side = (uint8_t*)take(a->D.side, n_bin);
-        e.D.miss_planes = (uint32_t*)take(a->D.miss_planes, plane_b);
-        e.D.eov_planes = (uint32_t*)take(a->D.eov_planes, plane_b);
-        e.D.phase_planes = (uint32_t*)take(a->D.phase_planes, plane_b);
+        e.D.side = (uint8_t*)take(D.side, n_bin);
+        e.D.miss_planes = (uint32_t*)take(D.miss_planes, plane_b);
+        e.D.eov_planes = (uint32_t*)take(D.eov_planes, plane_b);
+        e.D.phase_planes = (uint32_t*)take(D.phase_planes, plane_b);
     }
     if (part) {
         e.partial = true;
@@ -873,18 +915,35 @@ static bool accessor_cache_store(xsi_accessor* a, uint64_t block, const PartialI
         e.d_state = (uint32_t*)take(part->ws_state, part->state_bytes);
         e.d_walk = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(e.d_state) + part->state_bytes - 64u);
         e.wah_before = *part->wah_before;
+        // the parsed plan: what a continuation reads instead of parsing and scanning the block again
+        e.P.L.rank = (uint32_t*)take(P.L.rank, 4 * n_bin + 64);
+        e.P.L.wah_start = (decltype(e.P.L.wah_start))take(P.L.wah_start, 4 * n_bin + 64);
+        e.P.L.sparse_start = (decltype(e.P.L.sparse_start))take(P.L.sparse_start, 4 * n_bin + 64);
+        e.P.L.wah_lines = (uint32_t*)take(P.L.wah_lines, 4 * n_bin + 64);
+        e.P.L.sparse_lines = (uint32_t*)take(P.L.sparse_lines, 4 * n_bin + 64);
+        e.P.L.wah_cumg = (decltype(e.P.L.wah_cumg))take(P.L.wah_cumg, 4 * n_bin + 64);
+        e.has_plan = true;
     }
     if (!ok || hipStreamSynchronize(s) != hipSuccess || off > need) {
         (void)hipGetLastError();
         (void)hipFree(mem);
+        std::lock_guard<std::mutex> lk(a->cache_m);
+        a->cache_bytes -= need;
         return false;
     }
     e.block = block;
-    e.last_use = ++a->tick;
     e.bytes = need;
     e.mem = mem;
-    e.biallelic = a->biallelic;
-    a->cache_bytes += need;
+    e.biallelic = biallelic;
+    return true;
+}
+
+// The block the main thread has just decoded in its context's workspace -> cache; (P, D) repointed at the entry.
+static bool accessor_cache_store(xsi_accessor* a, uint64_t block, const PartialInfo* part = nullptr) {
+    xsi_accessor::CachedBlock e;
+    if (!accessor_cache_build(a, a->ctx, a->P, a->D, a->biallelic, block, part, false, &e)) return false;
+    std::lock_guard<std::mutex> lk(a->cache_m);
+    e.last_use = ++a->tick;
     a->P = e.P;
     a->D = e.D;
     a->cache.push_back(std::move(e));
@@ -914,25 +973,41 @@ static uint32_t bin_valid_of(const std::vector<uint32_t>& wah_before, uint32_t n
 // The current block is a prefix-decoded cache entry and the caller is about to read binary lines below need_bin (0: all):
 // run the chain on from where it stopped (the reference's seek does the same replay, one line at a time, on the host:
 // accessor_internals_new.hpp:154-196).
+static bool accessor_sequential(const xsi_accessor* a) { return a->seq_run >= 4u && !tuning_env("XSI_ACCESSOR_NO_READAHEAD"); }
+
 static int accessor_ensure_lines(xsi_accessor* a, uint32_t need_bin) {
     if (a->cur_block < 0 || a->cur_in_workspace) return XSI_OK;
-    xsi_accessor::CachedBlock* e = nullptr;
-    for (auto& c : a->cache)
-        if (c.block == (uint64_t)a->cur_block) e = &c;
+    xsi_accessor::CachedBlock* e;
+    {
+        std::lock_guard<std::mutex> lk(a->cache_m);
+        e = accessor_find(a, (uint64_t)a->cur_block);  // (entries keep their address; the read-ahead thread never evicts this one)
+    }
     if (!e || !e->partial) return XSI_OK;
     const uint32_t n_wah = e->P.n_wah;
-    const uint32_t target = prefix_target(e->wah_before, n_wah, e->wah_done, need_bin);
+    // a sequential scan will read the whole block: one continuation to its end instead of a dozen growing ones
+    const uint32_t target = accessor_sequential(a) && prefix_target(e->wah_before, n_wah, e->wah_done, need_bin) > e->wah_done
+                                ? n_wah
+                                : prefix_target(e->wah_before, n_wah, e->wah_done, need_bin);
     if (target <= e->wah_done) return XSI_OK;
     const uint8_t* img;
     uint64_t len, blk;
     int rc = accessor_block_image(a, (uint64_t)a->cur_block, &img, &len, &blk);
     if (rc) return rc;
     DecodePlan Pt;
-    rc = decode_prepare(a->ctx, img, len, blk, 1, &Pt);
-    if (rc) return rc;
-    Pt.L.ones = e->P.L.ones;  // the expansion writes the new lines' counts next to the ones already there
+    const bool keep_plan = e->has_plan && !tuning_env("XSI_ACCESSOR_REPARSE");
+    if (keep_plan) {
+        // the parsed plan of the first decode (dictionary, flag vectors, line lists, WAH line starts) is the entry's; only
+        // the scratch (expanded rows, tiles, totals) is the context's
+        Pt = e->P;
+        rc = decode_plan_scratch(a->ctx, &Pt, /*restore_totals=*/true);
+        if (rc) return rc;
+    } else {
+        rc = decode_prepare(a->ctx, img, len, blk, 1, &Pt);
+        if (rc) return rc;
+        Pt.L.ones = e->P.L.ones;  // the expansion writes the new lines' counts next to the ones already there
+    }
     PartialDecode pd{e->wah_done, target, e->d_state, false, bin_valid_of(e->wah_before, n_wah, e->wah_done),
-                     bin_valid_of(e->wah_before, n_wah, target), e->d_walk};
+                     bin_valid_of(e->wah_before, n_wah, target), e->d_walk, keep_plan};
     DecodedPlanes Dv = e->D;
     rc = decode_all_planes(a->ctx, img, Pt, &Dv, &pd);
     if (rc) return rc;
@@ -943,21 +1018,87 @@ static int accessor_ensure_lines(xsi_accessor* a, uint32_t need_bin) {
     return XSI_OK;
 }
 
+// ---- read-ahead: block b + 1 of a sequential scan, decoded whole by a thread of its own into the cache
+static void accessor_readahead_join(xsi_accessor* a) {
+    if (a->pf_started) {
+        a->pf_thread.join();
+        a->pf_started = false;
+    }
+}
+
+static void accessor_readahead_body(xsi_accessor* a, uint64_t block) {
+    // (errors end the attempt silently: the main thread decodes the block itself when it gets there)
+    if (hipSetDevice(a->ctx->device) != hipSuccess) return;
+    DecodePlan P;
+    DecodedPlanes D;
+    if (decode_prepare(a->pf_ctx, a->d_file, a->file.size(), block, 1, &P)) return;
+    if (decode_all_planes(a->pf_ctx, a->d_file, P, &D)) return;
+    xsi_accessor::CachedBlock e;
+    if (!accessor_cache_build(a, a->pf_ctx, P, D, P.n_bin == P.n_bcf, block, nullptr, true, &e)) return;
+    std::lock_guard<std::mutex> lk(a->cache_m);
+    if (accessor_find(a, block)) {  // (the main thread got there first)
+        (void)hipFree(e.mem);
+        a->cache_bytes -= e.bytes;
+        return;
+    }
+    e.last_use = ++a->tick;
+    a->cache.push_back(std::move(e));
+}
+
+// called behind a served query of a sequential scan in block `cur`
+static void accessor_readahead_maybe(xsi_accessor* a, uint64_t cur) {
+    const uint64_t next = cur + 1u;
+    if (next >= a->n_blocks || a->zstd || a->pf_block == (int64_t)next || !accessor_sequential(a)) return;
+    {
+        std::lock_guard<std::mutex> lk(a->cache_m);
+        if (accessor_find(a, next)) return;
+        // room for the block being served and the next one, or the read-ahead would throw out what is being read
+        xsi_accessor::CachedBlock* c = accessor_find(a, cur);
+        if (!c || 2u * c->bytes + (c->bytes >> 2) > a->cache_budget) return;
+    }
+    accessor_readahead_join(a);
+    if (!a->pf_ctx) {
+        if (xsi_hip_ctx_create(&a->pf_ctx, a->ctx->device, nullptr) != XSI_OK) {
+            a->pf_ctx = nullptr;
+            a->pf_block = (int64_t)next;  // (not tried again for this block)
+            return;
+        }
+    }
+    a->pf_block = (int64_t)next;
+    ++a->readahead_started;
+    a->pf_thread = std::thread([a, next] {
+        try {
+            accessor_readahead_body(a, next);
+        } catch (...) {
+        }
+    });
+    a->pf_started = true;
+}
+
 // need_bin: the binary lines below it are what the caller reads first (0: the whole block); a cold block is decoded up
 // to there (prefix decode) when the ranged chain takes it and the cache can hold it
 static int accessor_load_block(xsi_accessor* a, uint64_t block, uint32_t need_bin = 0) {
-    for (auto& e : a->cache)
-        if (e.block == block) {
-            e.last_use = ++a->tick;
-            a->P = e.P;
-            a->D = e.D;
-            a->biallelic = e.biallelic;
+    if (a->pf_started && a->pf_block == (int64_t)block) accessor_readahead_join(a);  // the read-ahead is at this very block: take its result
+    {
+        std::unique_lock<std::mutex> lk(a->cache_m);
+        if (xsi_accessor::CachedBlock* e = accessor_find(a, block)) {
+            e->last_use = ++a->tick;
+            a->P = e->P;
+            a->D = e->D;
+            a->biallelic = e->biallelic;
             a->cur_block = (int64_t)block;
             a->cur_in_workspace = false;
             a->win_n = 0;
             ++a->cache_hits;
-            return e.partial ? accessor_ensure_lines(a, need_bin) : XSI_OK;
+            if (a->pf_block == (int64_t)block) ++a->readahead_hits;
+            const bool partial = e->partial;
+            lk.unlock();
+            return partial ? accessor_ensure_lines(a, need_bin) : XSI_OK;
         }
+    }
+    // a decode in this thread reuses the context workspace the current block may live in, and evicts: the read-ahead thread
+    // must not be making room at the same time with a stale idea of what is being served
+    accessor_readahead_join(a);
     ++a->cache_misses;
     // XSI_ACCESSOR_PROF=1: wall clock of the pieces of a first touch (synchronising between them) on stderr
     const bool prof = tuning_env("XSI_ACCESSOR_PROF") != nullptr;
@@ -990,7 +1131,7 @@ static int accessor_load_block(xsi_accessor* a, uint64_t block, uint32_t need_bi
     a->cnt_block = -1;
     a->win_n = 0;
     const bool want_prefix = need_bin && need_bin < a->P.n_bin && a->P.n_wah >= 64u && decode_partial_supported(a->P) &&
-                             !tuning_env("XSI_ACCESSOR_FULL_DECODE");
+                             !tuning_env("XSI_ACCESSOR_FULL_DECODE") && !accessor_sequential(a);  // (a scan reads every line anyway)
     if (want_prefix) {
         hipStream_t s = a->ctx->stream;
         std::vector<uint8_t> kind(a->P.n_bin);
@@ -1259,23 +1400,32 @@ int xsi_accessor_open(xsi_accessor** out, xsi_hip_ctx* ctx, const char* path) {
 
 int xsi_accessor_set_cache_bytes(xsi_accessor* a, uint64_t bytes) {
     if (!a) return set_error(XSI_ERR_ARG, "set_cache_bytes: null accessor");
+    accessor_readahead_join(a);
+    std::lock_guard<std::mutex> lk(a->cache_m);
     a->cache_budget = (size_t)bytes;
     while (a->cache_bytes > a->cache_budget && !a->cache.empty()) {
-        size_t lru = 0;
-        for (size_t i = 1; i < a->cache.size(); ++i)
-            if (a->cache[i].last_use < a->cache[lru].last_use) lru = i;
-        if (a->cur_block >= 0 && !a->cur_in_workspace && a->cache[lru].block == (uint64_t)a->cur_block) a->cur_block = -1;
+        CacheIt lru = accessor_lru(a, -1);
+        if (a->cur_block >= 0 && !a->cur_in_workspace && lru->block == (uint64_t)a->cur_block) a->cur_block = -1;
         accessor_evict(a, lru);
     }
+    a->pf_block = -1;  // (what was read ahead may be gone)
     return XSI_OK;
 }
 
 int xsi_accessor_cache_stats(const xsi_accessor* a, uint64_t* blocks, uint64_t* bytes, uint64_t* hits, uint64_t* misses) {
     if (!a) return set_error(XSI_ERR_ARG, "cache_stats: null accessor");
+    std::lock_guard<std::mutex> lk(const_cast<xsi_accessor*>(a)->cache_m);
     if (blocks) *blocks = a->cache.size();
     if (bytes) *bytes = a->cache_bytes;
     if (hits) *hits = a->cache_hits;
     if (misses) *misses = a->cache_misses;
+    return XSI_OK;
+}
+
+int xsi_accessor_readahead_stats(const xsi_accessor* a, uint64_t* started, uint64_t* hits) {
+    if (!a) return set_error(XSI_ERR_ARG, "readahead_stats: null accessor");
+    if (started) *started = a->readahead_started;
+    if (hits) *hits = a->readahead_hits;
     return XSI_OK;
 }
 
@@ -1402,10 +1552,20 @@ static int64_t accessor_line_view(xsi_accessor* a, uint32_t n_alleles, uint64_t 
     // AccessorInternalsNewTemplate::seek, accessor_internals_new.hpp:722-738
     const uint64_t block = (position & 0xFFFFFFFFull) >> BM_BLOCK_BITS;
     const uint32_t offset = (uint32_t)(position & ((1u << BM_BLOCK_BITS) - 1u));
+    // does this query follow the one before, line by line (the next binary line of the same block, or the first line of the
+    // next block)?  Counted before the block is loaded: the count decides how it is decoded.
+    if ((a->seq_block == (int64_t)block && offset == a->seq_next) || (a->seq_block + 1 == (int64_t)block && offset == 0u && a->seq_block >= 0)) {
+        if (a->seq_run < 0x7FFFFFFFu) ++a->seq_run;
+    } else {
+        a->seq_run = 0;
+    }
+    a->seq_block = (int64_t)block;
+    a->seq_next = offset + (n_alleles - 1u);
     if (a->cur_block < 0 || (uint64_t)a->cur_block != block) {
         int rc = accessor_load_block(a, block, offset + (n_alleles - 1u));
         if (rc) return rc;
     }
+    if (!a->cur_in_workspace) accessor_readahead_maybe(a, block);  // (a no-op unless the scan is sequential and block + 1 is cold)
     if (offset + (n_alleles - 1) > a->P.n_bin)
         return set_error(XSI_ERR_ARG, "position offset %u (+%u alleles) beyond the %u binary lines of block %llu", offset,
                          n_alleles - 1, a->P.n_bin, (unsigned long long)block);
@@ -1827,6 +1987,8 @@ const char* xsi_accessor_sample_name(const xsi_accessor* a, uint64_t i) {
 
 void xsi_accessor_close(xsi_accessor* a) {
     if (!a) return;
+    accessor_readahead_join(a);
+    if (a->pf_ctx) xsi_hip_ctx_destroy(a->pf_ctx);
     if (a->ctx) (void)hipStreamSynchronize(a->ctx->stream);
     accessor_drop_registration(a);
     for (auto& e : a->owned_arrays) (void)hipHostFree(e.first);  // (arrays of xsi_accessor_alloc_array the caller did not free)
