@@ -55,6 +55,11 @@ namespace {
 struct ZstdApi {
     size_t (*compress)(void*, size_t, const void*, size_t, int) = nullptr;
     size_t (*decompress)(void*, size_t, const void*, size_t) = nullptr;
+    // (optional) an explicit compression context, reused by a pool thread: ZSTD_compressCCtx is ZSTD_compress with the
+    // context handed in - the same frame bytes - without the allocation and release of its tables on every block
+    void* (*create_cctx)() = nullptr;
+    size_t (*free_cctx)(void*) = nullptr;
+    size_t (*compress_cctx)(void*, void*, size_t, const void*, size_t, int) = nullptr;
     unsigned (*is_error)(size_t) = nullptr;
     const char* (*error_name)(size_t) = nullptr;
     bool ok = false;
@@ -69,6 +74,10 @@ const ZstdApi& zstd_api() {
         a.decompress = reinterpret_cast<decltype(a.decompress)>(dlsym(h, "ZSTD_decompress"));
         a.is_error = reinterpret_cast<decltype(a.is_error)>(dlsym(h, "ZSTD_isError"));
         a.error_name = reinterpret_cast<decltype(a.error_name)>(dlsym(h, "ZSTD_getErrorName"));
+        a.create_cctx = reinterpret_cast<decltype(a.create_cctx)>(dlsym(h, "ZSTD_createCCtx"));
+        a.free_cctx = reinterpret_cast<decltype(a.free_cctx)>(dlsym(h, "ZSTD_freeCCtx"));
+        a.compress_cctx = reinterpret_cast<decltype(a.compress_cctx)>(dlsym(h, "ZSTD_compressCCtx"));
+        if (!a.create_cctx || !a.free_cctx || !a.compress_cctx) a.create_cctx = nullptr;
         a.ok = a.compress && a.decompress && a.is_error;
         return a;
     }();
@@ -96,9 +105,33 @@ struct ZstdPool {
     bool stop = false;
     int level = 0;
     bool prof = false;
+    // Buffers go round: a block's bytes and its frame are megabytes each, and a fresh vector per job is an mmap, a page
+    // fault per 4 KiB and a munmap - with its TLB shoot-down to every core the process runs on - sixteen threads at a time
+    // (measured: a 5 MB block took 75 ms alone and 190 - 300 ms next to seven others).
+    std::vector<std::vector<uint8_t>> spare;
+    std::vector<uint8_t> take_buf() {
+        std::lock_guard<std::mutex> lk(m);
+        if (spare.empty()) return {};
+        std::vector<uint8_t> v = std::move(spare.back());
+        spare.pop_back();
+        return v;
+    }
+    void give_buf(std::vector<uint8_t>&& v) {
+        if (!v.capacity()) return;
+        std::lock_guard<std::mutex> lk(m);
+        if (spare.size() < 128u) spare.push_back(std::move(v));
+    }
     void run() {
         const ZstdApi& z = zstd_api();
         std::vector<uint8_t> scratch;
+        void* cctx = z.create_cctx ? z.create_cctx() : nullptr;
+        struct Free {
+            const ZstdApi& z;
+            void*& c;
+            ~Free() {
+                if (c) z.free_cctx(c);
+            }
+        } free_cctx{z, cctx};
         for (;;) {
             std::shared_ptr<ZstdJob> j;
             {
@@ -117,14 +150,17 @@ struct ZstdPool {
                 // fault per 4 KiB in sixteen threads at once); only the frame's bytes are copied into the job
                 const size_t bound = j->raw.size() + j->raw.size() / 128u + 1024u;  // (above ZSTD_compressBound: size + size / 256 + 64 KiB-block margins)
                 if (scratch.size() < bound) scratch.resize(bound + bound / 4u);
-                cs = z.compress(scratch.data(), scratch.size(), j->raw.data(), j->raw.size(), level);
+                cs = cctx ? z.compress_cctx(cctx, scratch.data(), scratch.size(), j->raw.data(), j->raw.size(), level)
+                          : z.compress(scratch.data(), scratch.size(), j->raw.data(), j->raw.size(), level);
                 if (z.is_error(cs)) {
                     failed = true;
                     err = z.error_name ? z.error_name(cs) : "zstd";
                 } else {
+                    j->frame = take_buf();
                     j->frame.assign(scratch.data(), scratch.data() + cs);
                 }
-                std::vector<uint8_t>().swap(j->raw);
+                give_buf(std::move(j->raw));
+                j->raw = std::vector<uint8_t>();
             } catch (const std::exception& e) {
                 failed = true;
                 err = e.what();
@@ -290,6 +326,7 @@ static int writer_drain_zstd(xsi_writer* w, bool all) {
             if (fputc(0, w->f) == EOF) return set_error(XSI_ERR_IO, "short write");
             w->file_pos++;
         }
+        w->zpool->give_buf(std::move(j->frame));
     }
 }
 
@@ -368,6 +405,7 @@ static int writer_encode_batch(xsi_writer* w, int b, uint64_t n_lines) {
         const uint64_t off = w->h_offs[k] - 256, usize = w->h_sizes[k];
         if (off + usize > w->h_out.size() || usize < 16) return set_error(XSI_ERR_FORMAT, "writer: block %llu of the batch has no sane length", (unsigned long long)k);
         auto j = std::make_shared<ZstdJob>();
+        j->raw = w->zpool->take_buf();
         j->raw.assign(w->h_out.data() + off, w->h_out.data() + off + usize);
         j->usize = usize;
         w->zpool->submit(j);
@@ -500,9 +538,8 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
         if (k > 64) k = 64;
         if (k > fit) k = fit;
         if (const char* e = tuning_env("XSI_WRITER_BATCH_BLOCKS")) k = strtoull(e, nullptr, 10);
-        // --zstd: a block's compression (tens of milliseconds on one core) starts when its batch has been encoded, so small
-        // batches put the pool to work early and shorten the tail behind the last append
-        if (p->zstd_level && k > 4 && !tuning_env("XSI_WRITER_BATCH_BLOCKS")) k = 4;
+        // (--zstd keeps the same batches: a batch costs the chain's latency whatever its size - four-block batches measured
+        // 1.28 against 1.36 G cells/s at 5008 haplotypes -, and the pool takes a batch's blocks side by side)
         if (k < 1) k = 1;
         w->batch_blocks = (uint32_t)k;
     }
