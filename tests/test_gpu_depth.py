@@ -73,6 +73,14 @@ def test_full_depth_block_against_oracle(n_haps, n_lines, thr, kernels, monkeypa
     (5008, 6, 900, 5, dict(XSI_DEC_PHASES_SMALL="1", XSI_DEC_PHASES="5", XSI_RANKENC_MIN_N="2")),   # the batch-staged decode chain in ranges
     (64976, 1, 8192, 64, dict(XSI_RANK_WG_MIN_BLOCKS="1")),   # the kernel instantiation bench.py's default line decodes with (<64>, ramp + equal ranges, two-part boundary scan), one whole block deep
     (64976, 1, 8192, 64, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_DEC_PHASES="1")),   # and in one range
+    # round 6: the position-major decode chain (k_chain_decode_pos) in place of the one-workgroup rank chain
+    (64976, 3, 700, 64, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_POS_DECODE="1")),                      # a partial last chunk (16 of 64 positions), 12 line ranges
+    (64976, 1, 8192, 64, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_POS_DECODE="1", XSI_DEC_PHASES="1")),   # one whole block deep, one range
+    (64976, 1, 8192, 64, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_POS_DECODE="1")),                      # ... in the bench's ranges (array parked between launches)
+    (40000, 4, 777, 40, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_POS_DECODE="1", XSI_DEC_PHASES="7")),    # 625 chunks (odd), 40 per wave, tail chunk in the middle of a wave's slots
+    (40960, 3, 500, 40, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_POS_DECODE="1", XSI_DEC_PHASES="3")),    # N a multiple of 64: no partial chunk
+    (50002, 3, 500, 50, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_POS_DECODE="1", XSI_DEC_PHASES="3")),    # 56 chunks per wave
+    (16450, 5, 600, 16, dict(XSI_RANK_WG_MIN_BLOCKS="1", XSI_POS_DECODE="1")),                       # the smallest size the family takes: 24 chunks per wave
     (24576, 3, 900, 24, dict()),                          # rank-tracking encode below 64 chunks per wave
     (12300, 2, 1200, 12, dict(XSI_RANKENC_MIN_N="2")),
 ])
@@ -84,8 +92,9 @@ def test_chain_kernel_variants_at_depth(n_haps, n_blocks, block_len, thr, force,
     for k, v in force.items():
         monkeypatch.setenv(k, v)
     if "XSI_RANK_WG_MIN_BLOCKS" in force:
-        assert L.xsi_hip_chain_kernel(n_haps, n_blocks, 1).decode() == "k_chain_decode_rank_wg"
-    assert L.xsi_hip_chain_kernel(n_haps, n_blocks, 0).decode() == "k_chain_rank_enc"
+        assert L.xsi_hip_chain_kernel(n_haps, n_blocks, 1).decode() == ("k_chain_decode_pos" if "XSI_POS_DECODE" in force else "k_chain_decode_rank_wg")
+    if "XSI_POS_DECODE" not in force:
+        assert L.xsi_hip_chain_kernel(n_haps, n_blocks, 0).decode() == "k_chain_rank_enc"
     n_lines = n_blocks * block_len
     bits, packed, stride = _device_synth(n_haps, n_lines, 7)
     p = G.params(n_haps // 2, block_len, thr)

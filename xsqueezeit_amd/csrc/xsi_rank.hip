@@ -37,6 +37,8 @@ static uint32_t next_pow2_log2(uint32_t v) {
 // y by the even members of `a`, which needs the permutation itself).
 // ------------------------------------------------------------------------------------------
 typedef uint32_t rank_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t rank_v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t rank_v16u __attribute__((ext_vector_type(16)));
 
 struct RankArgs {
     const DecBlock* blocks;
@@ -638,6 +640,235 @@ __global__ void __launch_bounds__(1024) k_chain_decode_rank_wg(RankArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Position-major decode chain for N <= 65 536 (round 6): k_chain_decode_pos.
+//
+// The element-major kernels walk every haplotype through every WAH line: one random LDS gather and ten vector
+// instructions per 64 haplotypes, whatever the line looks like.  Decode knows the PERMUTED row y_k - it is indexed by
+// POSITION - so a kernel that owns positions gets a chunk's 64 row bits and the ones in front of it as scalars (compact
+// rows: DecLines::yp_compact), and on PBWT-ordered rows most chunks are uniform (at 64 976 haplotypes 66 % of the chunks of
+// a WAH line are all zero, 11 % all one, 23 % mixed).  The stable partition a_{k+1} = [a_k[i] : y = 0] ++ [a_k[i] : y = 1]
+// (gt_block.hpp:124-136; accessor_internals_new.hpp:548-589) moves a uniform chunk as ONE linear run: 64 consecutive
+// 16-bit entries to a destination that is a scalar -
+//     zeros of chunk c  ->  position 64 c - ones_before(c)          ones of chunk c  ->  Z + ones_before(c)
+// - one v_add (lane offset + scalar destination) and one conflict-free ds_write_b16; only a mixed chunk computes per-lane
+// destinations (two v_mbcnt + a select).  `a` lives in registers position-major (lane l of chunk c holds a[64 c + l]): a line
+// scatters the registers into a 16-bit copy of the array in LDS, a barrier, and every lane reads its positions back
+// (linear ds_read_u16 with the chunk in the instruction's offset field: no address arithmetic).  The decoded row is
+// x_k[a_k[i]] = y_k[i]: only the ONES are deposited, with LDS atomic ORs into a row bitmap that leaves with the line.
+// Two barriers a line (the scatter must land before the read-back, the read-back before the next line's scatter).
+// ------------------------------------------------------------------------------------------
+extern "C" __device__ rank_v4u __xsi_s_buffer_load_v4_r(rank_v4u rsrc, uint32_t byte_offset, uint32_t cache_policy)
+    __asm("llvm.amdgcn.s.buffer.load.v4i32");
+extern "C" __device__ rank_v16u __xsi_s_buffer_load_v16_r(rank_v4u rsrc, uint32_t byte_offset, uint32_t cache_policy)
+    __asm("llvm.amdgcn.s.buffer.load.v16i32");
+
+// One chunk of a line of k_chain_decode_pos, written out: the compiler's structurizer turns the three-way uniform branch
+// into flag registers and second branches (8 scalar instructions for a chunk of zeros; the scalar unit issues one
+// instruction per SIMD every fourth clock, like the vector unit, so at 64 chunks x 4 waves they set the pace).  Here a
+// chunk of zeros is s_cmp, branch not taken, v_add, ds_write_b16, s_add.
+//   yb      the chunk's 64 row bits            z2 / o2   byte addresses, in the scattered array, of where my wave's next
+//   lane2   2 x lane                                     zero / next one goes: moved on by what the chunk held
+//   av      the lane's entry of the prefix array (a haplotype): stored at its new position; deposited into the row
+//           bitmap at LDS address 0 when its bit is set
+__device__ __forceinline__ void pos_chunk(uint64_t yb, uint32_t& z2, uint32_t& o2, uint32_t lane2, uint32_t av) {
+    uint32_t t0, t1, sp;
+    uint64_t sx;
+    asm volatile(
+        "s_cmp_lg_u64 %[y], 0\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "v_add_u32_e32 %[t0], %[z2], %[l2]\n\t"
+        "ds_write_b16 %[t0], %[a]\n\t"
+        "s_addk_i32 %[z2], 0x80\n\t"
+        "s_branch 9f\n"
+        "1:\n\t"
+        "s_bcnt1_i32_b64 %[sp], %[y]\n\t"
+        "s_lshl_b32 %[sp], %[sp], 1\n\t"
+        "s_cmp_eq_u64 %[y], -1\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_mov_b64 vcc, %[y]\n\t"
+        "v_mbcnt_lo_u32_b32 %[t0], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t0], vcc_hi, %[t0]\n\t"
+        "v_lshlrev_b32_e32 %[t0], 1, %[t0]\n\t"
+        "v_add_u32_e32 %[t1], %[z2], %[l2]\n\t"
+        "v_sub_u32_e32 %[t1], %[t1], %[t0]\n\t"
+        "v_add_u32_e32 %[t0], %[o2], %[t0]\n\t"
+        "v_cndmask_b32_e32 %[t0], %[t1], %[t0], vcc\n\t"
+        "ds_write_b16 %[t0], %[a]\n\t"
+        "s_branch 3f\n"
+        "2:\n\t"
+        "v_add_u32_e32 %[t0], %[o2], %[l2]\n\t"
+        "ds_write_b16 %[t0], %[a]\n"
+        "3:\n\t"
+        "s_and_saveexec_b64 %[sx], %[y]\n\t"
+        "v_lshrrev_b32_e32 %[t0], 3, %[a]\n\t"
+        "v_and_b32_e32 %[t0], 0x1ffc, %[t0]\n\t"
+        "v_lshlrev_b32_e64 %[t1], %[a], 1\n\t"
+        "ds_or_b32 %[t0], %[t1]\n\t"
+        "s_mov_b64 exec, %[sx]\n\t"
+        "s_add_i32 %[o2], %[o2], %[sp]\n\t"
+        "s_sub_i32 %[z2], %[z2], %[sp]\n\t"
+        "s_addk_i32 %[z2], 0x80\n"
+        "9:"
+        : [z2] "+s"(z2), [o2] "+s"(o2), [t0] "=&v"(t0), [t1] "=&v"(t1), [sp] "=&s"(sp), [sx] "=&s"(sx)
+        : [y] "s"(yb), [l2] "v"(lane2), [a] "v"(av)
+        : "vcc", "scc", "memory");
+}
+
+template <int E>
+__global__ void __launch_bounds__(1024) k_chain_decode_pos(RankArgs A) {
+    constexpr uint32_t T = 1024, W = 16;
+    constexpr int G = 8;
+    static_assert(E % G == 0 && E <= 64, "groups of 8 chunks");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DecBlock& D = A.blocks[blockIdx.x];
+    if (D.error || D.n_wah == 0 || D.off_line_haploid != VAL_UNDEFINED) return;
+    const uint32_t N = A.N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t cg0 = w * E;  // my wave's first chunk
+    const uint32_t wah_first = A.ph_start ? A.ph_start[blockIdx.x] : D.wah_first;
+    const uint32_t n_wah = A.ph_start ? A.ph_cnt[blockIdx.x] : D.n_wah;
+    if (n_wah == 0) return;  // no line of this block in this range: the array stays parked
+    // LDS: [0, ROW_BYTES) the row bitmap of the line (so that a haplotype's word address is two instructions);
+    //      [ROW_BYTES, +2 * 16 E 64) the scattered array (16-bit entries by position)
+    constexpr uint32_t ROW_WORDS = W * E * 2u;  // bits of 16 E chunks
+    constexpr uint32_t ROW_BYTES = ROW_WORDS * 4u;
+    uint32_t* orow = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    if (lds0 != 0u) __builtin_trap();  // (addresses below are formed from positions alone)
+    using LdsU16 = __attribute__((address_space(3))) uint16_t;
+
+    uint32_t a[E];
+    uint32_t* park = A.state + ((size_t)blockIdx.x * (uint32_t)E) * T + tid;  // chunk e of my wave: park[e * T]
+    if (!A.ph_start || wah_first == D.wah_first) {
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            a[e] = (cg0 + (uint32_t)e) * 64u + lane;  // identity (gt_block.hpp:179); positions beyond N never move
+        });
+    } else {
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            a[e] = park[(size_t)e * T];
+        });
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) asm volatile("" : "+v"(a[e]));  // (the parked array has arrived: no pending load rides into the loop)
+    for (uint32_t i = tid; i < ROW_WORDS; i += T) orow[i] = 0;
+    const uint32_t nch = (N + 63u) / 64u;
+    const uint32_t tail_bits = N & 63u;                          // valid positions of the last chunk (0: it is full)
+    const uint32_t lane2 = lane * 2u;
+    uint32_t vm_lo = 0, vm_hi = 0;  // thread t stores the row's words 2 t, 2 t + 1 = chunk t: its bits that exist
+    if ((uint64_t)tid * 64u < N) {
+        const uint64_t left = N - (uint64_t)tid * 64u;
+        const uint64_t vmk = left >= 64u ? ~0ull : (1ull << left) - 1ull;
+        vm_lo = (uint32_t)vmk;
+        vm_hi = (uint32_t)(vmk >> 32);
+    }
+    const uint32_t rb_base = ROW_BYTES + (cg0 * 64u + lane) * 2u;  // my lane's entry of chunk 0 of my wave
+    const uint32_t row_bytes = A.yc_stride * 8u;
+    // my wave's chunks that exist (whole groups beyond the row are skipped by one scalar branch)
+    const uint32_t my_chunks = cg0 >= nch ? 0u : (nch - cg0 < (uint32_t)E ? nch - cg0 : (uint32_t)E);
+    // the slot, among my wave's chunks, of the row's last chunk when that one is partial (else: none)
+    const uint32_t tail_slot0 = (tail_bits && nch - 1u >= cg0 && nch - 1u < cg0 + (uint32_t)E) ? nch - 1u - cg0 : 0xFFFFFF00u;
+    auto rsrc_of = [&](const void* base, uint32_t bytes) -> rank_v4u {
+        const uint64_t b = reinterpret_cast<uint64_t>(base);
+        rank_v4u d;
+        d[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+        d[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xFFFFu));
+        d[2] = bytes;          // beyond the row: zeros
+        d[3] = 0x00020000u;
+        return d;
+    };
+    __syncthreads();
+    for (uint32_t j = 0; j < n_wah; ++j) {
+        const uint32_t rank = wah_first + j;
+        const uint32_t line = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.wah_lines[rank]);
+        const uint32_t Z2 = ROW_BYTES + 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)A.wah_z[rank]);
+        const rank_v4u rs_y = rsrc_of(A.yc + (size_t)rank * A.yc_stride, row_bytes);
+        // The key bits of group g + 1 travel while group g is scattered.  Written out as asm: left to the compiler every
+        // group's loads are hoisted to the top of the line (8 x 16 SGPRs: spilled lane by lane), and scalar loads return out
+        // of order, so the wait for group g stands in front of the request for g + 1.
+        auto request = [&](uint32_t chunk, rank_v16u& y) {
+            asm volatile("s_buffer_load_dwordx16 %0, %1, %2" : "=&s"(y) : "s"(rs_y), "s"(chunk * 8u));
+        };
+        // formed inside the line (hoisted out of it, the per-chunk scalars of all 64 chunks live in SGPRs the kernel does
+        // not have: they were spilled lane by lane and read back with a v_readlane each)
+        uint32_t tail_slot = tail_slot0, cg0_l = cg0;
+        uint64_t tail_pad = tail_bits ? ~((1ull << tail_bits) - 1ull) : 0ull;
+        asm volatile("" : "+s"(tail_slot), "+s"(cg0_l), "+s"(tail_pad));
+        rank_v16u yv;
+        request(cg0_l, yv);
+        // Byte addresses, in the scattered array, of where the next zero and the next one of my wave's positions go: the
+        // prefix of my first chunk starts them, every chunk moves them on by what it held (a scalar instruction a chunk,
+        // where the per-chunk prefixes cost four: the scalar unit issues one instruction per SIMD every fourth clock, like
+        // the vector unit, and a chunk of zeros is otherwise three scalar and one vector instruction)
+        uint32_t z2, o2;
+        {
+            const uint32_t ob0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)A.ypre[(size_t)rank * A.yc_stride + (cg0_l < nch ? cg0_l : 0u)]);
+            z2 = ROW_BYTES + (cg0_l * 64u - (cg0_l < nch ? ob0 : 0u)) * 2u;
+            o2 = Z2 + ob0 * 2u;
+        }
+        static_for<0, E / G>([&](auto gcn) {
+            constexpr int g0 = decltype(gcn)::value * G;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(yv));
+            rank_v16u yn = yv;
+            if constexpr (g0 + G < E) request(cg0_l + (uint32_t)(g0 + G), yn);
+            if ((uint32_t)g0 < my_chunks) {
+                if (tail_slot / (uint32_t)G == (uint32_t)(g0 / G)) {
+                    // Positions at or beyond N (the row's last chunk when N is not a multiple of 64) count as ONES: the
+                    // partition then keeps them where they are, behind the N real entries ([zeros][ones][pads]), with no
+                    // case of their own; what they deposit into the row lies beyond bit N and is masked when the row leaves.
+                    static_for<0, G>([&](auto ecn) {
+                        constexpr int e = decltype(ecn)::value;
+                        if ((tail_slot & (uint32_t)(G - 1)) == (uint32_t)e) {
+                            yv[2 * e] |= (uint32_t)tail_pad;
+                            yv[2 * e + 1] |= (uint32_t)(tail_pad >> 32);
+                        }
+                    });
+                }
+                static_for<0, G>([&](auto ecn) {
+                    constexpr int e = decltype(ecn)::value;
+                    constexpr int c = g0 + e;
+                    const uint64_t yb = ((uint64_t)yv[2 * e + 1] << 32) | yv[2 * e];
+                    // (chunks beyond the row read as zeros: they move onto themselves)
+                    pos_chunk(yb, z2, o2, lane2, a[c]);
+                });
+            }
+            yv = yn;
+        });
+        lds_barrier();  // the scattered array and the row are complete
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            a[e] = (uint32_t)*reinterpret_cast<const LdsU16*>((uintptr_t)(rb_base + (uint32_t)e * 128u));
+        });
+        {
+            uint32_t* orow_g = A.out + (size_t)line * A.out_stride_w;
+            uint2 v = make_uint2(0u, 0u);
+            if (2u * tid < ROW_WORDS) {
+                v = *reinterpret_cast<const uint2*>(orow + 2u * tid);
+                *reinterpret_cast<uint2*>(orow + 2u * tid) = make_uint2(0u, 0u);  // ready for the next line (behind the barrier below)
+                v.x &= vm_lo;  // (the pads' deposits)
+                v.y &= vm_hi;
+            }
+            if (2u * tid + 1u < A.out_stride_w) {
+                rank_u32x2 ov = {v.x, v.y};
+                __builtin_nontemporal_store(ov, reinterpret_cast<rank_u32x2*>(orow_g) + tid);
+            } else if (2u * tid < A.out_stride_w) {
+                orow_g[2u * tid] = v.x;
+            }
+            for (uint32_t i = 2u * T + tid; i < A.out_stride_w; i += T) orow_g[i] = 0;  // rows padded past 2048 words
+        }
+        lds_barrier();  // everyone has read its positions back: the next line may scatter
+    }
+    if (A.ph_start && wah_first + n_wah != D.wah_first + D.n_wah) {
+        static_for<0, E>([&](auto ecn) {
+            constexpr int e = decltype(ecn)::value;
+            park[(size_t)e * T] = a[e];
+        });
+    }
+}
+
 struct RankGeom {
     int T, E;
     uint32_t splits, batch, lds_bytes, log2_cwp;
@@ -844,13 +1075,42 @@ static bool use_rank_wg(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
 }
 
 const char* rank_decode_kernel_name(uint32_t N, uint32_t yp_stride, uint32_t n_blocks) {
-    if (use_rank_wg(N, yp_stride, n_blocks)) return "k_chain_decode_rank_wg";
+    if (use_rank_wg(N, yp_stride, n_blocks))
+        return (N <= 65536u && tuning_env("XSI_POS_DECODE") && !tuning_env("XSI_NO_COMPACT_YP")) ? "k_chain_decode_pos" : "k_chain_decode_rank_wg";
     return N >= 49152u ? "k_chain_decode_rank_big" : "k_chain_decode_rank";
+}
+
+static hipError_t launch_pos(hipStream_t s, uint32_t n_blocks, const RankArgs& R, uint32_t e) {
+    const uint32_t lds = 16u * e * 64u * 2u + 16u * e * 2u * 4u;
+#define XSI_POS_CASE(EE)                                                                                   \
+    if (e == EE) {                                                                                          \
+        auto kern = &k_chain_decode_pos<EE>;                                                                \
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                           \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        if (err != hipSuccess) return err;                                                                  \
+        kern<<<dim3(n_blocks), dim3(1024), lds, s>>>(R);                                                    \
+        return hipGetLastError();                                                                           \
+    }
+    XSI_POS_CASE(16)
+    XSI_POS_CASE(24)
+    XSI_POS_CASE(32)
+    XSI_POS_CASE(40)
+    XSI_POS_CASE(48)
+    XSI_POS_CASE(56)
+    XSI_POS_CASE(64)
+#undef XSI_POS_CASE
+    return hipErrorInvalidValue;
+}
+
+// position-major chain (k_chain_decode_pos): compact rows (8-byte chunks: every row base is dword-aligned for the scalar loads)
+static bool use_pos_decode(const RankArgs& R) {
+    return R.yc && R.ypre && R.N <= 65536u && tuning_env("XSI_POS_DECODE") != nullptr;
 }
 
 static hipError_t launch_rank_wg(hipStream_t s, uint32_t n_blocks, const RankArgs& R) {
     const uint32_t nch = (R.N + 63u) / 64u;
     const uint32_t e = ((nch + 15u) / 16u + 7u) / 8u * 8u;  // chunks per wave, multiple of 8
+    if (use_pos_decode(R)) return launch_pos(s, n_blocks, R, e);
     const uint32_t lds = 2u * 16384u;
 #define XSI_WG_CASE(EE)                                                                                    \
     if (e == EE) {                                                                                          \
