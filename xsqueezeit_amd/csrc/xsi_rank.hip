@@ -663,57 +663,69 @@ extern "C" __device__ rank_v4u __xsi_s_buffer_load_v4_r(rank_v4u rsrc, uint32_t 
 extern "C" __device__ rank_v16u __xsi_s_buffer_load_v16_r(rank_v4u rsrc, uint32_t byte_offset, uint32_t cache_policy)
     __asm("llvm.amdgcn.s.buffer.load.v16i32");
 
-// One chunk of a line of k_chain_decode_pos, written out: the compiler's structurizer turns the three-way uniform branch
-// into flag registers and second branches (8 scalar instructions for a chunk of zeros; the scalar unit issues one
-// instruction per SIMD every fourth clock, like the vector unit, so at 64 chunks x 4 waves they set the pace).  Here a
-// chunk of zeros is s_cmp, branch not taken, v_add, ds_write_b16, s_add.
-//   yb      the chunk's 64 row bits            z2 / o2   byte addresses, in the scattered array, of where my wave's next
-//   lane2   2 x lane                                     zero / next one goes: moved on by what the chunk held
-//   av      the lane's entry of the prefix array (a haplotype): stored at its new position; deposited into the row
+// Eight chunks of a line of k_chain_decode_pos, written out.  The compiler's structurizer turns the three-way uniform branch of
+// a chunk into flag registers and second branches (8 scalar instructions for a chunk of zeros; the scalar unit issues one
+// instruction per SIMD every fourth clock, like the vector unit, so at 64 chunks x 4 waves they set the pace).  Here a chunk of
+// zeros is s_cmp, a branch not taken, v_add, ds_write_b16, s_addk, and falls into the next chunk's compare; the other two
+// cases stand behind the eight fast paths and jump back.
+//   y[k]    the chunk's 64 row bits            z2 / o2   byte addresses, in the scattered array, of where my wave's next
+//   lane2   2 x lane                                     zero / next one goes: moved on by what each chunk held
+//   a[k]    the lane's entry of the prefix array (a haplotype): stored at its new position; deposited into the row
 //           bitmap at LDS address 0 when its bit is set
-__device__ __forceinline__ void pos_chunk(uint64_t yb, uint32_t& z2, uint32_t& o2, uint32_t lane2, uint32_t av) {
+#define XSI_POS_FAST(K)                                  \
+    "s_cmp_lg_u64 %[y" #K "], 0\n\t"                     \
+    "s_cbranch_scc1 1" #K "f\n\t"                        \
+    "v_add_u32_e32 %[t0], %[z2], %[l2]\n\t"              \
+    "ds_write_b16 %[t0], %[a" #K "]\n\t"                 \
+    "s_addk_i32 %[z2], 0x80\n"                           \
+    "2" #K ":\n\t"
+#define XSI_POS_SLOW(K)                                  \
+    "1" #K ":\n\t"                                       \
+    "s_bcnt1_i32_b64 %[sp], %[y" #K "]\n\t"              \
+    "s_lshl_b32 %[sp], %[sp], 1\n\t"                     \
+    "s_cmp_eq_u64 %[y" #K "], -1\n\t"                    \
+    "s_cbranch_scc1 3" #K "f\n\t"                        \
+    "s_mov_b64 vcc, %[y" #K "]\n\t"                      \
+    "v_mbcnt_lo_u32_b32 %[t0], vcc_lo, 0\n\t"           \
+    "v_mbcnt_hi_u32_b32 %[t0], vcc_hi, %[t0]\n\t"       \
+    "v_lshlrev_b32_e32 %[t0], 1, %[t0]\n\t"             \
+    "v_add_u32_e32 %[t1], %[z2], %[l2]\n\t"             \
+    "v_sub_u32_e32 %[t1], %[t1], %[t0]\n\t"             \
+    "v_add_u32_e32 %[t0], %[o2], %[t0]\n\t"             \
+    "v_cndmask_b32_e32 %[t0], %[t1], %[t0], vcc\n\t"    \
+    "ds_write_b16 %[t0], %[a" #K "]\n\t"                 \
+    "s_branch 4" #K "f\n"                                \
+    "3" #K ":\n\t"                                       \
+    "v_add_u32_e32 %[t0], %[o2], %[l2]\n\t"             \
+    "ds_write_b16 %[t0], %[a" #K "]\n"                    \
+    "4" #K ":\n\t"                                       \
+    "s_and_saveexec_b64 %[sx], %[y" #K "]\n\t"           \
+    "v_lshrrev_b32_e32 %[t0], 3, %[a" #K "]\n\t"         \
+    "v_and_b32_e32 %[t0], 0x1ffc, %[t0]\n\t"            \
+    "v_lshlrev_b32_e64 %[t1], %[a" #K "], 1\n\t"         \
+    "ds_or_b32 %[t0], %[t1]\n\t"                        \
+    "s_mov_b64 exec, %[sx]\n\t"                         \
+    "s_add_i32 %[o2], %[o2], %[sp]\n\t"                 \
+    "s_sub_i32 %[z2], %[z2], %[sp]\n\t"                 \
+    "s_addk_i32 %[z2], 0x80\n\t"                        \
+    "s_branch 2" #K "b\n"
+__device__ __forceinline__ void pos_group8(const uint64_t (&y)[8], uint32_t& z2, uint32_t& o2, uint32_t lane2, uint32_t a0,
+                                           uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7) {
     uint32_t t0, t1, sp;
     uint64_t sx;
+    const uint64_t y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3], y4 = y[4], y5 = y[5], y6 = y[6], y7 = y[7];
     asm volatile(
-        "s_cmp_lg_u64 %[y], 0\n\t"
-        "s_cbranch_scc1 1f\n\t"
-        "v_add_u32_e32 %[t0], %[z2], %[l2]\n\t"
-        "ds_write_b16 %[t0], %[a]\n\t"
-        "s_addk_i32 %[z2], 0x80\n\t"
-        "s_branch 9f\n"
-        "1:\n\t"
-        "s_bcnt1_i32_b64 %[sp], %[y]\n\t"
-        "s_lshl_b32 %[sp], %[sp], 1\n\t"
-        "s_cmp_eq_u64 %[y], -1\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "s_mov_b64 vcc, %[y]\n\t"
-        "v_mbcnt_lo_u32_b32 %[t0], vcc_lo, 0\n\t"
-        "v_mbcnt_hi_u32_b32 %[t0], vcc_hi, %[t0]\n\t"
-        "v_lshlrev_b32_e32 %[t0], 1, %[t0]\n\t"
-        "v_add_u32_e32 %[t1], %[z2], %[l2]\n\t"
-        "v_sub_u32_e32 %[t1], %[t1], %[t0]\n\t"
-        "v_add_u32_e32 %[t0], %[o2], %[t0]\n\t"
-        "v_cndmask_b32_e32 %[t0], %[t1], %[t0], vcc\n\t"
-        "ds_write_b16 %[t0], %[a]\n\t"
-        "s_branch 3f\n"
-        "2:\n\t"
-        "v_add_u32_e32 %[t0], %[o2], %[l2]\n\t"
-        "ds_write_b16 %[t0], %[a]\n"
-        "3:\n\t"
-        "s_and_saveexec_b64 %[sx], %[y]\n\t"
-        "v_lshrrev_b32_e32 %[t0], 3, %[a]\n\t"
-        "v_and_b32_e32 %[t0], 0x1ffc, %[t0]\n\t"
-        "v_lshlrev_b32_e64 %[t1], %[a], 1\n\t"
-        "ds_or_b32 %[t0], %[t1]\n\t"
-        "s_mov_b64 exec, %[sx]\n\t"
-        "s_add_i32 %[o2], %[o2], %[sp]\n\t"
-        "s_sub_i32 %[z2], %[z2], %[sp]\n\t"
-        "s_addk_i32 %[z2], 0x80\n"
-        "9:"
+        XSI_POS_FAST(0) XSI_POS_FAST(1) XSI_POS_FAST(2) XSI_POS_FAST(3) XSI_POS_FAST(4) XSI_POS_FAST(5) XSI_POS_FAST(6) XSI_POS_FAST(7)
+        "s_branch 99f\n"
+        XSI_POS_SLOW(0) XSI_POS_SLOW(1) XSI_POS_SLOW(2) XSI_POS_SLOW(3) XSI_POS_SLOW(4) XSI_POS_SLOW(5) XSI_POS_SLOW(6) XSI_POS_SLOW(7)
+        "99:"
         : [z2] "+s"(z2), [o2] "+s"(o2), [t0] "=&v"(t0), [t1] "=&v"(t1), [sp] "=&s"(sp), [sx] "=&s"(sx)
-        : [y] "s"(yb), [l2] "v"(lane2), [a] "v"(av)
+        : [y0] "s"(y0), [y1] "s"(y1), [y2] "s"(y2), [y3] "s"(y3), [y4] "s"(y4), [y5] "s"(y5), [y6] "s"(y6), [y7] "s"(y7),
+          [l2] "v"(lane2), [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [a4] "v"(a4), [a5] "v"(a5), [a6] "v"(a6), [a7] "v"(a7)
         : "vcc", "scc", "memory");
 }
+#undef XSI_POS_FAST
+#undef XSI_POS_SLOW
 
 template <int E>
 __global__ void __launch_bounds__(1024) k_chain_decode_pos(RankArgs A) {
@@ -769,8 +781,11 @@ __global__ void __launch_bounds__(1024) k_chain_decode_pos(RankArgs A) {
     const uint32_t row_bytes = A.yc_stride * 8u;
     // my wave's chunks that exist (whole groups beyond the row are skipped by one scalar branch)
     const uint32_t my_chunks = cg0 >= nch ? 0u : (nch - cg0 < (uint32_t)E ? nch - cg0 : (uint32_t)E);
-    // the slot, among my wave's chunks, of the row's last chunk when that one is partial (else: none)
-    const uint32_t tail_slot0 = (tail_bits && nch - 1u >= cg0 && nch - 1u < cg0 + (uint32_t)E) ? nch - 1u - cg0 : 0xFFFFFF00u;
+    // the slot, among my wave's chunks, of the first chunk that holds positions at or beyond N: the row's last chunk when it
+    // is partial, else the chunk behind it (0xFFFFFF00: none of mine; 0 also when every chunk of mine lies beyond)
+    const uint32_t first_pad_chunk = tail_bits ? nch - 1u : nch;
+    const uint32_t pad_slot0 = first_pad_chunk >= cg0 + (uint32_t)E ? 0xFFFFFF00u : (first_pad_chunk > cg0 ? first_pad_chunk - cg0 : 0u);
+    const uint64_t tail_pad = tail_bits ? ~((1ull << tail_bits) - 1ull) : ~0ull;
     auto rsrc_of = [&](const void* base, uint32_t bytes) -> rank_v4u {
         const uint64_t b = reinterpret_cast<uint64_t>(base);
         rank_v4u d;
@@ -786,6 +801,15 @@ __global__ void __launch_bounds__(1024) k_chain_decode_pos(RankArgs A) {
         const uint32_t line = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.wah_lines[rank]);
         const uint32_t Z2 = ROW_BYTES + 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)A.wah_z[rank]);
         const rank_v4u rs_y = rsrc_of(A.yc + (size_t)rank * A.yc_stride, row_bytes);
+        // The key bits reach the waves through scalar loads of rows nothing has touched before: left alone every group of
+        // every line waits out a round trip to memory (the first form of this kernel: 8.2 us a line, 40 ms at configs[2]).
+        // One coalesced vector load per thread pulls the row of line j + 2 into L2 two lines ahead (as k_chain_rank_enc does).
+        uint2 pf;
+        {
+            const uint32_t jp = j + 2u < n_wah ? j + 2u : j;
+            const uint2* rowp = A.yc + (size_t)(wah_first + jp) * A.yc_stride;
+            pf = rowp[tid < A.yc_stride ? tid : 0u];
+        }
         // The key bits of group g + 1 travel while group g is scattered.  Written out as asm: left to the compiler every
         // group's loads are hoisted to the top of the line (8 x 16 SGPRs: spilled lane by lane), and scalar loads return out
         // of order, so the wait for group g stands in front of the request for g + 1.
@@ -794,9 +818,8 @@ __global__ void __launch_bounds__(1024) k_chain_decode_pos(RankArgs A) {
         };
         // formed inside the line (hoisted out of it, the per-chunk scalars of all 64 chunks live in SGPRs the kernel does
         // not have: they were spilled lane by lane and read back with a v_readlane each)
-        uint32_t tail_slot = tail_slot0, cg0_l = cg0;
-        uint64_t tail_pad = tail_bits ? ~((1ull << tail_bits) - 1ull) : 0ull;
-        asm volatile("" : "+s"(tail_slot), "+s"(cg0_l), "+s"(tail_pad));
+        uint32_t cg0_l = cg0;
+        asm volatile("" : "+s"(cg0_l));
         rank_v16u yv;
         request(cg0_l, yv);
         // Byte addresses, in the scattered array, of where the next zero and the next one of my wave's positions go: the
@@ -815,28 +838,38 @@ __global__ void __launch_bounds__(1024) k_chain_decode_pos(RankArgs A) {
             rank_v16u yn = yv;
             if constexpr (g0 + G < E) request(cg0_l + (uint32_t)(g0 + G), yn);
             if ((uint32_t)g0 < my_chunks) {
-                if (tail_slot / (uint32_t)G == (uint32_t)(g0 / G)) {
-                    // Positions at or beyond N (the row's last chunk when N is not a multiple of 64) count as ONES: the
-                    // partition then keeps them where they are, behind the N real entries ([zeros][ones][pads]), with no
-                    // case of their own; what they deposit into the row lies beyond bit N and is masked when the row leaves.
-                    static_for<0, G>([&](auto ecn) {
-                        constexpr int e = decltype(ecn)::value;
-                        if ((tail_slot & (uint32_t)(G - 1)) == (uint32_t)e) {
-                            yv[2 * e] |= (uint32_t)tail_pad;
-                            yv[2 * e + 1] |= (uint32_t)(tail_pad >> 32);
-                        }
-                    });
-                }
+                uint64_t yq[G];
                 static_for<0, G>([&](auto ecn) {
                     constexpr int e = decltype(ecn)::value;
-                    constexpr int c = g0 + e;
-                    const uint64_t yb = ((uint64_t)yv[2 * e + 1] << 32) | yv[2 * e];
-                    // (chunks beyond the row read as zeros: they move onto themselves)
-                    pos_chunk(yb, z2, o2, lane2, a[c]);
+                    yq[e] = ((uint64_t)yv[2 * e + 1] << 32) | yv[2 * e];
                 });
+                if (__builtin_expect(pad_slot0 < (uint32_t)(g0 + G), 0)) {
+                    // Positions at or beyond N - the end of the row's last chunk when N is not a multiple of 64, and the
+                    // chunks behind it that this group still covers - count as ONES: the partition then keeps them where
+                    // they are, behind the N real entries ([zeros][ones][pads]), with no case of their own; what they
+                    // deposit into the row lies beyond bit N and is masked when the row leaves.  (One group of one wave; in
+                    // asm so that the selects stay in SGPRs: the results of asm statements count as divergent.)
+                    static_for<0, G>([&](auto ecn) {
+                        constexpr int e = decltype(ecn)::value;
+                        uint64_t t, y = yq[e];
+                        const uint32_t ps = (uint32_t)__builtin_amdgcn_readfirstlane((int)pad_slot0);  // (an SGPR operand below)
+                        const uint64_t tp = tail_pad;
+                        asm volatile("s_cmp_eq_u32 %[ps], %[c]\n\t"
+                                     "s_cselect_b64 %[t], %[tp], 0\n\t"
+                                     "s_cmp_lt_u32 %[ps], %[c]\n\t"
+                                     "s_cselect_b64 %[t], -1, %[t]\n\t"
+                                     "s_or_b64 %[y], %[y], %[t]"
+                                     : [y] "+s"(y), [t] "=&s"(t)
+                                     : [ps] "s"(ps), [c] "i"(g0 + e), [tp] "s"(tp)
+                                     : "scc");
+                        yq[e] = y;
+                    });
+                }
+                pos_group8(yq, z2, o2, lane2, a[g0], a[g0 + 1], a[g0 + 2], a[g0 + 3], a[g0 + 4], a[g0 + 5], a[g0 + 6], a[g0 + 7]);
             }
             yv = yn;
         });
+        asm volatile("" ::"v"(pf.x), "v"(pf.y));  // the prefetch has landed (nothing reads the registers)
         lds_barrier();  // the scattered array and the row are complete
         static_for<0, E>([&](auto ecn) {
             constexpr int e = decltype(ecn)::value;
