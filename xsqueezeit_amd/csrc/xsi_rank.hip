@@ -796,47 +796,55 @@ __global__ void __launch_bounds__(1024) k_chain_decode_pos(RankArgs A) {
         return d;
     };
     __syncthreads();
+    // Nothing a line needs may be asked of memory when the line starts (all sixteen waves would wait out the round trip, every
+    // line): its number, its zeros, my wave's first prefix and my wave's first eight chunks are requested a line ahead.
+    const uint32_t pre_idx = cg0 < nch ? cg0 : 0u;
+    uint32_t line_v = A.wah_lines[wah_first], z_v = A.wah_z[wah_first], ob_v = (uint32_t)A.ypre[(size_t)wah_first * A.yc_stride + pre_idx];
+    auto request = [&](const rank_v4u& rs, uint32_t chunk, rank_v16u& y) {
+        asm volatile("s_buffer_load_dwordx16 %0, %1, %2" : "=&s"(y) : "s"(rs), "s"(chunk * 8u));
+    };
+    rank_v16u yv;
+    request(rsrc_of(A.yc + (size_t)wah_first * A.yc_stride, row_bytes), cg0, yv);
     for (uint32_t j = 0; j < n_wah; ++j) {
         const uint32_t rank = wah_first + j;
-        const uint32_t line = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.wah_lines[rank]);
-        const uint32_t Z2 = ROW_BYTES + 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)A.wah_z[rank]);
+        const uint32_t line = (uint32_t)__builtin_amdgcn_readfirstlane((int)line_v);
+        const uint32_t Z2 = ROW_BYTES + 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)z_v);
+        const uint32_t ob0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ob_v);
         const rank_v4u rs_y = rsrc_of(A.yc + (size_t)rank * A.yc_stride, row_bytes);
+        const uint32_t rank_n = wah_first + (j + 1u < n_wah ? j + 1u : j);  // (the last line asks for itself again: unconditional loads)
+        line_v = A.wah_lines[rank_n];
+        z_v = A.wah_z[rank_n];
+        ob_v = (uint32_t)A.ypre[(size_t)rank_n * A.yc_stride + pre_idx];
         // The key bits reach the waves through scalar loads of rows nothing has touched before: left alone every group of
-        // every line waits out a round trip to memory (the first form of this kernel: 8.2 us a line, 40 ms at configs[2]).
-        // One coalesced vector load per thread pulls the row of line j + 2 into L2 two lines ahead (as k_chain_rank_enc does).
+        // every line waits out a round trip to memory.  One coalesced vector load per thread pulls the row of line j + 2
+        // into L2 two lines ahead (as k_chain_rank_enc does).
         uint2 pf;
         {
             const uint32_t jp = j + 2u < n_wah ? j + 2u : j;
             const uint2* rowp = A.yc + (size_t)(wah_first + jp) * A.yc_stride;
             pf = rowp[tid < A.yc_stride ? tid : 0u];
         }
-        // The key bits of group g + 1 travel while group g is scattered.  Written out as asm: left to the compiler every
-        // group's loads are hoisted to the top of the line (8 x 16 SGPRs: spilled lane by lane), and scalar loads return out
-        // of order, so the wait for group g stands in front of the request for g + 1.
-        auto request = [&](uint32_t chunk, rank_v16u& y) {
-            asm volatile("s_buffer_load_dwordx16 %0, %1, %2" : "=&s"(y) : "s"(rs_y), "s"(chunk * 8u));
-        };
+        // The key bits of group g + 1 travel while group g is scattered (the first group: since the end of the line before).
+        // Written out as asm: left to the compiler every group's loads are hoisted to the top of the line (8 x 16 SGPRs:
+        // spilled lane by lane), and scalar loads return out of order, so the wait for group g stands in front of the
+        // request for g + 1.
         // formed inside the line (hoisted out of it, the per-chunk scalars of all 64 chunks live in SGPRs the kernel does
         // not have: they were spilled lane by lane and read back with a v_readlane each)
         uint32_t cg0_l = cg0;
         asm volatile("" : "+s"(cg0_l));
-        rank_v16u yv;
-        request(cg0_l, yv);
         // Byte addresses, in the scattered array, of where the next zero and the next one of my wave's positions go: the
         // prefix of my first chunk starts them, every chunk moves them on by what it held (a scalar instruction a chunk,
         // where the per-chunk prefixes cost four: the scalar unit issues one instruction per SIMD every fourth clock, like
         // the vector unit, and a chunk of zeros is otherwise three scalar and one vector instruction)
-        uint32_t z2, o2;
-        {
-            const uint32_t ob0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)A.ypre[(size_t)rank * A.yc_stride + (cg0_l < nch ? cg0_l : 0u)]);
-            z2 = ROW_BYTES + (cg0_l * 64u - (cg0_l < nch ? ob0 : 0u)) * 2u;
-            o2 = Z2 + ob0 * 2u;
-        }
+        uint32_t z2 = ROW_BYTES + (cg0_l * 64u - (cg0_l < nch ? ob0 : 0u)) * 2u, o2 = Z2 + ob0 * 2u;
         static_for<0, E / G>([&](auto gcn) {
             constexpr int g0 = decltype(gcn)::value * G;
             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(yv));
             rank_v16u yn = yv;
-            if constexpr (g0 + G < E) request(cg0_l + (uint32_t)(g0 + G), yn);
+            if constexpr (g0 + G < E)
+                request(rs_y, cg0_l + (uint32_t)(g0 + G), yn);
+            else
+                request(rsrc_of(A.yc + (size_t)rank_n * A.yc_stride, row_bytes), cg0_l, yn);  // the next line's first group, across the barriers
             if ((uint32_t)g0 < my_chunks) {
                 uint64_t yq[G];
                 static_for<0, G>([&](auto ecn) {
