@@ -238,38 +238,6 @@ def test_block_batched_calls_equal_single_call():
         binding.check(L.xsi_hip_ctx_set_workspace_budget(h, 0))
 
 
-@pytest.mark.parametrize("n_haps,n_blocks,block_len,force", [
-    (50000, 3, 700, dict()),                                  # long-row family of the ranged chain, 8 ranges
-    (64976, 2, 1100, dict(XSI_RANK_WG_MIN_BLOCKS="1")),       # one workgroup per block, ramp + equal ranges
-    (50000, 3, 700, dict(XSI_DEC_PHASES="5")),                # ranges that do not divide the lines
-])
-def test_decode_gt_composes_finished_ranges_under_the_chain(n_haps, n_blocks, block_len, force, monkeypatch):
-    """Round 6: xsi_hip_decode_gt composes the int32 rows of the lines a range of the phased chain has
-    finished on a stream of its own while the next range runs (the chain is bound by its per-line latency, the composition
-    by HBM).  Rows, value counts and allele counts equal those of the serial call (XSI_GT_NO_OVERLAP=1) and the source."""
-    import gpu_util as G
-    for k, v in force.items():
-        monkeypatch.setenv(k, v)
-    n_lines = n_blocks * block_len - 13
-    bits, packed, stride = _device_synth(n_haps, n_lines, 23)
-    n = n_haps // 2
-    p = G.params(n, block_len, n_haps // 1000)
-    region, offs, res = G.encode_packed(packed, n_haps, p)
-    image = G.assemble_file(region, offs, p, n_lines, n_lines, ["S%d" % i for i in range(n)])
-    nal = [2] * n_lines
-    monkeypatch.delenv("XSI_GT_NO_OVERLAP", raising=False)
-    rows_o, counts_o = G.decode_gt(image, nal)
-    monkeypatch.setenv("XSI_GT_NO_OVERLAP", "1")
-    rows_s, counts_s = G.decode_gt(image, nal)
-    src = synth.bits_to_gt(bits, 1)
-    for i in range(n_lines):
-        assert len(rows_o[i]) == n_haps == len(rows_s[i])
-        assert np.array_equal(rows_o[i], src[i]), "overlapped call, line %d" % i
-        assert np.array_equal(rows_s[i], src[i]), "serial call, line %d" % i
-    assert np.array_equal(counts_o, counts_s)
-    assert np.array_equal(counts_o[:, 1], bits.sum(1))
-
-
 def test_batched_decode_keeps_the_workspace_within_the_budget():
     """the batch-cutting pre-pass of xsi_hip_decode_packed must not size the expanded-row buffer by the
     WHOLE block range.  A fresh context (its row buffer has never grown) decodes 11 blocks under a budget of about

@@ -90,12 +90,6 @@ void xsi_hip_ctx_destroy(xsi_hip_ctx* c) {
         (void)hipStreamSynchronize(c->side2);
         (void)hipStreamDestroy(c->side2);
     }
-    if (c->side3) {
-        (void)hipStreamSynchronize(c->side3);
-        (void)hipStreamDestroy(c->side3);
-    }
-    if (c->ev_range) (void)hipEventDestroy(c->ev_range);
-    if (c->ev_composed) (void)hipEventDestroy(c->ev_composed);
     for (auto e : c->ev_phase) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -112,7 +106,6 @@ int xsi_hip_ctx_synchronize(xsi_hip_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->side) HIP_TRY(hipStreamSynchronize(c->side));  // normally already joined; covers error exits
     if (c->side2) HIP_TRY(hipStreamSynchronize(c->side2));
-    if (c->side3) HIP_TRY(hipStreamSynchronize(c->side3));
     return XSI_OK;
 }
 
@@ -1048,10 +1041,6 @@ static int run_wah_phases(xsi_hip_ctx* ctx, const uint8_t* f, DecodePlan& P, uin
         const uint32_t* tab = d_tab + (size_t)p * (3u * nb + 1u);
         if (p) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_phase[p], 0));
         HIP_TRY(launch_rank_decode_phase(s, P.d_blocks, nb, L, out, stride_w, tab, tab + nb, d_state));
-        if (ctx->after_range) {  // (xsi_hip_decode_gt: the lines this range has finished are composed while the next one runs)
-            int rc = ctx->after_range(p, K);
-            if (rc) return rc;
-        }
     }
     return XSI_OK;
 }

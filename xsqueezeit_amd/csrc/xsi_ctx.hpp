@@ -4,7 +4,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -61,11 +60,6 @@ struct xsi_hip_ctx {
     uint32_t reencode_ranges = 0;     // block ranges the last xsi_hip_reencode walked the file in
     // optional side output of the encode entry points (xsi_hip_ctx_set_block_sizes_out): bytes of every block of the call
     // before its pad to 4; `pos` = blocks of the running call already encoded (a call may run as several batches)
-    // xsi_hip_decode_gt composes the lines a range of the phased chain has finished while the next range runs: run_wah_phases
-    // calls this behind the launch of range p of K (the plan's phase_tab holds the ranges); set for the duration of one call
-    std::function<int(uint32_t p, uint32_t K)> after_range;
-    hipStream_t side3 = nullptr;      // the stream those compose launches go to (created on first use)
-    hipEvent_t ev_range = nullptr, ev_composed = nullptr;
     uint32_t* block_sizes_out = nullptr;
     uint64_t block_sizes_cap = 0, block_sizes_pos = 0;
 };
@@ -144,7 +138,7 @@ int dot_planes(xsi_hip_ctx* ctx, const DecodePlan& P, const uint32_t* planes, ui
 int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D, const uint32_t* d_first_bin,
                   const uint32_t* d_n_allele, uint32_t n_out, int32_t* d_gt_out, uint64_t gt_stride,
                   uint32_t* d_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles,
-                  const uint32_t* d_out_index = nullptr, hipStream_t on_stream = nullptr);
+                  const uint32_t* d_out_index = nullptr);
 int select_samples(xsi_hip_ctx* ctx, const int32_t* d_rows, uint64_t row_stride, const uint32_t* d_line_ngt,
                    uint32_t n_lines, uint32_t n_samples, const uint32_t* d_sel, uint32_t n_sel, int32_t* d_out,
                    uint64_t out_stride, uint32_t* d_ac, uint32_t n_alt);

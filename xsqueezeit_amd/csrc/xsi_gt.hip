@@ -1118,8 +1118,7 @@ int decode_all_planes(xsi_hip_ctx* ctx, const void* d_file, DecodePlan& P, Decod
 // int32 rows for n_out BCF lines given (first binary line, n_allele) per line (device arrays).
 int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D, const uint32_t* d_first_bin,
                   const uint32_t* d_n_allele, uint32_t n_out, int32_t* d_gt_out, uint64_t gt_stride,
-                  uint32_t* d_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles, const uint32_t* d_out_index,
-                  hipStream_t on_stream) {
+                  uint32_t* d_line_ngt, uint64_t* d_allele_counts, uint32_t max_alleles, const uint32_t* d_out_index) {
     if (!n_out) return XSI_OK;
     ComposeArgs C{};
     C.planes = D.planes;
@@ -1145,11 +1144,11 @@ int compose_lines(xsi_hip_ctx* ctx, const DecodePlan& P, const DecodedPlanes& D,
     C.allele_counts = d_allele_counts;
     C.max_alleles = max_alleles;
     C.out_index = d_out_index;
-    if (!on_stream) stage_mark(ctx, XSI_ST_GT_COMPOSE);  // (stage events live on the context's stream)
+    stage_mark(ctx, XSI_ST_GT_COMPOSE);
     uint32_t splits = (P.L.N + 2047u) / 2048u;  // >= 8 values per thread
     if (splits > 2048u / n_out) splits = 2048u / n_out;
     if (splits < 1u) splits = 1u;
-    k_compose_gt<<<dim3(n_out, splits), dim3(256), 0, on_stream ? on_stream : ctx->stream>>>(C);
+    k_compose_gt<<<dim3(n_out, splits), dim3(256), 0, ctx->stream>>>(C);
     HIP_TRY(hipGetLastError());
     return XSI_OK;
 }
@@ -1433,110 +1432,11 @@ int xsi_hip_decode_gt(xsi_hip_ctx* ctx, const void* d_file, uint64_t file_len, u
     // before any error return below can unwind this frame
     HIP_TRY(hipStreamSynchronize(s));
     DecodedPlanes DPn;
-    // Overlap of the two halves: the chain is bound by its own per-line latency on a few CUs' worth of
-    // workgroups, the composition of the int32 rows by HBM.  The phased chain finishes every block's lines range by range
-    // (run_wah_phases); the lines a range has finished are composed on a stream of their own while the next range runs, so
-    // that what shows of the composition is the last range's share.  Blocks without side channels only (those matrices
-    // are decoded behind the chain); rows and counts are those of the serial call (same kernel, other launch bounds).
-    struct Overlap {
-        std::vector<uint32_t> wah_lines, done, fb, na, oi;
-        uint32_t *d_fb = nullptr, *d_na = nullptr, *d_oi = nullptr, filled = 0, launches = 0;
-    } ov;
-    const bool overlap = !P.has_side && n_bcf >= 1024u && P.n_wah && !tuning_env("XSI_GT_NO_OVERLAP");
-    if (overlap) {
-        ov.wah_lines.resize(P.n_wah);
-        HIP_TRY(hipMemcpyAsync(ov.wah_lines.data(), P.L.wah_lines, 4ull * P.n_wah, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        ov.done.resize(P.n_blocks);
-        for (uint32_t b = 0; b < P.n_blocks; ++b) ov.done[b] = P.blocks_h[b].first_bcf;
-        ov.fb.resize(n_bcf);
-        ov.na.resize(n_bcf);
-        ov.oi.resize(n_bcf);
-        WS(ov.d_fb, "gt.ov_first_bin", 4ull * n_bcf);
-        WS(ov.d_na, "gt.ov_nallele", 4ull * n_bcf);
-        WS(ov.d_oi, "gt.ov_out_index", 4ull * n_bcf);
-        if (!ctx->side3) HIP_TRY(hipStreamCreateWithFlags(&ctx->side3, hipStreamNonBlocking));
-        if (!ctx->ev_range) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_range, hipEventDisableTiming));
-        if (!ctx->ev_composed) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_composed, hipEventDisableTiming));
-    }
-    StreamSyncGuard ov_guard(ctx->side3 ? ctx->side3 : s);  // (ov's vectors are read by asynchronous copies until the join below)
-    if (!overlap) ov_guard.release();
-    struct HookReset {
-        xsi_hip_ctx* c;
-        ~HookReset() { c->after_range = nullptr; }
-    } hook_reset{ctx};
-    if (overlap) {
-        ctx->after_range = [&](uint32_t p, uint32_t K) -> int {
-            const uint32_t nb = P.n_blocks;
-            const uint32_t* start = P.phase_tab.data() + (size_t)p * (3u * nb + 1u);
-            const uint32_t* cnt = start + nb;
-            const uint32_t first = ov.filled;
-            for (uint32_t b = 0; b < nb; ++b) {
-                const DecBlock& B = P.blocks_h[b];
-                if (B.error) continue;
-                const uint32_t end_rank = start[b] + cnt[b];
-                // binary lines of the block in front of its first WAH line that has not been through the chain
-                const uint32_t bin_bound = (p + 1u == K || end_rank >= B.wah_first + B.n_wah) ? B.first_bin + B.n_bin : ov.wah_lines[end_rank];
-                uint32_t l = ov.done[b];
-                const uint32_t l_end = B.first_bcf + B.n_bcf;
-                while (l < l_end && first_bin[l] + (h_n_allele[l] - 1u) <= bin_bound) {
-                    ov.fb[ov.filled] = first_bin[l];
-                    ov.na[ov.filled] = h_n_allele[l];
-                    ov.oi[ov.filled] = l;
-                    ++ov.filled;
-                    ++l;
-                }
-                ov.done[b] = l;
-            }
-            const uint32_t n_new = ov.filled - first;
-            if (!n_new) return XSI_OK;
-            hipStream_t cs = ctx->side3;
-            HIP_TRY(hipEventRecord(ctx->ev_range, s));  // behind the chain launch of this range
-            HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_range, 0));
-            if (!ov.launches) HIP_TRY(hipStreamWaitEvent(cs, ctx->ev_join, 0));  // the sparse lines' rows (side stream of decode_planes)
-            HIP_TRY(hipMemcpyAsync(ov.d_fb + first, ov.fb.data() + first, 4ull * n_new, hipMemcpyHostToDevice, cs));
-            HIP_TRY(hipMemcpyAsync(ov.d_na + first, ov.na.data() + first, 4ull * n_new, hipMemcpyHostToDevice, cs));
-            HIP_TRY(hipMemcpyAsync(ov.d_oi + first, ov.oi.data() + first, 4ull * n_new, hipMemcpyHostToDevice, cs));
-            // (planes and stride are known before the call: decode_all_planes fills DPn at its start)
-            int rc2 = compose_lines(ctx, P, DPn, ov.d_fb + first, ov.d_na + first, n_new, d_gt_out, gt_stride, d_line_ngt,
-                                    d_allele_counts, max_alleles, ov.d_oi + first, cs);
-            if (rc2) return rc2;
-            ++ov.launches;
-            return XSI_OK;
-        };
-    }
     rc = decode_all_planes(ctx, d_file, P, &DPn);
-    ctx->after_range = nullptr;
     if (rc) return rc;
-    if (overlap && ov.launches) {
-        // whatever the ranges left (nothing, as a rule: the last range takes every remaining line) on the same stream, then join
-        uint32_t first = ov.filled;
-        for (uint32_t b = 0; b < P.n_blocks; ++b)
-            for (uint32_t l = ov.done[b]; l < P.blocks_h[b].first_bcf + P.blocks_h[b].n_bcf; ++l) {
-                ov.fb[ov.filled] = first_bin[l];
-                ov.na[ov.filled] = h_n_allele[l];
-                ov.oi[ov.filled] = l;
-                ++ov.filled;
-            }
-        if (ov.filled > first) {
-            const uint32_t n_new = ov.filled - first;
-            HIP_TRY(hipEventRecord(ctx->ev_range, s));
-            HIP_TRY(hipStreamWaitEvent(ctx->side3, ctx->ev_range, 0));
-            HIP_TRY(hipMemcpyAsync(ov.d_fb + first, ov.fb.data() + first, 4ull * n_new, hipMemcpyHostToDevice, ctx->side3));
-            HIP_TRY(hipMemcpyAsync(ov.d_na + first, ov.na.data() + first, 4ull * n_new, hipMemcpyHostToDevice, ctx->side3));
-            HIP_TRY(hipMemcpyAsync(ov.d_oi + first, ov.oi.data() + first, 4ull * n_new, hipMemcpyHostToDevice, ctx->side3));
-            rc = compose_lines(ctx, P, DPn, ov.d_fb + first, ov.d_na + first, n_new, d_gt_out, gt_stride, d_line_ngt, d_allele_counts,
-                               max_alleles, ov.d_oi + first, ctx->side3);
-            if (rc) return rc;
-        }
-        stage_mark(ctx, XSI_ST_GT_COMPOSE);  // what shows of the composition: the wait for its stream
-        HIP_TRY(hipEventRecord(ctx->ev_composed, ctx->side3));
-        HIP_TRY(hipStreamWaitEvent(s, ctx->ev_composed, 0));
-    } else {
-        rc = compose_lines(ctx, P, DPn, d_first_bin, d_nallele, n_bcf, d_gt_out, gt_stride, d_line_ngt, d_allele_counts,
-                           max_alleles);
-        if (rc) return rc;
-    }
+    rc = compose_lines(ctx, P, DPn, d_first_bin, d_nallele, n_bcf, d_gt_out, gt_stride, d_line_ngt, d_allele_counts,
+                       max_alleles);
+    if (rc) return rc;
     stage_mark(ctx, -1);
     if (h_line_ngt) HIP_TRY(hipMemcpyAsync(h_line_ngt, d_line_ngt, 4ull * n_bcf, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
