@@ -1294,10 +1294,14 @@ static int encode_gt_impl(xsi_hip_ctx* ctx, const xsi_encode_params* p, const in
     WS(d_bin_nbits, "gt.bin_nbits", 4ull * n_bin);
     // what the unpack kernel reads goes first; the per-binary-line arrays (read by the classification behind it) are
     // formed and sent while it runs; one synchronisation behind them.
+    // From here to the synchronisation behind the second pair of copies, asynchronous copies read the caller's arrays and
+    // this frame's vectors: every exit in between (a workspace allocation that fails, a launch error) waits for the stream
+    // first (the guard's destructor), or the DMA would read memory that has been handed back.
+    std::vector<uint32_t> parent, nbits_bin;  // (declared in front of the guard: destroyed behind its wait)
+    StreamSyncGuard copies_in_flight(s);
     HIP_TRY(hipMemcpyAsync(d_nbits, h_ngt, 4ull * n_bcf, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_nallele, h_n_allele, 4ull * n_bcf, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_first_bin, first_bin.data(), 4ull * n_bcf, hipMemcpyHostToDevice, s));
-    std::vector<uint32_t> parent, nbits_bin;
 
     UnpackArgs U{};
     U.gt = d_gt;
@@ -1337,6 +1341,7 @@ static int encode_gt_impl(xsi_hip_ctx* ctx, const xsi_encode_params* p, const in
     HIP_TRY(hipMemcpyAsync(d_parent, parent.data(), 4ull * n_bin, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_bin_nbits, nbits_bin.data(), 4ull * n_bin, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));  // every copy has left the host vectors (an error return below may destroy them early)
+    copies_in_flight.release();
 
     EncLines L{};
     L.planes = U.planes;
