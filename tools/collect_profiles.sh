@@ -5,7 +5,7 @@
 #   gpurun -- bash tools/collect_profiles.sh r03
 # Output lands in gpurun_out/<tag>_*; tools/summarize_profile.py folds it into profiles/.
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:?not on a gpurun box}"
 O=gpurun_out
