@@ -538,10 +538,9 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
         if (k > 64) k = 64;
         if (k > fit) k = fit;
         if (const char* e = tuning_env("XSI_WRITER_BATCH_BLOCKS")) k = strtoull(e, nullptr, 10);
-        // --zstd: a block's compression (75 ms for 5 MB at level 7) starts when its batch has been encoded, so batches of half
-        // the size put the pool to work earlier and shorten the tail behind the last append (four-block batches measured
-        // slower again: a batch costs the chain's latency whatever its size)
-        if (p->zstd_level && k > 2 && !tuning_env("XSI_WRITER_BATCH_BLOCKS")) k = (k + 1) / 2;
+        // (--zstd keeps these batches: a batch costs the chain's latency whatever its size - batches of four and of six
+        // blocks measured 1.28 and 1.06 G cells/s at 5008 haplotypes x 100 000 lines where eleven give 2.7 -, and the pool takes
+        // a batch's blocks side by side)
         if (k < 1) k = 1;
         w->batch_blocks = (uint32_t)k;
     }
@@ -748,6 +747,10 @@ struct xsi_accessor {
     };
     // (a list: entries keep their address while the read-ahead thread inserts others)
     std::list<CachedBlock> cache;
+    // the cache entry of cur_block (nullptr: none / the block lives in the context workspace): entries keep their address and
+    // the read-ahead thread never evicts this one, so the per-query paths read it without the lock (the thread holds the lock
+    // across a hipMalloc of hundreds of megabytes: milliseconds)
+    CachedBlock* cur_entry = nullptr;
     std::mutex cache_m;  // guards cache, cache_bytes, tick: the read-ahead thread inserts what it has decoded
     uint64_t prefix_decodes = 0, prefix_extensions = 0;
     size_t cache_bytes = 0, cache_budget = 0;
@@ -986,6 +989,7 @@ static bool accessor_cache_store(xsi_accessor* a, uint64_t block, const PartialI
     a->P = e.P;
     a->D = e.D;
     a->cache.push_back(std::move(e));
+    a->cur_entry = &a->cache.back();  // (the callers make this block the current one)
     return true;
 }
 
@@ -1016,12 +1020,8 @@ static bool accessor_sequential(const xsi_accessor* a) { return a->seq_run >= 4u
 
 static int accessor_ensure_lines(xsi_accessor* a, uint32_t need_bin) {
     if (a->cur_block < 0 || a->cur_in_workspace) return XSI_OK;
-    xsi_accessor::CachedBlock* e;
-    {
-        std::lock_guard<std::mutex> lk(a->cache_m);
-        e = accessor_find(a, (uint64_t)a->cur_block);  // (entries keep their address; the read-ahead thread never evicts this one)
-    }
-    if (!e || !e->partial) return XSI_OK;
+    xsi_accessor::CachedBlock* e = a->cur_entry;
+    if (!e || e->block != (uint64_t)a->cur_block || !e->partial) return XSI_OK;
     const uint32_t n_wah = e->P.n_wah;
     // a sequential scan will read the whole block: one continuation to its end instead of a dozen growing ones
     const uint32_t target = accessor_sequential(a) && prefix_target(e->wah_before, n_wah, e->wah_done, need_bin) > e->wah_done
@@ -1126,6 +1126,7 @@ static int accessor_load_block(xsi_accessor* a, uint64_t block, uint32_t need_bi
             a->D = e->D;
             a->biallelic = e->biallelic;
             a->cur_block = (int64_t)block;
+            a->cur_entry = e;
             a->cur_in_workspace = false;
             a->win_n = 0;
             ++a->cache_hits;
@@ -1164,6 +1165,7 @@ static int accessor_load_block(xsi_accessor* a, uint64_t block, uint32_t need_bi
     int rc = accessor_block_image(a, block, &img, &len, &blk);
     if (rc) return rc;
     a->cur_block = -1;
+    a->cur_entry = nullptr;
     rc = decode_prepare(a->ctx, img, len, blk, 1, &a->P);
     if (rc) return rc;
     lap("decode_prepare");
@@ -1444,7 +1446,10 @@ int xsi_accessor_set_cache_bytes(xsi_accessor* a, uint64_t bytes) {
     a->cache_budget = (size_t)bytes;
     while (a->cache_bytes > a->cache_budget && !a->cache.empty()) {
         CacheIt lru = accessor_lru(a, -1);
-        if (a->cur_block >= 0 && !a->cur_in_workspace && lru->block == (uint64_t)a->cur_block) a->cur_block = -1;
+        if (a->cur_block >= 0 && !a->cur_in_workspace && lru->block == (uint64_t)a->cur_block) {
+            a->cur_block = -1;
+            a->cur_entry = nullptr;
+        }
         accessor_evict(a, lru);
     }
     a->pf_block = -1;  // (what was read ahead may be gone)
