@@ -402,6 +402,7 @@ def run_config4(args, real_stdout, emit=True):
         return {"lines": n_scan, "seconds": t_scan, "lines_per_s": n_scan / t_scan, "cells_per_s": float(N) * n_scan / t_scan,
                 "stalls_over_1ms": int((lat > 1e-3).sum()), "stall_ms_total": float(lat[lat > 1e-3].sum() * 1e3),
                 "max_call_ms": float(lat.max() * 1e3), "median_call_us": float(np.median(lat) * 1e6),
+                "stall_calls": [[int(i), round(float(lat[i]) * 1e3, 2)] for i in np.nonzero(lat > 1e-3)[0][:24]],
                 "readaheads_started": int(ra1.value - ra0.value), "first_touches_served_by_readahead": int(rh1.value - rh0.value),
                 "rows_match_source": ok}
 

@@ -37,6 +37,27 @@ int set_error(int code, const char* fmt, ...) {
                                                __FILE__, __LINE__);                                          \
     } while (0)
 
+namespace xsi {
+int ctx_make_low_priority(xsi_hip_ctx* c) {
+    if (!c || !c->owns_stream) return set_error(XSI_ERR_ARG, "ctx_make_low_priority: a context with a stream of its own");
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t a = nullptr, b = nullptr;
+    HIP_TRY(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, least));
+    hipError_t e = hipStreamCreateWithPriority(&b, hipStreamNonBlocking, least);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(a);
+        return set_error(XSI_ERR_HIP, "hipStreamCreateWithPriority: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamDestroy(c->stream);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    c->stream = a;
+    c->side = b;
+    c->low_priority = true;
+    return XSI_OK;
+}
+}  // namespace xsi
+
 extern "C" {
 
 int xsi_hip_abi_version(void) { return XSI_HIP_ABI_VERSION; }
@@ -1016,7 +1037,12 @@ static int run_wah_phases(xsi_hip_ctx* ctx, const uint8_t* f, DecodePlan& P, uin
     uint32_t* d_tab;
     WS(d_tab, "dec.phase_tab", 4ull * P.phase_tab.size());
     HIP_TRY(hipMemcpyAsync(d_tab, P.phase_tab.data(), 4ull * P.phase_tab.size(), hipMemcpyHostToDevice, s));
-    if (!ctx->side2) HIP_TRY(hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
+    if (!ctx->side2) {
+        int least = 0, greatest = 0;
+        if (ctx->low_priority) HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(ctx->low_priority ? hipStreamCreateWithPriority(&ctx->side2, hipStreamNonBlocking, least)
+                                  : hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
+    }
     while (ctx->ev_phase.size() < (size_t)K + 1u) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));

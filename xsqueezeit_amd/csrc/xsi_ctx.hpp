@@ -38,6 +38,7 @@ struct xsi_hip_ctx {
     // second side stream + events of the phased decode: the WAH expansion of the next range of lines runs
     // underneath the chain of the current one (created on first use)
     hipStream_t side2 = nullptr;
+    bool low_priority = false;       // the context's own streams were made at the device's lowest priority (ctx_make_low_priority)
     std::vector<hipEvent_t> ev_phase;
     struct Buf {
         void* p = nullptr;
@@ -93,6 +94,9 @@ void stage_mark(xsi_hip_ctx* c, int stage);
 // after a stream sync: fold the recorded events into stage_ms / stage_n
 void stage_collect(xsi_hip_ctx* c);
 int ws_ensure(xsi_hip_ctx* c, const char* name, size_t bytes, void** out);
+// background work (the accessor's read-ahead): the context's own stream and side streams at the lowest priority of the device,
+// so that a foreground context's kernels are dispatched first.  Only for a context that owns its stream and has not run yet.
+int ctx_make_low_priority(xsi_hip_ctx* c);
 int pinned_ensure(xsi_hip_ctx* c, size_t bytes, void** out);
 
 struct DecodePlan {

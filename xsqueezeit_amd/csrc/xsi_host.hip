@@ -1102,6 +1102,9 @@ static void accessor_readahead_maybe(xsi_accessor* a, uint64_t cur) {
             a->pf_block = (int64_t)next;  // (not tried again for this block)
             return;
         }
+        // its kernels go to the CUs the foreground leaves idle: the compose kernel of a query is dispatched first (without
+        // this a query that falls into the read-ahead's expansion or fill waits milliseconds for its turn)
+        (void)xsi::ctx_make_low_priority(a->pf_ctx);
     }
     a->pf_block = (int64_t)next;
     ++a->readahead_started;
