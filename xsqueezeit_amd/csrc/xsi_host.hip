@@ -236,6 +236,9 @@ struct xsi_writer {
     uint64_t N = 0;
     // two device batches of up to batch_blocks blocks of int32 rows
     uint32_t batch_blocks = 1;
+    // blocks the batch being filled may take: batch_blocks, except that under --zstd the first batches are short (2, 4, 8, ...)
+    // so that the compression pool - whose last block ends the file's tail - gets its first blocks early
+    uint32_t batch_limit = 1;
     int32_t* d_rows[2] = {nullptr, nullptr};
     std::vector<uint32_t> ngt[2], n_allele[2];
     int cur = 0;                    // batch being filled
@@ -447,6 +450,7 @@ static int writer_flush_batch(xsi_writer* w) {
         }
     });
     w->cur ^= 1;
+    if (w->batch_limit < w->batch_blocks) w->batch_limit = w->batch_limit * 2u < w->batch_blocks ? w->batch_limit * 2u : w->batch_blocks;
     w->lines_in_batch = w->lines_on_device = 0;
     w->ngt[w->cur].clear();
     w->n_allele[w->cur].clear();
@@ -558,6 +562,7 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
         w->zstd_max_pending = nt > 1 ? (size_t)2 * w->batch_blocks : 0;
         w->h_sizes.resize(w->batch_blocks);
     }
+    w->batch_limit = (p->zstd_level && w->batch_blocks > 2 && !tuning_env("XSI_WRITER_BATCH_BLOCKS")) ? 2u : w->batch_blocks;
     hipError_t e = hipSuccess;
     w->bit_stride = (uint32_t)(((w->N + 1023u) / 1024u) * 128u);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&w->d_rows[i], block_bytes * w->batch_blocks);
@@ -594,7 +599,7 @@ int32_t* xsi_writer_row_buffer(xsi_writer* w) {
         return nullptr;
     }
     // check_flush_block, xsi_factory.hpp:527-539, K blocks at a time
-    if (w->lines_in_batch == (uint64_t)w->p.block_len * w->batch_blocks) {
+    if (w->lines_in_batch == (uint64_t)w->p.block_len * w->batch_limit) {
         if (writer_flush_batch(w)) return nullptr;
     }
     return w->h_chunk + (size_t)w->chunk_fill * w->N;
@@ -605,7 +610,7 @@ static int writer_commit(xsi_writer* w, uint32_t ngt, uint32_t n_allele, bool li
     if (ngt != w->p.n_samples && ngt != 2u * w->p.n_samples)
         return set_error(XSI_ERR_ARG, "PLOIDY ERROR: %u values for %u samples", ngt, w->p.n_samples);
     if (n_allele < 2) return set_error(XSI_ERR_UNSUPPORTED, "lines without an ALT allele are rejected (see xsi_hip_encode_gt)");
-    if (w->lines_in_batch == (uint64_t)w->p.block_len * w->batch_blocks)
+    if (w->lines_in_batch == (uint64_t)w->p.block_len * w->batch_limit)
         return set_error(XSI_ERR_ARG, "writer_commit_row without xsi_writer_row_buffer");
     if (!line_is_packed) {
         // the caller filled the int32 slot (bcf_get_genotypes' destination): pack from it when the line allows, so
