@@ -1018,11 +1018,12 @@ static uint32_t bin_valid_of(const std::vector<uint32_t>& wah_before, uint32_t n
     return (uint32_t)(std::upper_bound(wah_before.begin() + 1, wah_before.end(), k) - (wah_before.begin() + 1));
 }
 
+// four or more single-line queries have followed one another line by line (accessor_line_view counts them)
+static bool accessor_sequential(const xsi_accessor* a) { return a->seq_run >= 4u && !tuning_env("XSI_ACCESSOR_NO_READAHEAD"); }
+
 // The current block is a prefix-decoded cache entry and the caller is about to read binary lines below need_bin (0: all):
 // run the chain on from where it stopped (the reference's seek does the same replay, one line at a time, on the host:
 // accessor_internals_new.hpp:154-196).
-static bool accessor_sequential(const xsi_accessor* a) { return a->seq_run >= 4u && !tuning_env("XSI_ACCESSOR_NO_READAHEAD"); }
-
 static int accessor_ensure_lines(xsi_accessor* a, uint32_t need_bin) {
     if (a->cur_block < 0 || a->cur_in_workspace) return XSI_OK;
     xsi_accessor::CachedBlock* e = a->cur_entry;
