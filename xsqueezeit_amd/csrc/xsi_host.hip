@@ -1113,13 +1113,17 @@ static void accessor_readahead_maybe(xsi_accessor* a, uint64_t cur) {
         (void)xsi::ctx_make_low_priority(a->pf_ctx);
     }
     a->pf_block = (int64_t)next;
+    try {  // (a thread that cannot be started is a read-ahead that does not happen, not an exception through the C ABI)
+        a->pf_thread = std::thread([a, next] {
+            try {
+                accessor_readahead_body(a, next);
+            } catch (...) {
+            }
+        });
+    } catch (...) {
+        return;
+    }
     ++a->readahead_started;
-    a->pf_thread = std::thread([a, next] {
-        try {
-            accessor_readahead_body(a, next);
-        } catch (...) {
-        }
-    });
     a->pf_started = true;
 }
 
