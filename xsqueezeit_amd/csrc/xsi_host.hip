@@ -556,9 +556,17 @@ int xsi_writer_open(xsi_writer** out, xsi_hip_ctx* ctx, const char* path, const 
         if (nt > 16) nt = 16;
         if (const char* e = tuning_env("XSI_WRITER_ZSTD_THREADS")) nt = (unsigned)atoi(e);
         if (nt < 1) nt = 1;
-        w->zpool = new ZstdPool();
-        w->zpool->prof = tuning_env("XSI_WRITER_PROF") != nullptr;
-        w->zpool->start(nt, (int)p->zstd_level);
+        try {  // (threads that cannot be started: an error code, not an exception through the C ABI)
+            w->zpool = new ZstdPool();
+            w->zpool->prof = tuning_env("XSI_WRITER_PROF") != nullptr;
+            w->zpool->start(nt, (int)p->zstd_level);
+        } catch (const std::exception& ex) {
+            if (!w->zpool || w->zpool->threads.empty()) {
+                writer_free(w);
+                return set_error(XSI_ERR_IO, "writer_open: the compression pool could not be started: %s", ex.what());
+            }
+            // (some threads run: the pool works with those)
+        }
         w->zstd_max_pending = nt > 1 ? (size_t)2 * w->batch_blocks : 0;
         w->h_sizes.resize(w->batch_blocks);
     }
